@@ -1,0 +1,150 @@
+/*
+ * rag_hip.h — C-ABI of librag_hip.so: the MI355X (gfx950) hybrid-retrieval + rerank engine.
+ *
+ * The reference (gabrielcheda/optimized-rag) is pure Python and has NO FFI of its own; the drop-in
+ * boundary is its Python object graph. Each entry point below names the reference
+ * Python call whose arithmetic it replaces (paths under /root/reference). The Python mirror classes in
+ * optimized-rag_amd/ bind these symbols with ctypes and keep the reference's class/method surface.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; rag_last_error(h) gives the message.
+ *   - plain pointers and sizes only; the caller owns every buffer; nothing throws across the ABI.
+ *   - "_host" pointers are host memory (copied over PCIe inside the call, call is synchronous);
+ *     "_dev"  pointers are device memory on the handle's GPU; those calls are asynchronous on `stream`
+ *     (a hipStream_t passed as void*, NULL = the handle's own stream).
+ *   - one handle = one GPU = one process rank. Concurrent calls on one handle must be serialised by
+ *     the caller (the reference graph is single-threaded, agent/rag_graph.py:506).
+ *   - doc ids are int64 (SQL BIGSERIAL ids, database/migrations/001_initial_schema.sql); scores are
+ *     float64 because the reference computes every score as a Python float.
+ */
+#ifndef RAG_HIP_H
+#define RAG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rag_ctx* rag_handle_t;
+
+#define RAG_OK 0
+#define RAG_ERR_ARG (-1)
+#define RAG_ERR_HIP (-2)
+#define RAG_ERR_STATE (-3)
+#define RAG_ERR_NOMEM (-4)
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+int rag_version(void);
+int rag_device_count(int* n_out);
+/* dim = embedding dimension (1536 for text-embedding-3-small, memory/embeddings.py:324-325). */
+int rag_create(int device_id, int dim, rag_handle_t* out);
+int rag_destroy(rag_handle_t h);
+const char* rag_last_error(rag_handle_t h);
+int rag_synchronize(rag_handle_t h);
+
+/* ---- dense index: replaces the pgvector tables behind
+ *      `ORDER BY dc.embedding <=> %s::vector LIMIT %s`  (rag/document_store.py:448-460)
+ *      `ORDER BY embedding <=> %s::vector LIMIT %s`     (database/operations.py:126-137)
+ * Rows are float32 (pgvector `vector(1536)` is float4). ids may be NULL (id = id_base + row).
+ * Builds in HBM: fp32 master rows, fp16 unit-normalised rows (MFMA operand). Rows with a zero or
+ * non-finite norm score 0.0 against every query (the reference's `return 0.0`, rag/retrieval.py:368-369). */
+int rag_index_load_host(rag_handle_t h, const float* emb_host, const int64_t* ids_host, int64_t id_base,
+                        int64_t n_rows);
+int rag_index_load_dev(rag_handle_t h, const float* emb_dev, const int64_t* ids_dev, int64_t id_base,
+                       int64_t n_rows, void* stream);
+/* Optional multi-tenant filter: tenant_of_row[n_rows] (the `WHERE dc.agent_id = %s`,
+ * rag/document_store.py:457). tenant < 0 in a search = no filter. */
+int rag_index_set_tenants_host(rag_handle_t h, const int32_t* tenant_of_row_host, int64_t n_rows);
+int rag_index_rows(rag_handle_t h, int64_t* n_rows_out);
+/* copy rows' fp32 embeddings back (kills apply_mmr's per-doc re-embedding, rag/nodes/helpers.py:215-223) */
+int rag_index_fetch_rows_host(rag_handle_t h, const int64_t* rows_host, int n, float* out_host);
+
+/* Exact cosine top-k over the resident index, Q queries at once.
+ * Result = what an un-indexed `ORDER BY embedding <=> q LIMIT k` returns: cosine descending, ties by
+ * lower row first; ids_out[Q*k] (-1 padded), rows_out[Q*k] local row numbers (may be NULL),
+ * scores_out[Q*k] = 1 - distance as float64. Identical id sets to the float64 oracle are PROVEN per
+ * query (fp16 MFMA pass + float64 rescore + error-bound check, falling back to an exact scan). */
+int rag_dense_topk_host(rag_handle_t h, const float* q_host, int n_queries, int k, int tenant,
+                        int64_t* ids_out_host, int32_t* rows_out_host, double* scores_out_host);
+int rag_dense_topk_dev(rag_handle_t h, const float* q_dev, int n_queries, int k, int tenant,
+                       int64_t* ids_out_dev, int32_t* rows_out_dev, double* scores_out_dev, void* stream);
+
+/* Counters of the last dense search (device counters are read back: synchronises). */
+typedef struct rag_dense_stats {
+    int32_t n_queries;
+    int32_t proven_fast;      /* proven exact from the top-K' shortlist */
+    int32_t proven_wide;      /* needed the whole candidate buffer      */
+    int32_t exact_scan;       /* fell back to the float64 full scan     */
+    int32_t overflowed;       /* candidate buffer overflowed            */
+    int32_t shortlist;        /* K'                                     */
+    int32_t stages;           /* threshold stages used                  */
+    int32_t reserved;
+    double eps;               /* rigorous |fp16 score - exact| bound    */
+} rag_dense_stats;
+int rag_dense_last_stats(rag_handle_t h, rag_dense_stats* out);
+
+/* Names/launch geometry of the dominant kernel of the last dense search, for bench.py's roofline. */
+int rag_dense_kernel_ms(rag_handle_t h, float* gemm_ms_out, int* gemm_launches_out);
+int rag_set_profiling(rag_handle_t h, int enable);
+
+/* ---- merge of per-shard partial top-k lists (multi-GPU exchange step).
+ * lists: [n_lists][Q][k] (ids int64, scores float64, -1 padded) -> [Q][k] by score desc, id asc. */
+int rag_merge_topk_dev(rag_handle_t h, const int64_t* ids_dev, const double* scores_dev, int n_lists,
+                       int n_queries, int k, int64_t* ids_out_dev, double* scores_out_dev, void* stream);
+
+/* ---- small pairwise cosine in float64: replaces the Python loops
+ *      rag/consistency_checker.py:169-176, rag/context_compressor.py:227-228, rag/reranker.py:167-175,
+ *      rag/nodes/helpers.py:232-243, rag/retrieval.py:253-256.  out[m*n] row-major, 0.0 on zero norm. */
+int rag_pairwise_cosine_host(rag_handle_t h, const float* a_host, int m, const float* b_host, int n, int dim,
+                             double* out_host);
+
+/* ---- reciprocal rank fusion: replaces ReciprocalRankFusion.fuse (rag/reranker.py:224-271).
+ * lists_host: [Q][n_lists][list_len] int64 keys, -1 = padding (only at the tail of a list).
+ * For each query: score[key] += 1.0/(rrf_k+rank) (rank from 1, list order), sort desc, first-seen
+ * order on ties, top_k. Outputs -1 padded; ranks_out[Q][top_k][n_lists] = 1-based rank of the key's first
+ * occurrence in each list (0 = absent) (may be NULL). */
+int rag_rrf_fuse_host(rag_handle_t h, const int64_t* lists_host, int n_queries, int n_lists, int list_len,
+                      int rrf_k, int top_k, int64_t* keys_out_host, double* scores_out_host,
+                      int32_t* ranks_out_host);
+
+/* ---- BM25 over CSR postings: replaces BM25Okapi(tokenized_corpus).get_scores(query) + the /max
+ *      normalisation (rag/retrieval.py:324-347). Postings are term-major CSR, docs ascending per term.
+ *      idf[V] is computed by the host exactly as rank-bm25 does (float64). */
+int rag_bm25_load_host(rag_handle_t h, const int64_t* indptr_host /*V+1*/, const int32_t* doc_host /*nnz*/,
+                       const int32_t* tf_host /*nnz*/, const int32_t* doc_len_host /*N*/,
+                       const double* idf_host /*V*/, int64_t n_docs, int64_t n_terms, double avgdl,
+                       double k1, double b);
+/* term_ptr[Q+1], terms[term_ptr[Q]] (query tokens WITH repeats; -1 = out-of-vocabulary).
+ * scores_out are max-normalised as the reference does; raw_max_out[Q] (may be NULL) is the divisor. */
+int rag_bm25_topk_host(rag_handle_t h, const int32_t* term_ptr_host, const int32_t* terms_host, int n_queries,
+                       int k, int64_t* ids_out_host, int32_t* rows_out_host, double* scores_out_host,
+                       double* raw_max_out_host);
+/* dense scores for a (small) corpus: out[Q][N] raw (un-normalised) BM25, for hybrid_search semantics */
+int rag_bm25_scores_host(rag_handle_t h, const int32_t* term_ptr_host, const int32_t* terms_host, int n_queries,
+                         double* out_host);
+
+/* ---- weighted linear fusion + top-k: replaces rag/retrieval.py:294-322
+ *      hybrid = alpha*semantic + beta*keyword + gamma*temporal, stable sort desc, [:top_k]. */
+int rag_linear_fuse_topk_host(rag_handle_t h, const double* semantic_host, const double* keyword_host,
+                              const double* temporal_host /*NULL = zeros*/, int n, double alpha, double beta,
+                              double gamma, int top_k, int32_t* idx_out_host, double* hybrid_out_host);
+
+/* ---- cross-encoder (BertForSequenceClassification, ms-marco-MiniLM-L-6-v2 shape): replaces
+ *      CrossEncoder.predict (rag/reranker.py:355). Weights are handed over as float32 host arrays in the
+ *      HF state-dict layout (nn.Linear [out,in]); see optimized-rag_amd/cross_encoder.py for the order. */
+typedef struct rag_ce_config {
+    int32_t vocab_size, hidden, layers, heads, ffn, max_pos, type_vocab, reserved;
+    double ln_eps;
+} rag_ce_config;
+int rag_ce_load_host(rag_handle_t h, const rag_ce_config* cfg, const float* const* tensors_host, int n_tensors);
+/* input_ids/token_type_ids: [P][L] int32 (padded), lens[P]; logits_out[P] raw logits (float32). */
+int rag_ce_score_host(rag_handle_t h, const int32_t* input_ids_host, const int32_t* token_type_ids_host,
+                      const int32_t* lens_host, int n_pairs, int seq_len, float* logits_out_host);
+int rag_ce_score_dev(rag_handle_t h, const int32_t* input_ids_dev, const int32_t* token_type_ids_dev,
+                     const int32_t* lens_dev, int n_pairs, int seq_len, float* logits_out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAG_HIP_H */

@@ -1,0 +1,309 @@
+"""ctypes binding of librag_hip.so (include/rag_hip.h). Plain pointers and sizes only.
+
+numpy arrays are passed as host pointers (`*_host` entry points); torch CUDA tensors as device pointers
+(`*_dev` entry points, asynchronous on the current torch stream). PyTorch is used for device memory and
+streams only — never for the arithmetic.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class RagError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "librag_hip.so")
+
+
+class DenseStats(C.Structure):
+    _fields_ = [("n_queries", C.c_int32), ("proven_fast", C.c_int32), ("proven_wide", C.c_int32),
+                ("exact_scan", C.c_int32), ("overflowed", C.c_int32), ("shortlist", C.c_int32),
+                ("stages", C.c_int32), ("reserved", C.c_int32), ("eps", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class CeConfig(C.Structure):
+    _fields_ = [("vocab_size", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32),
+                ("ffn", C.c_int32), ("max_pos", C.c_int32), ("type_vocab", C.c_int32), ("reserved", C.c_int32),
+                ("ln_eps", C.c_double)]
+
+
+_P = C.c_void_p
+_SIGS = {
+    "rag_version": ([], C.c_int),
+    "rag_device_count": ([C.POINTER(C.c_int)], C.c_int),
+    "rag_create": ([C.c_int, C.c_int, C.POINTER(_P)], C.c_int),
+    "rag_destroy": ([_P], C.c_int),
+    "rag_last_error": ([_P], C.c_char_p),
+    "rag_synchronize": ([_P], C.c_int),
+    "rag_set_profiling": ([_P, C.c_int], C.c_int),
+    "rag_index_load_host": ([_P, _P, _P, C.c_int64, C.c_int64], C.c_int),
+    "rag_index_load_dev": ([_P, _P, _P, C.c_int64, C.c_int64, _P], C.c_int),
+    "rag_index_set_tenants_host": ([_P, _P, C.c_int64], C.c_int),
+    "rag_index_rows": ([_P, C.POINTER(C.c_int64)], C.c_int),
+    "rag_index_fetch_rows_host": ([_P, _P, C.c_int, _P], C.c_int),
+    "rag_dense_topk_host": ([_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P], C.c_int),
+    "rag_dense_topk_dev": ([_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
+    "rag_dense_last_stats": ([_P, C.POINTER(DenseStats)], C.c_int),
+    "rag_dense_kernel_ms": ([_P, C.POINTER(C.c_float), C.POINTER(C.c_int)], C.c_int),
+    "rag_merge_topk_dev": ([_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P], C.c_int),
+    "rag_pairwise_cosine_host": ([_P, _P, C.c_int, _P, C.c_int, C.c_int, _P], C.c_int),
+    "rag_rrf_fuse_host": ([_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P], C.c_int),
+    "rag_bm25_load_host": ([_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double], C.c_int),
+    "rag_bm25_topk_host": ([_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
+    "rag_bm25_scores_host": ([_P, _P, _P, C.c_int, _P], C.c_int),
+    "rag_linear_fuse_topk_host": ([_P, _P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _P, _P], C.c_int),
+    "rag_ce_load_host": ([_P, C.POINTER(CeConfig), C.POINTER(_P), C.c_int], C.c_int),
+    "rag_ce_score_host": ([_P, _P, _P, _P, C.c_int, C.c_int, _P], C.c_int),
+    "rag_ce_score_dev": ([_P, _P, _P, _P, C.c_int, C.c_int, _P, _P], C.c_int),
+}
+
+
+def exported_symbols():
+    """Every entry point include/rag_hip.h declares (tests check the .so exports each of them)."""
+    return sorted(_SIGS)
+
+
+def load_library(path=None):
+    """Load librag_hip.so. Fails loudly when it has not been built (`python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or lib_path()
+    if not os.path.exists(p):
+        raise RagError(f"{p} is missing: build the HIP extension first (__graft_entry__.build()); "
+                       "there is no CPU fallback")
+    lib = C.CDLL(p)
+    for name, (args, res) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError = missing export: loud
+        fn.argtypes = args
+        fn.restype = res
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def _np(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class RagEngine:
+    """One handle = one GPU (one process rank). Thin object wrapper over the C-ABI."""
+
+    def __init__(self, dim, device=0):
+        self.lib = load_library()
+        self.dim = int(dim)
+        self.device = int(device)
+        h = _P()
+        rc = self.lib.rag_create(self.device, self.dim, C.byref(h))
+        if rc != 0:
+            raise RagError(f"rag_create(device={device}, dim={dim}) failed with {rc} (no usable MI355X / bad dim)")
+        self.h = h
+        self._keep = []
+        self.n_rows = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rag_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.rag_last_error(self.h)
+            raise RagError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def synchronize(self):
+        self._check(self.lib.rag_synchronize(self.h), "rag_synchronize")
+
+    def set_profiling(self, on):
+        self._check(self.lib.rag_set_profiling(self.h, 1 if on else 0), "rag_set_profiling")
+
+    # ---- dense index ---------------------------------------------------------------------------
+    def index_load(self, emb, ids=None, id_base=0):
+        """emb: [N, dim] float32 numpy array (host) or torch CUDA tensor (device)."""
+        if _is_torch(emb):
+            import torch
+            assert emb.is_cuda and emb.dtype == torch.float32 and emb.is_contiguous() and emb.shape[1] == self.dim
+            idp = None
+            if ids is not None:
+                assert ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous()
+                idp = C.c_void_p(ids.data_ptr())
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self._check(self.lib.rag_index_load_dev(self.h, C.c_void_p(emb.data_ptr()), idp, int(id_base),
+                                                    emb.shape[0], st), "rag_index_load_dev")
+            torch.cuda.current_stream().synchronize()
+            self.n_rows = int(emb.shape[0])
+            return
+        emb = _np(emb, np.float32)
+        if emb.ndim != 2 or emb.shape[1] != self.dim:
+            raise RagError(f"index_load: expected [N,{self.dim}] got {emb.shape}")
+        ida = None if ids is None else _np(ids, np.int64)
+        self._check(self.lib.rag_index_load_host(self.h, _ptr(emb), _ptr(ida), int(id_base), emb.shape[0]),
+                    "rag_index_load_host")
+        self.n_rows = int(emb.shape[0])
+
+    def set_tenants(self, tenant_of_row):
+        t = None if tenant_of_row is None else _np(tenant_of_row, np.int32)
+        self._check(self.lib.rag_index_set_tenants_host(self.h, _ptr(t), 0 if t is None else t.shape[0]),
+                    "rag_index_set_tenants_host")
+
+    def fetch_rows(self, rows):
+        rows = _np(rows, np.int64)
+        out = np.empty((rows.shape[0], self.dim), dtype=np.float32)
+        self._check(self.lib.rag_index_fetch_rows_host(self.h, _ptr(rows), rows.shape[0], _ptr(out)),
+                    "rag_index_fetch_rows_host")
+        return out
+
+    def dense_topk(self, queries, k, tenant=-1):
+        """queries [Q, dim] float32 (numpy). Returns (ids int64 [Q,k], rows int32 [Q,k], scores float64 [Q,k])."""
+        q = _np(queries, np.float32)
+        if q.ndim == 1:
+            q = q[None]
+        if q.shape[1] != self.dim:
+            raise RagError(f"dense_topk: expected [Q,{self.dim}] got {q.shape}")
+        Q = q.shape[0]
+        ids = np.empty((Q, k), dtype=np.int64)
+        rows = np.empty((Q, k), dtype=np.int32)
+        sc = np.empty((Q, k), dtype=np.float64)
+        self._check(self.lib.rag_dense_topk_host(self.h, _ptr(q), Q, int(k), int(tenant), _ptr(ids), _ptr(rows), _ptr(sc)),
+                    "rag_dense_topk_host")
+        return ids, rows, sc
+
+    def dense_topk_dev(self, q, k, ids_out, rows_out, scores_out, tenant=-1, stream=None):
+        """torch CUDA tensors in/out; asynchronous on `stream` (default: torch's current stream)."""
+        import torch
+        assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and q.shape[1] == self.dim
+        assert ids_out.dtype == torch.int64 and scores_out.dtype == torch.float64
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        rp = None if rows_out is None else C.c_void_p(rows_out.data_ptr())
+        self._check(self.lib.rag_dense_topk_dev(self.h, C.c_void_p(q.data_ptr()), q.shape[0], int(k), int(tenant),
+                                                C.c_void_p(ids_out.data_ptr()), rp, C.c_void_p(scores_out.data_ptr()), st),
+                    "rag_dense_topk_dev")
+
+    def dense_stats(self):
+        s = DenseStats()
+        self._check(self.lib.rag_dense_last_stats(self.h, C.byref(s)), "rag_dense_last_stats")
+        return s.as_dict()
+
+    def dense_kernel_ms(self):
+        ms, n = C.c_float(), C.c_int()
+        self._check(self.lib.rag_dense_kernel_ms(self.h, C.byref(ms), C.byref(n)), "rag_dense_kernel_ms")
+        return float(ms.value), int(n.value)
+
+    def merge_topk_dev(self, ids, scores, ids_out, scores_out, stream=None):
+        """ids/scores: [L, Q, k] torch CUDA tensors (int64 / float64) -> [Q, k]."""
+        import torch
+        L, Q, k = ids.shape
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        self._check(self.lib.rag_merge_topk_dev(self.h, C.c_void_p(ids.data_ptr()), C.c_void_p(scores.data_ptr()), L, Q, k,
+                                                C.c_void_p(ids_out.data_ptr()), C.c_void_p(scores_out.data_ptr()), st),
+                    "rag_merge_topk_dev")
+
+    # ---- small ops --------------------------------------------------------------------------------
+    def pairwise_cosine(self, a, b=None):
+        a = _np(a, np.float32)
+        b = a if b is None else _np(b, np.float32)
+        if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
+            raise RagError(f"pairwise_cosine: shapes {a.shape} {b.shape}")
+        out = np.zeros((a.shape[0], b.shape[0]), dtype=np.float64)
+        if out.size:
+            self._check(self.lib.rag_pairwise_cosine_host(self.h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1],
+                                                          _ptr(out)), "rag_pairwise_cosine_host")
+        return out
+
+    def rrf_fuse(self, lists, rrf_k=60, top_k=10):
+        """lists: int64 [Q, L, len] (-1 padded at tails). Returns (keys [Q,top_k], scores, ranks [Q,top_k,L])."""
+        lists = _np(lists, np.int64)
+        Q, L, ln = lists.shape
+        keys = np.empty((Q, top_k), dtype=np.int64)
+        sc = np.empty((Q, top_k), dtype=np.float64)
+        ranks = np.empty((Q, top_k, L), dtype=np.int32)
+        self._check(self.lib.rag_rrf_fuse_host(self.h, _ptr(lists), Q, L, ln, int(rrf_k), int(top_k), _ptr(keys), _ptr(sc),
+                                               _ptr(ranks)), "rag_rrf_fuse_host")
+        return keys, sc, ranks
+
+    def linear_fuse_topk(self, semantic, keyword, temporal, alpha, beta, gamma, top_k):
+        s = _np(semantic, np.float64)
+        kw = _np(keyword, np.float64)
+        t = None if temporal is None else _np(temporal, np.float64)
+        n = s.shape[0]
+        kk = min(int(top_k), n) if n else 0
+        idx = np.empty((max(kk, 1),), dtype=np.int32)
+        hyb = np.empty((max(n, 1),), dtype=np.float64)
+        if n == 0 or kk <= 0:
+            return idx[:0], hyb[:0]
+        self._check(self.lib.rag_linear_fuse_topk_host(self.h, _ptr(s), _ptr(kw), _ptr(t), n, float(alpha), float(beta),
+                                                       float(gamma), kk, _ptr(idx), _ptr(hyb)), "rag_linear_fuse_topk_host")
+        return idx[:kk], hyb[:n]
+
+    # ---- BM25 -------------------------------------------------------------------------------------
+    def bm25_load(self, indptr, doc, tf, doc_len, idf, avgdl, k1=1.5, b=0.75):
+        indptr = _np(indptr, np.int64)
+        doc = _np(doc, np.int32)
+        tf = _np(tf, np.int32)
+        doc_len = _np(doc_len, np.int32)
+        idf = _np(idf, np.float64)
+        self._check(self.lib.rag_bm25_load_host(self.h, _ptr(indptr), _ptr(doc), _ptr(tf), _ptr(doc_len), _ptr(idf),
+                                                doc_len.shape[0], idf.shape[0], float(avgdl), float(k1), float(b)),
+                    "rag_bm25_load_host")
+        self.bm25_docs = int(doc_len.shape[0])
+
+    def bm25_topk(self, term_ptr, terms, k):
+        term_ptr = _np(term_ptr, np.int32)
+        terms = _np(terms, np.int32)
+        Q = term_ptr.shape[0] - 1
+        ids = np.empty((Q, k), dtype=np.int64)
+        rows = np.empty((Q, k), dtype=np.int32)
+        sc = np.empty((Q, k), dtype=np.float64)
+        mx = np.empty((Q,), dtype=np.float64)
+        self._check(self.lib.rag_bm25_topk_host(self.h, _ptr(term_ptr), _ptr(terms), Q, int(k), _ptr(ids), _ptr(rows),
+                                                _ptr(sc), _ptr(mx)), "rag_bm25_topk_host")
+        return ids, rows, sc, mx
+
+    def bm25_scores(self, term_ptr, terms):
+        term_ptr = _np(term_ptr, np.int32)
+        terms = _np(terms, np.int32)
+        Q = term_ptr.shape[0] - 1
+        out = np.zeros((Q, self.bm25_docs), dtype=np.float64)
+        self._check(self.lib.rag_bm25_scores_host(self.h, _ptr(term_ptr), _ptr(terms), Q, _ptr(out)), "rag_bm25_scores_host")
+        return out
+
+    # ---- cross-encoder ----------------------------------------------------------------------------
+    def ce_load(self, cfg, tensors):
+        c = CeConfig(cfg["vocab_size"], cfg["hidden"], cfg["layers"], cfg["heads"], cfg["ffn"], cfg["max_pos"],
+                     cfg.get("type_vocab", 2), 0, float(cfg.get("eps", 1e-12)))
+        arrs = [_np(t, np.float32) for t in tensors]
+        ptrs = (_P * len(arrs))(*[a.ctypes.data for a in arrs])
+        self._check(self.lib.rag_ce_load_host(self.h, C.byref(c), ptrs, len(arrs)), "rag_ce_load_host")
+
+    def ce_score(self, input_ids, token_type_ids, lens):
+        ids = _np(input_ids, np.int32)
+        tt = _np(token_type_ids, np.int32)
+        ln = _np(lens, np.int32)
+        P, L = ids.shape
+        out = np.empty((P,), dtype=np.float32)
+        self._check(self.lib.rag_ce_score_host(self.h, _ptr(ids), _ptr(tt), _ptr(ln), P, L, _ptr(out)), "rag_ce_score_host")
+        return out

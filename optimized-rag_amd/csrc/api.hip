@@ -1,0 +1,335 @@
+// C-ABI entry points of librag_hip.so (include/rag_hip.h). Thin: argument checks, host<->device
+// staging for the *_host variants, dispatch to the kernels' host drivers.
+#include "common.h"
+
+#include <cstdlib>
+#include <cstring>
+
+// drivers implemented in other translation units
+int rrf_fuse_host(rag_ctx* h, const int64_t* lists, int Q, int L, int len, int rrf_k, int top_k, int64_t* keys_out,
+                  double* scores_out, int32_t* ranks_out);
+int linear_fuse_topk_host(rag_ctx* h, const double* sem, const double* kw, const double* tmp, int n, double a, double b,
+                          double g, int top_k, int32_t* idx_out, double* hyb_out);
+int bm25_load_host(rag_ctx* h, const int64_t* indptr, const int32_t* doc, const int32_t* tf, const int32_t* doc_len,
+                   const double* idf, int64_t n_docs, int64_t n_terms, double avgdl, double k1, double b);
+int bm25_topk_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, int k, int64_t* ids_out,
+                   int32_t* rows_out, double* scores_out, double* raw_max_out);
+int bm25_scores_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, double* out);
+void bm25_free(rag_ctx* h);
+int ce_load_host(rag_ctx* h, const rag_ce_config* cfg, const float* const* tensors, int n);
+int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L, float* out,
+             hipStream_t st, bool host_ptrs);
+void ce_free(rag_ctx* h);
+
+static thread_local std::string g_null_err = "null handle";
+
+extern "C" {
+
+int rag_version(void) { return 100; }
+
+int rag_device_count(int* n_out) {
+    if (!n_out) return RAG_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        *n_out = 0;
+        return RAG_ERR_HIP;
+    }
+    *n_out = n;
+    return RAG_OK;
+}
+
+int rag_create(int device_id, int dim, rag_handle_t* out) {
+    if (!out || dim <= 0 || dim % 4 != 0) return RAG_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0 || device_id < 0 || device_id >= n) return RAG_ERR_HIP;
+    if (hipSetDevice(device_id) != hipSuccess) return RAG_ERR_HIP;
+    rag_ctx* h = new rag_ctx();
+    h->device = device_id;
+    h->dim = dim;
+    h->dim_pad = (int)round_up(dim, RAG_BK);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return RAG_ERR_HIP;
+    }
+    *out = h;
+    return RAG_OK;
+}
+
+int rag_destroy(rag_handle_t h) {
+    if (!h) return RAG_ERR_ARG;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    dense_free(h);
+    bm25_free(h);
+    ce_free(h);
+    hipFree(h->q32); hipFree(h->q16); hipFree(h->cand); hipFree(h->cnt); hipFree(h->tau); hipFree(h->bound);
+    hipFree(h->n_sorted); hipFree(h->exact); hipFree(h->flag); hipFree(h->stats); hipFree(h->out_ids);
+    hipFree(h->out_rows); hipFree(h->out_scores);
+    for (auto& e : h->gemm_events) {
+        hipEventDestroy(e.first);
+        hipEventDestroy(e.second);
+    }
+    hipStreamDestroy(h->stream);
+    delete h;
+    return RAG_OK;
+}
+
+const char* rag_last_error(rag_handle_t h) { return h ? h->err.c_str() : g_null_err.c_str(); }
+
+int rag_synchronize(rag_handle_t h) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return RAG_OK;
+}
+
+int rag_set_profiling(rag_handle_t h, int enable) {
+    if (!h) return RAG_ERR_ARG;
+    h->profiling = enable != 0;
+    return RAG_OK;
+}
+
+// ---- dense index ---------------------------------------------------------------------------------
+static int index_load_common(rag_ctx* h, const float* emb, const int64_t* ids, int64_t id_base, int64_t n_rows,
+                             hipStream_t st, bool host) {
+    ARG_CHECK(h, n_rows >= 0 && n_rows < (int64_t)0x7fffff00, "n_rows must fit int32 per GPU");
+    ARG_CHECK(h, n_rows == 0 || emb != nullptr, "emb is null");
+    HIP_TRY(h, hipSetDevice(h->device));
+    dense_free(h);
+    h->n_rows = n_rows;
+    h->id_base = id_base;
+    const hipMemcpyKind kind = host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    if (n_rows > 0) {
+        HIP_TRY(h, hipMalloc(&h->emb32, (size_t)n_rows * h->dim * sizeof(float)));
+        HIP_TRY(h, hipMemcpyAsync(h->emb32, emb, (size_t)n_rows * h->dim * sizeof(float), kind, st));
+        if (ids) {
+            HIP_TRY(h, hipMalloc(&h->ids, (size_t)n_rows * sizeof(int64_t)));
+            HIP_TRY(h, hipMemcpyAsync(h->ids, ids, (size_t)n_rows * sizeof(int64_t), kind, st));
+        }
+    }
+    int rc = dense_index_build(h, h->emb32, n_rows, st);
+    if (rc) return rc;
+    if (host) HIP_TRY(h, hipStreamSynchronize(st));
+    return RAG_OK;
+}
+
+int rag_index_load_host(rag_handle_t h, const float* emb_host, const int64_t* ids_host, int64_t id_base, int64_t n_rows) {
+    if (!h) return RAG_ERR_ARG;
+    return index_load_common(h, emb_host, ids_host, id_base, n_rows, h->stream, true);
+}
+
+int rag_index_load_dev(rag_handle_t h, const float* emb_dev, const int64_t* ids_dev, int64_t id_base, int64_t n_rows,
+                       void* stream) {
+    if (!h) return RAG_ERR_ARG;
+    return index_load_common(h, emb_dev, ids_dev, id_base, n_rows, stream ? (hipStream_t)stream : h->stream, false);
+}
+
+int rag_index_set_tenants_host(rag_handle_t h, const int32_t* t, int64_t n_rows) {
+    if (!h) return RAG_ERR_ARG;
+    ARG_CHECK(h, n_rows == h->n_rows, "tenant array length must equal the index row count");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipFree(h->tenants);
+    h->tenants = nullptr;
+    if (t == nullptr || n_rows == 0) return RAG_OK;
+    HIP_TRY(h, hipMalloc(&h->tenants, (size_t)n_rows * sizeof(int32_t)));
+    HIP_TRY(h, hipMemcpy(h->tenants, t, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice));
+    return RAG_OK;
+}
+
+int rag_index_rows(rag_handle_t h, int64_t* n_rows_out) {
+    if (!h || !n_rows_out) return RAG_ERR_ARG;
+    *n_rows_out = h->n_rows;
+    return RAG_OK;
+}
+
+int rag_index_fetch_rows_host(rag_handle_t h, const int64_t* rows, int n, float* out) {
+    if (!h) return RAG_ERR_ARG;
+    ARG_CHECK(h, n >= 0 && (n == 0 || (rows && out)), "null rows/out");
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (int i = 0; i < n; ++i) {
+        ARG_CHECK(h, rows[i] >= 0 && rows[i] < h->n_rows, "row out of range");
+        HIP_TRY(h, hipMemcpyAsync(out + (size_t)i * h->dim, h->emb32 + (size_t)rows[i] * h->dim, h->dim * sizeof(float),
+                                  hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return RAG_OK;
+}
+
+// ---- dense search ----------------------------------------------------------------------------------
+int rag_dense_topk_dev(rag_handle_t h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev,
+                       double* scores_dev, void* stream) {
+    if (!h) return RAG_ERR_ARG;
+    ARG_CHECK(h, q_dev && ids_dev && scores_dev, "null pointer");
+    ARG_CHECK(h, Q > 0 && Q <= 65535, "1 <= n_queries <= 65535");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return dense_search(h, q_dev, Q, k, tenant, ids_dev, rows_dev, scores_dev, stream ? (hipStream_t)stream : h->stream);
+}
+
+int rag_dense_topk_host(rag_handle_t h, const float* q_host, int Q, int k, int tenant, int64_t* ids_out, int32_t* rows_out,
+                        double* scores_out) {
+    if (!h) return RAG_ERR_ARG;
+    ARG_CHECK(h, q_host && ids_out && scores_out, "null pointer");
+    ARG_CHECK(h, Q > 0 && Q <= 65535, "1 <= n_queries <= 65535");
+    ARG_CHECK(h, k > 0 && k <= RAG_MAX_K, "0 < k <= 256");
+    HIP_TRY(h, hipSetDevice(h->device));
+    // workspace first (q32 staging lives there)
+    if (Q > h->ws_q) {
+        // dense_search re-checks; allocate via a dry call path: copy after ensure
+    }
+    hipStream_t st = h->stream;
+    // stage queries: allocate a temporary if the workspace is not there yet
+    float* qd = nullptr;
+    HIP_TRY(h, hipMalloc(&qd, (size_t)Q * h->dim * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(qd, q_host, (size_t)Q * h->dim * sizeof(float), hipMemcpyHostToDevice, st);
+    int rc = RAG_OK;
+    int64_t* ids_d = nullptr;
+    int32_t* rows_d = nullptr;
+    double* sc_d = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&ids_d, (size_t)Q * k * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(&rows_d, (size_t)Q * k * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&sc_d, (size_t)Q * k * sizeof(double));
+    if (e == hipSuccess) {
+        rc = dense_search(h, qd, Q, k, tenant, ids_d, rows_d, sc_d, st);
+        if (rc == RAG_OK) {
+            e = hipMemcpyAsync(ids_out, ids_d, (size_t)Q * k * sizeof(int64_t), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && rows_out)
+                e = hipMemcpyAsync(rows_out, rows_d, (size_t)Q * k * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(scores_out, sc_d, (size_t)Q * k * sizeof(double), hipMemcpyDeviceToHost, st);
+        }
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
+    hipFree(qd); hipFree(ids_d); hipFree(rows_d); hipFree(sc_d);
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) {
+        h->err = std::string("dense_topk_host: ") + hipGetErrorString(e != hipSuccess ? e : e2);
+        return RAG_ERR_HIP;
+    }
+    return RAG_OK;
+}
+
+int rag_dense_last_stats(rag_handle_t h, rag_dense_stats* out) {
+    if (!h || !out) return RAG_ERR_ARG;
+    ARG_CHECK(h, h->last_stats_valid && h->stats, "no dense search has run");
+    int s[8];
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(s, h->stats, sizeof(s), hipMemcpyDeviceToHost));
+    out->n_queries = h->last_q;
+    out->proven_fast = s[0];
+    out->proven_wide = s[1];
+    out->exact_scan = s[2];
+    out->overflowed = s[4];
+    out->shortlist = h->last_shortlist;
+    out->stages = h->last_stages;
+    out->reserved = 0;
+    out->eps = h->last_eps;
+    return RAG_OK;
+}
+
+int rag_dense_kernel_ms(rag_handle_t h, float* gemm_ms_out, int* launches_out) {
+    if (!h || !gemm_ms_out || !launches_out) return RAG_ERR_ARG;
+    ARG_CHECK(h, h->profiling && h->gemm_events_used > 0, "profiling not enabled or no search ran");
+    HIP_TRY(h, hipSetDevice(h->device));
+    float total = 0.f;
+    for (int i = 0; i < h->gemm_events_used; ++i) {
+        HIP_TRY(h, hipEventSynchronize(h->gemm_events[i].second));
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->gemm_events[i].first, h->gemm_events[i].second));
+        total += ms;
+    }
+    *gemm_ms_out = total;
+    *launches_out = h->gemm_events_used;
+    return RAG_OK;
+}
+
+int rag_merge_topk_dev(rag_handle_t h, const int64_t* ids_dev, const double* scores_dev, int n_lists, int Q, int k,
+                       int64_t* ids_out_dev, double* scores_out_dev, void* stream) {
+    if (!h) return RAG_ERR_ARG;
+    ARG_CHECK(h, ids_dev && scores_dev && ids_out_dev && scores_out_dev, "null pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return merge_topk(h, ids_dev, scores_dev, n_lists, Q, k, ids_out_dev, scores_out_dev,
+                      stream ? (hipStream_t)stream : h->stream);
+}
+
+int rag_pairwise_cosine_host(rag_handle_t h, const float* a, int m, const float* b, int n, int dim, double* out) {
+    if (!h) return RAG_ERR_ARG;
+    ARG_CHECK(h, m >= 0 && n >= 0 && dim > 0, "bad sizes");
+    if (m == 0 || n == 0) return RAG_OK;
+    ARG_CHECK(h, a && b && out, "null pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    float *ad = nullptr, *bd = nullptr;
+    double* od = nullptr;
+    const bool same = (a == b && m == n);
+    HIP_TRY(h, hipMalloc(&ad, (size_t)m * dim * sizeof(float)));
+    hipError_t e = hipSuccess;
+    if (!same) e = hipMalloc(&bd, (size_t)n * dim * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&od, (size_t)m * n * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(ad, a, (size_t)m * dim * sizeof(float), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && !same) e = hipMemcpyAsync(bd, b, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, h->stream);
+    int rc = RAG_OK;
+    if (e == hipSuccess) rc = pairwise_cosine(h, ad, m, same ? ad : bd, n, dim, od, h->stream);
+    if (e == hipSuccess && rc == RAG_OK)
+        e = hipMemcpyAsync(out, od, (size_t)m * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    hipFree(ad); hipFree(bd); hipFree(od);
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) {
+        h->err = std::string("pairwise_cosine_host: ") + hipGetErrorString(e != hipSuccess ? e : e2);
+        return RAG_ERR_HIP;
+    }
+    return RAG_OK;
+}
+
+int rag_rrf_fuse_host(rag_handle_t h, const int64_t* lists, int Q, int L, int len, int rrf_k, int top_k, int64_t* keys_out,
+                      double* scores_out, int32_t* ranks_out) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return rrf_fuse_host(h, lists, Q, L, len, rrf_k, top_k, keys_out, scores_out, ranks_out);
+}
+
+int rag_linear_fuse_topk_host(rag_handle_t h, const double* sem, const double* kw, const double* tmp, int n, double a,
+                              double b, double g, int top_k, int32_t* idx_out, double* hyb_out) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return linear_fuse_topk_host(h, sem, kw, tmp, n, a, b, g, top_k, idx_out, hyb_out);
+}
+
+int rag_bm25_load_host(rag_handle_t h, const int64_t* indptr, const int32_t* doc, const int32_t* tf, const int32_t* doc_len,
+                       const double* idf, int64_t n_docs, int64_t n_terms, double avgdl, double k1, double b) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return bm25_load_host(h, indptr, doc, tf, doc_len, idf, n_docs, n_terms, avgdl, k1, b);
+}
+
+int rag_bm25_topk_host(rag_handle_t h, const int32_t* term_ptr, const int32_t* terms, int Q, int k, int64_t* ids_out,
+                       int32_t* rows_out, double* scores_out, double* raw_max_out) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return bm25_topk_host(h, term_ptr, terms, Q, k, ids_out, rows_out, scores_out, raw_max_out);
+}
+
+int rag_bm25_scores_host(rag_handle_t h, const int32_t* term_ptr, const int32_t* terms, int Q, double* out) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return bm25_scores_host(h, term_ptr, terms, Q, out);
+}
+
+int rag_ce_load_host(rag_handle_t h, const rag_ce_config* cfg, const float* const* tensors, int n) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return ce_load_host(h, cfg, tensors, n);
+}
+
+int rag_ce_score_host(rag_handle_t h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L, float* out) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return ce_score(h, ids, tt, lens, P, L, out, h->stream, true);
+}
+
+int rag_ce_score_dev(rag_handle_t h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L, float* out,
+                     void* stream) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return ce_score(h, ids, tt, lens, P, L, out, stream ? (hipStream_t)stream : h->stream, false);
+}
+
+}  // extern "C"

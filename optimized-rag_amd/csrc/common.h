@@ -1,0 +1,122 @@
+// Shared declarations for librag_hip.so (gfx950 only). See include/rag_hip.h for the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rag_hip.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define RAG_CAND_CAP 4096        // per-query candidate buffer entries (u64 keys)
+#define RAG_STAGE0_ROWS 2048     // rows whose scores are stored densely (no threshold yet)
+#define RAG_STAGE_GROWTH 8       // each threshold stage covers ~8x the rows seen so far
+#define RAG_TILE 256             // GEMM tile edge (corpus rows x queries)
+#define RAG_BK 64                // K-slice per LDS stage (halfs)
+#define RAG_MAX_K 256            // largest k / shortlist supported by the select kernels
+#define RAG_SCALE_LOG2 7         // unit rows are stored as fp16(128 * x): keeps fp16 out of subnormals
+
+struct rag_ce_model;             // cross_encoder.hip
+struct rag_bm25_index;           // bm25.hip
+
+struct rag_ctx {
+    int device = 0;
+    int dim = 0;
+    int dim_pad = 0;             // multiple of RAG_BK
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool profiling = false;
+
+    // dense index
+    int64_t n_rows = 0, n_rows_pad = 0, id_base = 0;
+    float* emb32 = nullptr;      // [n_rows][dim]        fp32 master rows
+    half_t* emb16 = nullptr;     // [n_rows_pad][dim_pad] fp16 (2^7 * unit rows), zero padded
+    int64_t* ids = nullptr;      // [n_rows] or null
+    int32_t* tenants = nullptr;  // [n_rows] or null
+    int* bad_rows = nullptr;     // device counter: rows with zero / non-finite norm
+
+    // dense search workspace (sized for ws_q queries)
+    int ws_q = 0;
+    float* q32 = nullptr;            // [ws_q][dim]     staging for host queries
+    half_t* q16 = nullptr;           // [ws_qpad][dim_pad]
+    uint64_t* cand = nullptr;        // [ws_qpad][RAG_CAND_CAP]
+    unsigned* cnt = nullptr;         // [ws_qpad]   emitted candidates (may exceed cap = overflow)
+    float* tau = nullptr;            // [ws_qpad]   emission threshold (fp16-pass score)
+    float* bound = nullptr;          // [ws_qpad]   proof bound after the final select
+    int* n_sorted = nullptr;         // [ws_qpad]   candidates kept sorted in cand[] after final select
+    double* exact = nullptr;         // [ws_qpad][RAG_CAND_CAP] float64 rescored cosines
+    int* flag = nullptr;             // [ws_qpad]   0 proven fast, 1 needs wide, 2 needs exact scan
+    int* stats = nullptr;            // [8] device counters
+    // exact-scan fallback workspace
+    double* scan_scores = nullptr;   // [n_rows] (allocated on first use)
+    int64_t scan_rows = 0;
+    int64_t* out_ids = nullptr;      // [ws_q][RAG_MAX_K] staging for host calls
+    int32_t* out_rows = nullptr;
+    double* out_scores = nullptr;
+    int out_k = 0;
+
+    // profiling of the dominant kernel
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_events;
+    int gemm_events_used = 0;
+    rag_dense_stats last_stats = {};
+    bool last_stats_valid = false;
+    int last_q = 0, last_k = 0, last_stages = 0, last_shortlist = 0;
+    double last_eps = 0;
+
+    rag_bm25_index* bm25 = nullptr;
+    rag_ce_model* ce = nullptr;
+};
+
+#define HIP_TRY(h, expr)                                                                      \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                     \
+            return RAG_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+#define ARG_CHECK(h, cond, msg)                                                               \
+    do {                                                                                      \
+        if (!(cond)) {                                                                        \
+            (h)->err = std::string("bad argument: ") + (msg);                                 \
+            return RAG_ERR_ARG;                                                               \
+        }                                                                                     \
+    } while (0)
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- sortable keys: larger key = higher score, then lower row ---------------------------------
+__host__ __device__ static inline uint32_t f32_orderable(float s) {
+    uint32_t u = __builtin_bit_cast(uint32_t, s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ static inline float f32_from_orderable(uint32_t u) {
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __builtin_bit_cast(float, u);
+}
+__host__ __device__ static inline uint64_t make_key(float score, uint32_t row) {
+    return ((uint64_t)f32_orderable(score) << 32) | (uint64_t)(0xFFFFFFFFu - row);
+}
+__host__ __device__ static inline uint32_t key_row(uint64_t k) { return 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFu); }
+__host__ __device__ static inline float key_score(uint64_t k) { return f32_from_orderable((uint32_t)(k >> 32)); }
+__host__ __device__ static inline uint64_t f64_orderable(double s) {
+    uint64_t u = __builtin_bit_cast(uint64_t, s);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// entry points implemented per file
+int dense_index_build(rag_ctx* h, const float* emb_dev, int64_t n_rows, hipStream_t st);
+int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev,
+                 double* scores_dev, hipStream_t st);
+int dense_free(rag_ctx* h);
+int merge_topk(rag_ctx* h, const int64_t* ids, const double* scores, int n_lists, int Q, int k, int64_t* ids_out,
+               double* scores_out, hipStream_t st);
+int pairwise_cosine(rag_ctx* h, const float* a_dev, int m, const float* b_dev, int n, int dim, double* out_dev,
+                    hipStream_t st);

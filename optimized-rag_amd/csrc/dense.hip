@@ -1,0 +1,783 @@
+// Dense cosine top-k over the HBM-resident corpus (K0-K3 of SURVEY.md §2).
+//
+// Replaces `ORDER BY embedding <=> q LIMIT k` (/root/reference/rag/document_store.py:448-460,
+// database/operations.py:126-137) and the per-document Python cosine loop of
+// HybridRetriever.hybrid_search (rag/retrieval.py:253-256).
+//
+// Pipeline per batch of Q queries (all on one stream, no host round trip):
+//   normalize_rows   q -> fp16(2^7 * q/|q|)                                   (HBM-bound, tiny)
+//   dense_emit       S~ = C16 . Q16^T on MFMA (fp16 in, fp32 acc), 256x256 tiles through LDS; the
+//                    Q x N score matrix is never written: the epilogue emits only (score,row) keys
+//                    with S~ >= tau[q] into a per-query candidate buffer.  Run as a few stages over
+//                    growing row ranges; after each stage `select` sorts the buffer, keeps the best
+//                    K' and raises tau[q] to the K'-th best score seen so far.
+//   rescore          float64 cosine of the K' shortlisted rows against the fp32 master rows
+//   finalize         order by (float64 cosine desc, row asc), write top-k, and PROVE exactness:
+//                    every row outside the shortlist has S~ <= bound, |S~ - S| <= eps  =>  if the
+//                    k-th exact score > bound + eps the id set is the exact scan's.  Otherwise
+//   wide             rescore the whole candidate buffer (bound = last emission threshold), else
+//   scan             float64 exact scan of every row for that query.
+#include "common.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// K0: one wave per row: out16[row] = fp16(2^7 * x/|x|), zero row when |x| is 0 or not finite.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ in, half_t* __restrict__ out,
+                                                              int64_t n_rows, int dim, int dim_pad, int* bad_rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t row = wave_global; row < n_rows; row += n_waves) {
+        const float* x = in + row * dim;
+        double acc = 0.0;
+        for (int i = lane * 4; i < dim; i += 256) {
+            float4 v = *reinterpret_cast<const float4*>(x + i);
+            acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        const bool ok = (acc > 0.0) && (acc < 1e300);          // false for 0, inf and NaN
+        const float inv = ok ? (float)((double)(1 << RAG_SCALE_LOG2) / sqrt(acc)) : 0.0f;
+        if (!ok && lane == 0 && bad_rows) atomicAdd(bad_rows, 1);
+        half_t* o = out + row * dim_pad;
+        for (int i = lane * 4; i < dim_pad; i += 256) {
+            half4 hv = {0, 0, 0, 0};
+            if (i < dim) {
+                float4 v = *reinterpret_cast<const float4*>(x + i);
+                if (ok) {
+                    hv[0] = (half_t)(v.x * inv);
+                    hv[1] = (half_t)(v.y * inv);
+                    hv[2] = (half_t)(v.z * inv);
+                    hv[3] = (half_t)(v.w * inv);
+                }
+            }
+            *reinterpret_cast<half4*>(o + i) = hv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: fused GEMM + threshold emit.   tile = 256 corpus rows (M) x 256 queries (N), BK = 64, 8 waves
+// (2 along M x 4 along N, each 128 x 64), mfma_f32_16x16x32_f16, LDS double-buffered by LDS-DMA.
+// Queries sit on the MFMA column (lane & 15) so a lane's threshold is one value per 16-wide column block.
+// LDS tile image: [256 rows][8 chunks of 16 B], chunk c of row r stored at chunk position c ^ ((r>>1)&7)
+// (conflict-free ds_read_b128; the swizzle is applied on the DMA *source* address, dest stays linear).
+// Block -> tile map is XCD aware: the n_qtiles blocks that share one corpus tile run back-to-back on the
+// same XCD (blockIdx % 8), so each corpus tile leaves HBM once and is re-read from that XCD's L2.
+// ------------------------------------------------------------------------------------------------
+#define TILE_BYTES (RAG_TILE * RAG_BK * 2)   // 32 KiB per operand per stage
+
+__device__ __forceinline__ void stage_tile(const half_t* __restrict__ gsrc, int ld, char* lds_tile, int tid, int wid) {
+    // 2048 16-byte chunks, 512 threads -> 4 DMA pieces per thread; piece j of this wave lands at
+    // linear chunk j*512 + wid*64 (+lane): wave-uniform base + lane*16, as LDS-DMA requires.
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const half_t* g = gsrc + (size_t)j * 64 * ld;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(lds_tile + (j * 512 + wid * 64) * 16),
+                                         16, 0, 0);
+    }
+}
+
+template <bool DENSE0>
+__global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restrict__ corpus16, const half_t* __restrict__ q16,
+                                                          int Dp, int rtile_begin, int n_rtiles, int n_qtiles,
+                                                          int n_rows_valid, int q_valid, const float* __restrict__ tau,
+                                                          unsigned* __restrict__ cnt, uint64_t* __restrict__ cand,
+                                                          const int32_t* __restrict__ tenants, int tenant) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+
+    // XCD-aware tile assignment (speed only; any placement is correct)
+    const int b = blockIdx.x;
+    const int xcd = b & 7, seq = b >> 3;
+    const int rt = (seq / n_qtiles) * 8 + xcd;
+    const int qt = seq % n_qtiles;
+    if (rt >= n_rtiles) return;
+    const int row0 = (rtile_begin + rt) * RAG_TILE;
+    const int q0 = qt * RAG_TILE;
+
+    // per-thread DMA source: LDS linear chunk i = j*512 + tid -> row r = i>>3 (j*64 + tid>>3), position i&7
+    const int sr = tid >> 3;
+    const int schunk = (tid & 7) ^ ((sr >> 1) & 7);
+    const half_t* a_src = corpus16 + (size_t)(row0 + sr) * Dp + schunk * 8;
+    const half_t* b_src = q16 + (size_t)(q0 + sr) * Dp + schunk * 8;
+
+    // LDS: stage b holds A at smem + b*2*TILE_BYTES and B right after it
+
+    // fragment read offsets: row = base + (lane&15), chunk = kk*4 + (lane>>4), swizzled
+    const int fr = lane & 15, fq = lane >> 4;
+    const int sw = (fr >> 1) & 7;
+    int off_k[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) off_k[kk] = fr * 128 + (((kk * 4 + fq) ^ sw) << 4);
+    const int a_base = wm * 128 * 128;   // bytes: wave's first corpus row * 128 B
+    const int b_base = wn * 64 * 128;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt = Dp / RAG_BK;
+    stage_tile(a_src, Dp, smem, tid, wid);
+    stage_tile(b_src, Dp, smem + TILE_BYTES, tid, wid);
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) {
+            char* nxt = smem + (cur ^ 1) * 2 * TILE_BYTES;
+            stage_tile(a_src + (t + 1) * RAG_BK, Dp, nxt, tid, wid);
+            stage_tile(b_src + (t + 1) * RAG_BK, Dp, nxt + TILE_BYTES, tid, wid);
+        }
+        const char* la = smem + cur * 2 * TILE_BYTES + a_base;
+        const char* lb = smem + cur * 2 * TILE_BYTES + TILE_BYTES + b_base;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 bf[4], af[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const half8*>(lb + j * 16 * 128 + off_k[kk]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const half8*>(la + i * 16 * 128 + off_k[kk]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: C layout col = lane&15 (query), row = (lane>>4)*4 + reg (corpus row) ----------
+    const float scale = 1.0f / (float)(1 << (2 * RAG_SCALE_LOG2));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = q0 + wn * 64 + j * 16 + fr;
+        const bool q_ok = q < q_valid;
+        float thr = DENSE0 ? -INFINITY : (q_ok ? tau[q] : INFINITY);
+        if (!DENSE0) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                mx = fmaxf(mx, fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3])));
+            if (__ballot(q_ok && mx * scale >= thr) == 0ull) continue;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s = acc[i][j][r] * scale;
+                const int row = row0 + wm * 128 + i * 16 + fq * 4 + r;
+                if (q_ok && row < n_rows_valid && s >= thr) {
+                    if (tenants == nullptr || tenants[row] == tenant) {
+                        if (DENSE0) {
+                            cand[(size_t)q * RAG_CAND_CAP + row] = make_key(s, (uint32_t)row);
+                        } else {
+                            const unsigned slot = atomicAdd(&cnt[q], 1u);
+                            if (slot < RAG_CAND_CAP) cand[(size_t)q * RAG_CAND_CAP + slot] = make_key(s, (uint32_t)row);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: per-query select. One workgroup per query: bitonic sort (descending) of the candidate keys in
+// LDS; keys are unique (row is part of the key) so the order is total: score desc, row asc.
+//   n_in   = dense0_rows (stage 0: slots 0..rows-1, empty slots are 0) or min(cnt, cap)
+//   keep   = K' : cand[0..m) sorted, cnt = m, tau = score of the K'-th key (or -inf when fewer exist)
+//   final  : additionally leaves ALL sorted candidates in cand[], n_sorted = their count,
+//            bound = max(tau_in, score of the best candidate beyond the shortlist)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bitonic_sort_desc_u64(uint64_t* s, int P, int tid, int nthreads) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += nthreads) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t a = s[i], b = s[ixj];
+                    const bool desc_block = ((i & k) == 0);
+                    if (desc_block ? (a < b) : (a > b)) {
+                        s[i] = b;
+                        s[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void select_kernel(uint64_t* __restrict__ cand, unsigned* __restrict__ cnt,
+                                                      float* __restrict__ tau, float* __restrict__ bound,
+                                                      int* __restrict__ n_sorted, int* __restrict__ stats,
+                                                      int dense0_rows, int keep, int final_stage) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* s = reinterpret_cast<uint64_t*>(smem);
+    const int q = blockIdx.x, tid = threadIdx.x;
+    uint64_t* c = cand + (size_t)q * RAG_CAND_CAP;
+    const unsigned emitted = cnt[q];
+    int n_in = dense0_rows > 0 ? dense0_rows : (int)min(emitted, (unsigned)RAG_CAND_CAP);
+    if (dense0_rows == 0 && emitted > RAG_CAND_CAP && tid == 0) atomicAdd(&stats[4], 1);   // overflow
+    int P = 64;
+    while (P < n_in) P <<= 1;
+    for (int i = tid; i < P; i += 256) s[i] = i < n_in ? c[i] : 0ull;
+    __syncthreads();
+    bitonic_sort_desc_u64(s, P, tid, 256);
+    // count non-empty keys (sorted descending: zeros at the end)
+    __shared__ int n_valid_sh;
+    if (tid == 0) n_valid_sh = 0;
+    __syncthreads();
+    int local = 0;
+    for (int i = tid; i < n_in; i += 256) local += (s[i] != 0ull);
+    if (local) atomicAdd(&n_valid_sh, local);
+    __syncthreads();
+    const int n_valid = n_valid_sh;
+    const int m = min(n_valid, keep);
+    const int n_write = final_stage ? n_valid : m;
+    for (int i = tid; i < n_write; i += 256) c[i] = s[i];
+    if (tid == 0) {
+        const float tau_in = tau[q];
+        // bound[] starts at -inf; an overflow at ANY stage lost candidates for good -> sticky +inf:
+        // nothing can be proven from the buffer, the query goes to the exact scan.
+        float bnd = bound[q];
+        if (dense0_rows == 0 && emitted > RAG_CAND_CAP) bnd = INFINITY;
+        if (final_stage) {
+            bnd = fmaxf(bnd, tau_in);
+            if (n_valid > m) bnd = fmaxf(bnd, key_score(s[m]));
+            n_sorted[q] = n_valid;
+        }
+        bound[q] = bnd;
+        cnt[q] = (unsigned)m;
+        // the K'-th best score seen so far is a lower bound of the final K'-th best: safe emission threshold
+        tau[q] = (m == keep) ? fmaxf(key_score(s[keep - 1]), tau_in) : tau_in;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: float64 cosine of shortlisted rows. One wave per (query, candidate).
+// cos = dot / (sqrt(|q|^2) * sqrt(|c|^2)), 0.0 when a norm is 0 or not finite (rag/retrieval.py:362-371).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double exact_cosine_wave(const float* __restrict__ qv, const float* __restrict__ cv, int dim,
+                                                    int lane) {
+    double dot = 0.0, nq = 0.0, nc = 0.0;
+    for (int i = lane * 4; i < dim; i += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(qv + i);
+        const float4 c = *reinterpret_cast<const float4*>(cv + i);
+        dot += (double)a.x * c.x + (double)a.y * c.y + (double)a.z * c.z + (double)a.w * c.w;
+        nq += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
+        nc += (double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z + (double)c.w * c.w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        dot += __shfl_xor(dot, o);
+        nq += __shfl_xor(nq, o);
+        nc += __shfl_xor(nc, o);
+    }
+    const bool ok = (nq > 0.0) && (nq < 1e300) && (nc > 0.0) && (nc < 1e300);
+    return ok ? dot / (sqrt(nq) * sqrt(nc)) : 0.0;
+}
+
+__global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ q32, const float* __restrict__ emb32,
+                                                       const uint64_t* __restrict__ cand, const int* __restrict__ n_sorted,
+                                                       double* __restrict__ exact, int dim, int keep) {
+    const int q = blockIdx.y;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int m = min(n_sorted[q], keep);
+    if (j >= m) return;
+    const uint32_t row = key_row(cand[(size_t)q * RAG_CAND_CAP + j]);
+    const double c = exact_cosine_wave(q32 + (size_t)q * dim, emb32 + (size_t)row * dim, dim, lane);
+    if (lane == 0) exact[(size_t)q * RAG_CAND_CAP + j] = c;
+}
+
+// order by (exact desc, row asc); write top-k; prove exactness against `bound`.
+__global__ __launch_bounds__(256) void finalize_kernel(const uint64_t* __restrict__ cand, const int* __restrict__ n_sorted,
+                                                        const double* __restrict__ exact, const float* __restrict__ bound,
+                                                        const int64_t* __restrict__ ids, int64_t id_base, int keep, int k,
+                                                        double eps, int force_level, int64_t* __restrict__ ids_out,
+                                                        int32_t* __restrict__ rows_out, double* __restrict__ scores_out,
+                                                        int* __restrict__ flag, int* __restrict__ stats) {
+    __shared__ double sc[RAG_MAX_K];
+    __shared__ uint32_t rw[RAG_MAX_K];
+    __shared__ double kth;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int m = min(n_sorted[q], keep);
+    if (tid < m) {
+        sc[tid] = exact[(size_t)q * RAG_CAND_CAP + tid];
+        rw[tid] = key_row(cand[(size_t)q * RAG_CAND_CAP + tid]);
+    }
+    if (tid == 0) kth = -INFINITY;
+    for (int i = tid; i < k; i += 256) {
+        ids_out[(size_t)q * k + i] = -1;
+        if (rows_out) rows_out[(size_t)q * k + i] = -1;
+        scores_out[(size_t)q * k + i] = 0.0;
+    }
+    __syncthreads();
+    if (tid < m) {
+        const double e = sc[tid];
+        const uint32_t r = rw[tid];
+        int rank = 0;
+        for (int u = 0; u < m; ++u) rank += (sc[u] > e) || (sc[u] == e && rw[u] < r);
+        if (rank < k) {
+            ids_out[(size_t)q * k + rank] = ids ? ids[r] : id_base + (int64_t)r;
+            if (rows_out) rows_out[(size_t)q * k + rank] = (int32_t)r;
+            scores_out[(size_t)q * k + rank] = e;
+        }
+        if (rank == k - 1) kth = e;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float b = bound[q];
+        bool proven = (b == -INFINITY) || (m >= k && kth > (double)b + eps);
+        if (force_level > 0) proven = false;
+        flag[q] = proven ? 0 : 1;
+        if (proven) atomicAdd(&stats[0], 1);
+    }
+}
+
+// L2: rescore the WHOLE candidate buffer of an unproven query; bound = last emission threshold.
+__global__ __launch_bounds__(512) void wide_kernel(const float* __restrict__ q32, const float* __restrict__ emb32,
+                                                    const uint64_t* __restrict__ cand, const int* __restrict__ n_sorted,
+                                                    double* __restrict__ exact, const float* __restrict__ tau_last,
+                                                    const float* __restrict__ bound, const int64_t* __restrict__ ids,
+                                                    int64_t id_base, int dim, int keep, int k, double eps, int force_level,
+                                                    int64_t* __restrict__ ids_out, int32_t* __restrict__ rows_out,
+                                                    double* __restrict__ scores_out, int* __restrict__ flag,
+                                                    int* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sc = reinterpret_cast<double*>(smem);                       // [cap]
+    uint32_t* rw = reinterpret_cast<uint32_t*>(smem + RAG_CAND_CAP * 8);   // [cap]
+    __shared__ double kth;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (flag[q] != 1) return;
+    const int n = n_sorted[q];
+    const bool overflowed = bound[q] == INFINITY;
+    if (n <= keep || overflowed || force_level > 1) {      // nothing more to learn from the buffer
+        if (tid == 0) flag[q] = 2;
+        return;
+    }
+    const uint64_t* c = cand + (size_t)q * RAG_CAND_CAP;
+    double* ex = exact + (size_t)q * RAG_CAND_CAP;
+    for (int j = keep + wv; j < n; j += 8) {
+        const double v = exact_cosine_wave(q32 + (size_t)q * dim, emb32 + (size_t)key_row(c[j]) * dim, dim, lane);
+        if (lane == 0) ex[j] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 512) {
+        sc[i] = ex[i];
+        rw[i] = key_row(c[i]);
+    }
+    if (tid == 0) kth = -INFINITY;
+    __syncthreads();
+    for (int i = tid; i < n; i += 512) {
+        const double e = sc[i];
+        const uint32_t r = rw[i];
+        int rank = 0;
+        for (int u = 0; u < n && rank < k; ++u) rank += (sc[u] > e) || (sc[u] == e && rw[u] < r);
+        if (rank < k) {
+            ids_out[(size_t)q * k + rank] = ids ? ids[r] : id_base + (int64_t)r;
+            if (rows_out) rows_out[(size_t)q * k + rank] = (int32_t)r;
+            scores_out[(size_t)q * k + rank] = e;
+            if (rank == k - 1) kth = e;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float b = tau_last[q];
+        const bool proven = (b == -INFINITY) || (n >= k && kth > (double)b + eps);
+        flag[q] = proven ? 0 : 2;
+        if (proven) atomicAdd(&stats[1], 1);
+    }
+}
+
+// L3: exact float64 scan of every row for queries with flag == 2.
+#define SCAN_CHUNK 2048
+__device__ __forceinline__ bool pair_before(uint64_t ka, uint32_t ra, uint64_t kb, uint32_t rb) {
+    return ka > kb || (ka == kb && ra < rb);      // score desc, row asc
+}
+__device__ __forceinline__ void bitonic_sort_pairs(uint64_t* k1, uint32_t* k2, int P, int tid, int nthreads) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += nthreads) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool first_block = ((i & k) == 0);
+                    const bool a_before_b = pair_before(k1[i], k2[i], k1[ixj], k2[ixj]);
+                    if (first_block ? !a_before_b : a_before_b) {
+                        const uint64_t t1 = k1[i]; k1[i] = k1[ixj]; k1[ixj] = t1;
+                        const uint32_t t2 = k2[i]; k2[i] = k2[ixj]; k2[ixj] = t2;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_chunk_kernel(const float* __restrict__ q32, const float* __restrict__ emb32,
+                                                          const int32_t* __restrict__ tenants, int tenant, int64_t n_rows,
+                                                          int dim, int k, const int* __restrict__ flag,
+                                                          uint64_t* __restrict__ part_key, uint32_t* __restrict__ part_row) {
+    __shared__ uint64_t sk[SCAN_CHUNK];
+    __shared__ uint32_t sr[SCAN_CHUNK];
+    const int q = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (flag[q] != 2) return;
+    const int64_t base = (int64_t)chunk * SCAN_CHUNK;
+    for (int i = wv; i < SCAN_CHUNK; i += 4) {
+        const int64_t row = base + i;
+        uint64_t key = 0ull;          // 0 = empty (below every real score: orderable(-inf) > 0)
+        if (row < n_rows && (tenants == nullptr || tenants[row] == tenant)) {
+            const double v = exact_cosine_wave(q32 + (size_t)q * dim, emb32 + (size_t)row * dim, dim, lane);
+            key = f64_orderable(v);
+        }
+        if (lane == 0) {
+            sk[i] = key;
+            sr[i] = (uint32_t)row;
+        }
+    }
+    __syncthreads();
+    bitonic_sort_pairs(sk, sr, SCAN_CHUNK, tid, 256);
+    const size_t o = ((size_t)q * gridDim.x + chunk) * k;
+    for (int i = tid; i < k; i += 256) {
+        part_key[o + i] = sk[i];
+        part_row[o + i] = sr[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_merge_kernel(const uint64_t* __restrict__ part_key, const uint32_t* __restrict__ part_row,
+                                                          int n_chunks, int k, const int64_t* __restrict__ ids, int64_t id_base,
+                                                          int* __restrict__ flag, int64_t* __restrict__ ids_out,
+                                                          int32_t* __restrict__ rows_out, double* __restrict__ scores_out,
+                                                          int* __restrict__ stats) {
+    __shared__ uint64_t sk[SCAN_CHUNK];
+    __shared__ uint32_t sr[SCAN_CHUNK];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    if (flag[q] != 2) return;
+    const size_t total = (size_t)n_chunks * k;
+    const uint64_t* pk = part_key + (size_t)q * total;
+    const uint32_t* pr = part_row + (size_t)q * total;
+    for (int i = tid; i < SCAN_CHUNK; i += 256) { sk[i] = 0ull; sr[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    size_t pos = 0;
+    while (pos < total) {
+        const int room = SCAN_CHUNK - k;              // slots [k, CHUNK) take new partials
+        const int take = (int)min((size_t)room, total - pos);
+        for (int i = tid; i < room; i += 256) {
+            sk[k + i] = i < take ? pk[pos + i] : 0ull;
+            sr[k + i] = i < take ? pr[pos + i] : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        bitonic_sort_pairs(sk, sr, SCAN_CHUNK, tid, 256);
+        pos += take;
+    }
+    for (int i = tid; i < k; i += 256) {
+        const bool ok = sk[i] != 0ull;
+        uint64_t u = sk[i];
+        u = (u & 0x8000000000000000ull) ? (u & 0x7fffffffffffffffull) : ~u;
+        const uint32_t r = sr[i];
+        ids_out[(size_t)q * k + i] = ok ? (ids ? ids[r] : id_base + (int64_t)r) : -1;
+        if (rows_out) rows_out[(size_t)q * k + i] = ok ? (int32_t)r : -1;
+        scores_out[(size_t)q * k + i] = ok ? __builtin_bit_cast(double, u) : 0.0;
+    }
+    if (tid == 0) {
+        flag[q] = 3;
+        atomicAdd(&stats[2], 1);
+    }
+}
+
+__global__ void fill_f32_kernel(float* p, float v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int ensure_workspace(rag_ctx* h, int Q) {
+    if (Q <= h->ws_q) return RAG_OK;
+    hipFree(h->q32); hipFree(h->q16); hipFree(h->cand); hipFree(h->cnt); hipFree(h->tau); hipFree(h->bound);
+    hipFree(h->n_sorted); hipFree(h->exact); hipFree(h->flag); hipFree(h->out_ids); hipFree(h->out_rows);
+    hipFree(h->out_scores);
+    h->ws_q = 0;
+    const int64_t qpad = round_up(Q, RAG_TILE);
+    HIP_TRY(h, hipMalloc(&h->q32, (size_t)Q * h->dim * sizeof(float)));
+    HIP_TRY(h, hipMalloc(&h->q16, (size_t)qpad * h->dim_pad * sizeof(half_t)));
+    HIP_TRY(h, hipMalloc(&h->cand, (size_t)qpad * RAG_CAND_CAP * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc(&h->cnt, (size_t)qpad * sizeof(unsigned)));
+    HIP_TRY(h, hipMalloc(&h->tau, 2 * (size_t)qpad * sizeof(float)));      // [tau | tau_last]
+    HIP_TRY(h, hipMalloc(&h->bound, (size_t)qpad * sizeof(float)));
+    HIP_TRY(h, hipMalloc(&h->n_sorted, (size_t)qpad * sizeof(int)));
+    HIP_TRY(h, hipMalloc(&h->exact, (size_t)qpad * RAG_CAND_CAP * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->flag, (size_t)qpad * sizeof(int)));
+    HIP_TRY(h, hipMalloc(&h->out_ids, (size_t)Q * RAG_MAX_K * sizeof(int64_t)));
+    HIP_TRY(h, hipMalloc(&h->out_rows, (size_t)Q * RAG_MAX_K * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc(&h->out_scores, (size_t)Q * RAG_MAX_K * sizeof(double)));
+    if (!h->stats) HIP_TRY(h, hipMalloc(&h->stats, 8 * sizeof(int)));
+    HIP_TRY(h, hipMemset(h->q16, 0, (size_t)qpad * h->dim_pad * sizeof(half_t)));
+    h->ws_q = Q;
+    return RAG_OK;
+}
+
+int dense_free(rag_ctx* h) {
+    hipFree(h->emb32); hipFree(h->emb16); hipFree(h->ids); hipFree(h->tenants); hipFree(h->bad_rows);
+    h->emb32 = nullptr; h->emb16 = nullptr; h->ids = nullptr; h->tenants = nullptr; h->bad_rows = nullptr;
+    hipFree(h->scan_scores); h->scan_scores = nullptr; h->scan_rows = 0;
+    h->n_rows = h->n_rows_pad = 0;
+    return RAG_OK;
+}
+
+// emb32 must already be resident (h->emb32, n_rows rows). Builds the fp16 operand copy.
+int dense_index_build(rag_ctx* h, const float* emb_dev, int64_t n_rows, hipStream_t st) {
+    // pad to a multiple of 8 tiles so the XCD-aware block map needs no bounds logic on loads
+    h->n_rows_pad = round_up(n_rows, (int64_t)RAG_TILE * 8);
+    HIP_TRY(h, hipMalloc(&h->emb16, (size_t)h->n_rows_pad * h->dim_pad * sizeof(half_t)));
+    HIP_TRY(h, hipMalloc(&h->bad_rows, sizeof(int)));
+    HIP_TRY(h, hipMemsetAsync(h->bad_rows, 0, sizeof(int), st));
+    if (h->n_rows_pad > n_rows)
+        HIP_TRY(h, hipMemsetAsync(h->emb16 + (size_t)n_rows * h->dim_pad, 0,
+                                  (size_t)(h->n_rows_pad - n_rows) * h->dim_pad * sizeof(half_t), st));
+    if (n_rows > 0) {
+        const int grid = (int)std::min<int64_t>((n_rows + 3) / 4, 256 * 16);
+        hipLaunchKernelGGL(normalize_rows_kernel, dim3(grid), dim3(256), 0, st, emb_dev, h->emb16, n_rows, h->dim,
+                           h->dim_pad, h->bad_rows);
+        HIP_TRY(h, hipGetLastError());
+    }
+    return RAG_OK;
+}
+
+static double fp16_pass_eps(int dim_pad) {
+    // |S~ - S| for unit vectors: two fp16 roundings per product (rel 2^-11 each, + their product),
+    // fp32 accumulation of dim_pad terms (any order, rel <= dim_pad * 2^-24 of sum |a_i b_i| <= 1),
+    // fp32 normalisation of both rows (rel ~3 * 2^-24 each), small absolute slack for the 2^7 scaling's
+    // residual subnormals.  Cauchy-Schwarz: sum |q_i c_i| <= 1.
+    const double u16 = 1.0 / 2048.0, u32 = 1.0 / 16777216.0;
+    return (2 * u16 + u16 * u16) * 1.01 + 2.0 * dim_pad * u32 + 8 * u32 + 2e-6;
+}
+
+static int shortlist_for(int k) {
+    int kp = std::max(64, (int)round_up(2 * k + 24, 32));
+    return std::min(kp, RAG_MAX_K);
+}
+
+int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev,
+                 double* scores_dev, hipStream_t st) {
+    ARG_CHECK(h, h->emb16 != nullptr, "no index loaded");
+    ARG_CHECK(h, Q > 0 && k > 0 && k <= RAG_MAX_K, "need Q>0 and 0<k<=256");
+    ARG_CHECK(h, tenant < 0 || h->tenants != nullptr, "tenant filter requested but no tenants loaded");
+    int rc = ensure_workspace(h, Q);
+    if (rc) return rc;
+    const int32_t* tenants = tenant >= 0 ? h->tenants : nullptr;
+    const int keep = shortlist_for(k);
+    const double eps = fp16_pass_eps(h->dim_pad);
+    const int qpad = (int)round_up(Q, RAG_TILE);
+    const int n_qtiles = qpad / RAG_TILE;
+    float* tau = h->tau;
+    float* tau_last = h->tau + round_up(h->ws_q, RAG_TILE);
+    const char* fl = getenv("RAG_FORCE_LEVEL");
+    const int force_level = fl ? atoi(fl) : 0;
+
+    // queries -> fp16 unit rows (pad rows of q16 stay zero from allocation time / previous larger batch)
+    if (qpad > Q)
+        HIP_TRY(h, hipMemsetAsync(h->q16 + (size_t)Q * h->dim_pad, 0, (size_t)(qpad - Q) * h->dim_pad * sizeof(half_t), st));
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, q_dev, h->q16, (int64_t)Q, h->dim,
+                       h->dim_pad, (int*)nullptr);
+    HIP_TRY(h, hipMemsetAsync(h->stats, 0, 8 * sizeof(int), st));
+    HIP_TRY(h, hipMemsetAsync(h->cnt, 0, (size_t)qpad * sizeof(unsigned), st));
+    hipLaunchKernelGGL(fill_f32_kernel, dim3((qpad + 255) / 256), dim3(256), 0, st, tau, -INFINITY, qpad);
+    hipLaunchKernelGGL(fill_f32_kernel, dim3((qpad + 255) / 256), dim3(256), 0, st, tau_last, -INFINITY, qpad);
+    hipLaunchKernelGGL(fill_f32_kernel, dim3((qpad + 255) / 256), dim3(256), 0, st, h->bound, -INFINITY, qpad);
+
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wide_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, RAG_CAND_CAP * 12));
+        attr_set = true;
+    }
+
+    // ---- stage schedule over row tiles: [0, 2048), then ~8x growth each -------------------------
+    const int total_tiles = (int)(round_up(h->n_rows, RAG_TILE) / RAG_TILE);
+    const int stage0_tiles = std::min(total_tiles, RAG_STAGE0_ROWS / RAG_TILE);
+    int begin = 0, stage = 0;
+    h->gemm_events_used = 0;
+    while (begin < total_tiles) {
+        int end;
+        if (stage == 0) end = stage0_tiles;
+        else end = (int)std::min<int64_t>(total_tiles, (int64_t)begin * RAG_STAGE_GROWTH);
+        // avoid a tiny trailing stage
+        if (total_tiles - end < end / 4) end = total_tiles;
+        const int n_rt = end - begin;
+        const int grid = (int)round_up(n_rt, 8) * n_qtiles;
+        if (stage == 0) {
+            // dense slots: clear stage-0 slots so filtered / padded rows read as empty
+            HIP_TRY(h, hipMemset2DAsync(h->cand, RAG_CAND_CAP * sizeof(uint64_t), 0,
+                                        (size_t)stage0_tiles * RAG_TILE * sizeof(uint64_t), qpad, st));
+        } else {
+            HIP_TRY(h, hipMemcpyAsync(tau_last, tau, (size_t)qpad * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+        if (h->profiling) {
+            if ((int)h->gemm_events.size() <= h->gemm_events_used) {
+                hipEvent_t a, b;
+                HIP_TRY(h, hipEventCreate(&a));
+                HIP_TRY(h, hipEventCreate(&b));
+                h->gemm_events.push_back({a, b});
+            }
+            HIP_TRY(h, hipEventRecord(h->gemm_events[h->gemm_events_used].first, st));
+        }
+        if (stage == 0)
+            hipLaunchKernelGGL(dense_emit_kernel<true>, dim3(grid), dim3(512), 4 * TILE_BYTES, st, h->emb16, h->q16,
+                               h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant);
+        else
+            hipLaunchKernelGGL(dense_emit_kernel<false>, dim3(grid), dim3(512), 4 * TILE_BYTES, st, h->emb16, h->q16,
+                               h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant);
+        HIP_TRY(h, hipGetLastError());
+        if (h->profiling) {
+            HIP_TRY(h, hipEventRecord(h->gemm_events[h->gemm_events_used].second, st));
+            h->gemm_events_used++;
+        }
+        const bool last = end == total_tiles;
+        hipLaunchKernelGGL(select_kernel, dim3(Q), dim3(256), RAG_CAND_CAP * sizeof(uint64_t), st, h->cand, h->cnt, tau,
+                           h->bound, h->n_sorted, h->stats, stage == 0 ? stage0_tiles * RAG_TILE : 0, keep, last ? 1 : 0);
+        HIP_TRY(h, hipGetLastError());
+        begin = end;
+        ++stage;
+    }
+    if (total_tiles == 0) {   // empty index: nothing found
+        hipLaunchKernelGGL(select_kernel, dim3(Q), dim3(256), RAG_CAND_CAP * sizeof(uint64_t), st, h->cand, h->cnt, tau,
+                           h->bound, h->n_sorted, h->stats, 0, keep, 1);
+    }
+
+    hipLaunchKernelGGL(rescore_kernel, dim3((keep + 3) / 4, Q), dim3(256), 0, st, q_dev, h->emb32, h->cand, h->n_sorted,
+                       h->exact, h->dim, keep);
+    hipLaunchKernelGGL(finalize_kernel, dim3(Q), dim3(256), 0, st, h->cand, h->n_sorted, h->exact, h->bound, h->ids,
+                       h->id_base, keep, k, eps, force_level, ids_dev, rows_dev, scores_dev, h->flag, h->stats);
+    hipLaunchKernelGGL(wide_kernel, dim3(Q), dim3(512), RAG_CAND_CAP * 12, st, q_dev, h->emb32, h->cand, h->n_sorted,
+                       h->exact, tau_last, h->bound, h->ids, h->id_base, h->dim, keep, k, eps, force_level, ids_dev,
+                       rows_dev, scores_dev, h->flag, h->stats);
+    HIP_TRY(h, hipGetLastError());
+    // exact scan for whatever is still unproven (device-side early exit when nothing is flagged)
+    if (h->n_rows > 0) {
+        const int n_chunks = (int)((h->n_rows + SCAN_CHUNK - 1) / SCAN_CHUNK);
+        const size_t need = (size_t)Q * n_chunks * k;
+        if ((int64_t)need > h->scan_rows) {
+            hipFree(h->scan_scores);
+            h->scan_scores = nullptr;
+            HIP_TRY(h, hipMalloc(&h->scan_scores, need * 12));
+            h->scan_rows = (int64_t)need;
+        }
+        uint64_t* pk = reinterpret_cast<uint64_t*>(h->scan_scores);
+        uint32_t* pr = reinterpret_cast<uint32_t*>(pk + need);
+        hipLaunchKernelGGL(scan_chunk_kernel, dim3(n_chunks, Q), dim3(256), 0, st, q_dev, h->emb32, tenants, tenant,
+                           h->n_rows, h->dim, k, h->flag, pk, pr);
+        hipLaunchKernelGGL(scan_merge_kernel, dim3(Q), dim3(256), 0, st, pk, pr, n_chunks, k, h->ids, h->id_base, h->flag,
+                           ids_dev, rows_dev, scores_dev, h->stats);
+        HIP_TRY(h, hipGetLastError());
+    }
+    h->last_q = Q;
+    h->last_k = k;
+    h->last_stages = stage;
+    h->last_shortlist = keep;
+    h->last_eps = eps;
+    h->last_stats_valid = true;
+    return RAG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge of per-shard partial lists (multi-GPU exchange step): [L][Q][k] -> [Q][k], score desc, id asc
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void merge_topk_kernel(const int64_t* __restrict__ ids, const double* __restrict__ scores,
+                                                          int n_lists, int Q, int k, int64_t* __restrict__ ids_out,
+                                                          double* __restrict__ scores_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int total = n_lists * k;
+    double* sc = reinterpret_cast<double*>(smem);
+    int64_t* id = reinterpret_cast<int64_t*>(smem + (size_t)total * 8);
+    const int q = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < total; i += 256) {
+        const int l = i / k, j = i % k;
+        sc[i] = scores[((size_t)l * Q + q) * k + j];
+        id[i] = ids[((size_t)l * Q + q) * k + j];
+    }
+    for (int i = tid; i < k; i += 256) {
+        ids_out[(size_t)q * k + i] = -1;
+        scores_out[(size_t)q * k + i] = 0.0;
+    }
+    __syncthreads();
+    for (int i = tid; i < total; i += 256) {
+        const int64_t me = id[i];
+        if (me < 0) continue;
+        const double e = sc[i];
+        int rank = 0;
+        for (int u = 0; u < total && rank < k; ++u) {
+            const int64_t o = id[u];
+            rank += (o >= 0) && ((sc[u] > e) || (sc[u] == e && o < me));
+        }
+        if (rank < k) {
+            ids_out[(size_t)q * k + rank] = me;
+            scores_out[(size_t)q * k + rank] = e;
+        }
+    }
+}
+
+int merge_topk(rag_ctx* h, const int64_t* ids, const double* scores, int n_lists, int Q, int k, int64_t* ids_out,
+               double* scores_out, hipStream_t st) {
+    ARG_CHECK(h, n_lists > 0 && Q > 0 && k > 0, "merge: sizes must be positive");
+    const size_t lds = (size_t)n_lists * k * 16;
+    ARG_CHECK(h, lds <= 64 * 1024, "merge: n_lists*k too large (max 4096 entries)");
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(Q), dim3(256), lds, st, ids, scores, n_lists, Q, k, ids_out, scores_out);
+    HIP_TRY(h, hipGetLastError());
+    return RAG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8: small pairwise cosine in float64. One wave per output element block.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pairwise_cosine_kernel(const float* __restrict__ a, int m, const float* __restrict__ b,
+                                                               int n, int dim, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= (int64_t)m * n) return;
+    const int i = (int)(pair / n), j = (int)(pair % n);
+    const float* x = a + (size_t)i * dim;
+    const float* y = b + (size_t)j * dim;
+    double dot = 0.0, nx = 0.0, ny = 0.0;
+    for (int t = lane; t < dim; t += 64) {
+        const double u = x[t], v = y[t];
+        dot += u * v;
+        nx += u * u;
+        ny += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        dot += __shfl_xor(dot, o);
+        nx += __shfl_xor(nx, o);
+        ny += __shfl_xor(ny, o);
+    }
+    if (lane == 0) {
+        const double m1 = sqrt(nx), m2 = sqrt(ny);
+        out[pair] = (m1 == 0.0 || m2 == 0.0) ? 0.0 : dot / (m1 * m2);
+    }
+}
+
+int pairwise_cosine(rag_ctx* h, const float* a_dev, int m, const float* b_dev, int n, int dim, double* out_dev,
+                    hipStream_t st) {
+    const int64_t pairs = (int64_t)m * n;
+    if (pairs == 0) return RAG_OK;
+    hipLaunchKernelGGL(pairwise_cosine_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, st, a_dev, m, b_dev, n, dim,
+                       out_dev);
+    HIP_TRY(h, hipGetLastError());
+    return RAG_OK;
+}

@@ -1,0 +1,178 @@
+"""GPU parity: dense cosine top-k through the C-ABI vs the CPU oracle (bit-exact ids, scores within 1e-9;
+the north-star tolerance is 1e-3 — float64 rescoring makes it far tighter)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import rag_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 1e-9          # float64 on both sides, different summation order
+
+
+@pytest.fixture(scope="module")
+def eng_factory():
+    from optimized_rag_amd import RagEngine
+    made = []
+
+    def make(dim):
+        e = RagEngine(dim=dim, device=0)
+        made.append(e)
+        return e
+
+    yield make
+    for e in made:
+        e.close()
+
+
+def planted_queries(rng, corpus, Q, noise=0.5):
+    r = rng.integers(0, corpus.shape[0], Q)
+    return (corpus[r] + noise * rng.standard_normal((Q, corpus.shape[1]))).astype(np.float32)
+
+
+def check(eng, corpus, queries, k, tenant_of_row=None, tenant=-1, ids=None):
+    got_ids, got_rows, got_sc = eng.dense_topk(queries, k, tenant=tenant)
+    oid, osc = O.dense_topk(corpus, queries, k, tenant_of_row, tenant if tenant >= 0 else None)
+    np.testing.assert_array_equal(got_rows, oid.astype(np.int32))
+    exp_ids = oid if ids is None else np.where(oid >= 0, ids[np.maximum(oid, 0)], -1)
+    np.testing.assert_array_equal(got_ids, exp_ids)
+    np.testing.assert_allclose(got_sc, osc, rtol=0, atol=SCORE_TOL)
+    st = eng.dense_stats()
+    assert st["proven_fast"] + st["proven_wide"] + st["exact_scan"] == queries.shape[0], st
+    return st
+
+
+@pytest.mark.parametrize("N,D,Q,k", [
+    (300, 1536, 5, 20),          # single dense stage, N not a tile multiple
+    (2048, 1536, 16, 20),        # exactly stage 0
+    (5000, 1536, 33, 20),        # two stages
+    (40000, 1536, 64, 20),       # three stages
+    (40000, 64, 300, 5),         # small dim (padded K = 64), Q not a tile multiple
+    (9000, 384, 7, 100),         # large k -> larger shortlist
+    (70000, 128, 3, 1),
+    (17, 1536, 4, 20),           # fewer rows than k -> -1 padding
+])
+def test_dense_topk_matches_oracle(eng_factory, N, D, Q, k):
+    rng = np.random.default_rng(N + D + Q + k)
+    corpus = rng.standard_normal((N, D)).astype(np.float32)
+    queries = planted_queries(rng, corpus, Q)
+    eng = eng_factory(D)
+    eng.index_load(corpus)
+    st = check(eng, corpus, queries, k)
+    assert st["overflowed"] == 0
+
+
+def test_unnormalised_rows_and_scale_invariance(eng_factory):
+    rng = np.random.default_rng(5)
+    N, D = 6000, 1536
+    corpus = (rng.standard_normal((N, D)) * rng.uniform(1e-3, 1e3, (N, 1))).astype(np.float32)
+    queries = (planted_queries(rng, corpus, 12) * 37.5).astype(np.float32)
+    eng = eng_factory(D)
+    eng.index_load(corpus)
+    check(eng, corpus, queries, 20)
+
+
+def test_duplicates_ties_and_zero_rows(eng_factory):
+    """Exact duplicate rows tie; order must be lower row first (Python's stable sort). Zero rows score 0.0."""
+    rng = np.random.default_rng(6)
+    N, D = 8000, 256
+    corpus = rng.standard_normal((N, D)).astype(np.float32)
+    base = corpus[10].copy()
+    dup_rows = rng.choice(np.arange(100, N), 90, replace=False)
+    corpus[dup_rows] = base                       # 91 identical rows (incl. row 10)
+    corpus[20:30] = 0.0                           # zero-norm rows
+    corpus[31, 5] = np.inf                        # non-finite row -> scores 0.0, never NaN
+    queries = np.stack([base + 0.3 * rng.standard_normal(D), base, rng.standard_normal(D), np.zeros(D)]).astype(np.float32)
+    eng = eng_factory(D)
+    eng.index_load(corpus)
+    oc = corpus.copy()
+    oc[31] = 0.0                                  # oracle convention for a non-finite row: cosine 0.0
+    got_ids, got_rows, got_sc = eng.dense_topk(queries, 20)
+    oid, osc = O.dense_topk(oc, queries, 20)
+    np.testing.assert_array_equal(got_rows, oid.astype(np.int32))
+    np.testing.assert_allclose(got_sc, osc, atol=SCORE_TOL)
+    assert (got_sc[3] == 0.0).all() and (got_rows[3] == np.arange(20)).all()     # zero query: all ties at 0.0
+    st = eng.dense_stats()
+    assert st["exact_scan"] + st["proven_wide"] >= 1          # the dup cluster defeats the shortlist proof
+
+
+def test_tenant_filter_and_id_table(eng_factory):
+    rng = np.random.default_rng(7)
+    N, D = 12000, 512
+    corpus = rng.standard_normal((N, D)).astype(np.float32)
+    tenants = rng.integers(0, 3, N).astype(np.int32)
+    ids = (rng.permutation(N) + 1_000_000_000_000).astype(np.int64)
+    queries = planted_queries(rng, corpus, 9)
+    eng = eng_factory(D)
+    eng.index_load(corpus, ids=ids)
+    eng.set_tenants(tenants)
+    for t in (0, 2):
+        check(eng, corpus, queries, 20, tenant_of_row=tenants, tenant=t, ids=ids)
+    check(eng, corpus, queries, 20, ids=ids)                   # no filter
+    np.testing.assert_array_equal(eng.fetch_rows([5, 0, N - 1]), corpus[[5, 0, N - 1]])
+
+
+@pytest.mark.parametrize("level", ["1", "2"])
+def test_forced_fallback_levels_give_identical_results(eng_factory, level, monkeypatch):
+    rng = np.random.default_rng(8)
+    N, D = 20000, 1536
+    corpus = rng.standard_normal((N, D)).astype(np.float32)
+    queries = planted_queries(rng, corpus, 6)
+    eng = eng_factory(D)
+    eng.index_load(corpus)
+    monkeypatch.setenv("RAG_FORCE_LEVEL", level)
+    st = check(eng, corpus, queries, 20)
+    assert st["proven_fast"] == 0
+    if level == "2":
+        assert st["exact_scan"] == 6
+
+
+def test_clustered_corpus(eng_factory):
+    """Tight clusters: many near-ties around the k-th score -> exercises the proof / fallback logic."""
+    rng = np.random.default_rng(9)
+    N, D = 30000, 1536
+    centers = rng.standard_normal((20, D)).astype(np.float32)
+    corpus = (centers[rng.integers(0, 20, N)] + 0.01 * rng.standard_normal((N, D))).astype(np.float32)
+    queries = (centers[:8] + 0.01 * rng.standard_normal((8, D))).astype(np.float32)
+    eng = eng_factory(D)
+    eng.index_load(corpus)
+    check(eng, corpus, queries, 20)
+
+
+def test_golden_cosine_through_pairwise_kernel(eng_factory, golden_dir):
+    g = np.load(os.path.join(golden_dir, "cosine.npz"))
+    eng = eng_factory(1536)
+    M = eng.pairwise_cosine(g["a"], g["b"])
+    np.testing.assert_allclose(np.diag(M), g["exp_retrieval"], atol=1e-12)
+    assert M[5, 5] == 0.0 and M[6, 6] == 0.0                    # zero-norm -> exactly 0.0
+
+
+def test_merge_topk_equals_unsharded_search(eng_factory):
+    """Shard the corpus row-wise in 3, search each shard, merge on device == search of the whole corpus."""
+    import torch
+    rng = np.random.default_rng(10)
+    N, D, Q, k = 30000, 256, 40, 20
+    corpus = rng.standard_normal((N, D)).astype(np.float32)
+    corpus[2000] = corpus[25000]                                 # cross-shard exact tie
+    queries = planted_queries(rng, corpus, Q)
+    queries[0] = corpus[25000]
+    bounds = [0, 9000, 21000, N]
+    parts_i, parts_s = [], []
+    for s in range(3):
+        e = eng_factory(D)
+        e.index_load(corpus[bounds[s]:bounds[s + 1]], id_base=bounds[s])
+        i, _, sc = e.dense_topk(queries, k)
+        parts_i.append(i)
+        parts_s.append(sc)
+    e = eng_factory(D)
+    ids = torch.from_numpy(np.stack(parts_i)).cuda()
+    sc = torch.from_numpy(np.stack(parts_s)).cuda()
+    oi = torch.empty((Q, k), dtype=torch.int64, device="cuda")
+    os_ = torch.empty((Q, k), dtype=torch.float64, device="cuda")
+    e.merge_topk_dev(ids, sc, oi, os_)
+    torch.cuda.synchronize()
+    oid, osc = O.dense_topk(corpus, queries, k)
+    np.testing.assert_array_equal(oi.cpu().numpy(), oid)
+    np.testing.assert_allclose(os_.cpu().numpy(), osc, atol=SCORE_TOL)
