@@ -89,9 +89,12 @@ int rag_dense_kernel_ms(rag_handle_t h, float* gemm_ms_out, int* gemm_launches_o
 int rag_set_profiling(rag_handle_t h, int enable);
 
 /* ---- merge of per-shard partial top-k lists (multi-GPU exchange step).
- * lists: [n_lists][Q][k] (ids int64, scores float64, -1 padded) -> [Q][k] by score desc, id asc. */
+ * list l lives at ids_dev + l*list_stride / scores_dev + l*list_stride, each [Q][k] (ids int64, scores
+ * float64, -1 padded); list_stride is in elements (Q*k when the lists are contiguous, 2*Q*k for an
+ * all-gathered [rank][ids|scores][Q][k] buffer). Output [Q][k] by score desc, id asc. */
 int rag_merge_topk_dev(rag_handle_t h, const int64_t* ids_dev, const double* scores_dev, int n_lists,
-                       int n_queries, int k, int64_t* ids_out_dev, double* scores_out_dev, void* stream);
+                       int64_t list_stride, int n_queries, int k, int64_t* ids_out_dev, double* scores_out_dev,
+                       void* stream);
 
 /* ---- small pairwise cosine in float64: replaces the Python loops
  *      rag/consistency_checker.py:169-176, rag/context_compressor.py:227-228, rag/reranker.py:167-175,

@@ -54,7 +54,7 @@ _SIGS = {
     "rag_dense_topk_dev": ([_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
     "rag_dense_last_stats": ([_P, C.POINTER(DenseStats)], C.c_int),
     "rag_dense_kernel_ms": ([_P, C.POINTER(C.c_float), C.POINTER(C.c_int)], C.c_int),
-    "rag_merge_topk_dev": ([_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P], C.c_int),
+    "rag_merge_topk_dev": ([_P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P, _P], C.c_int),
     "rag_pairwise_cosine_host": ([_P, _P, C.c_int, _P, C.c_int, C.c_int, _P], C.c_int),
     "rag_rrf_fuse_host": ([_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P], C.c_int),
     "rag_bm25_load_host": ([_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double], C.c_int),
@@ -72,6 +72,22 @@ def exported_symbols():
     return sorted(_SIGS)
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (soname libamdhip64.so.7). Two HIP runtimes in one
+    process cannot both own the GPU, and device pointers are only shareable inside one runtime, so when torch is
+    installed its runtime is loaded FIRST: librag_hip.so's DT_NEEDED libamdhip64.so.7 then binds to it."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load_library(path=None):
     """Load librag_hip.so. Fails loudly when it has not been built (`python -c 'import __graft_entry__ as g; g.build()'`)."""
     global _LIB
@@ -81,6 +97,7 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise RagError(f"{p} is missing: build the HIP extension first (__graft_entry__.build()); "
                        "there is no CPU fallback")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(p)
     for name, (args, res) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError = missing export: loud
@@ -213,14 +230,19 @@ class RagEngine:
         self._check(self.lib.rag_dense_kernel_ms(self.h, C.byref(ms), C.byref(n)), "rag_dense_kernel_ms")
         return float(ms.value), int(n.value)
 
-    def merge_topk_dev(self, ids, scores, ids_out, scores_out, stream=None):
-        """ids/scores: [L, Q, k] torch CUDA tensors (int64 / float64) -> [Q, k]."""
+    def merge_topk_dev(self, ids, scores, ids_out, scores_out, n_lists=None, list_stride=None, stream=None):
+        """ids/scores: torch CUDA tensors holding n_lists lists of [Q, k] (int64 / float64), list l at element
+        offset l*list_stride (default: contiguous [L, Q, k]). Output [Q, k], score desc then id asc."""
         import torch
-        L, Q, k = ids.shape
+        Q, k = ids_out.shape
+        if n_lists is None:
+            n_lists = ids.shape[0]
+        if list_stride is None:
+            list_stride = Q * k
         st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
-        self._check(self.lib.rag_merge_topk_dev(self.h, C.c_void_p(ids.data_ptr()), C.c_void_p(scores.data_ptr()), L, Q, k,
-                                                C.c_void_p(ids_out.data_ptr()), C.c_void_p(scores_out.data_ptr()), st),
-                    "rag_merge_topk_dev")
+        self._check(self.lib.rag_merge_topk_dev(self.h, C.c_void_p(ids.data_ptr()), C.c_void_p(scores.data_ptr()),
+                                                int(n_lists), int(list_stride), Q, k, C.c_void_p(ids_out.data_ptr()),
+                                                C.c_void_p(scores_out.data_ptr()), st), "rag_merge_topk_dev")
 
     # ---- small ops --------------------------------------------------------------------------------
     def pairwise_cosine(self, a, b=None):

@@ -85,6 +85,7 @@ int rag_synchronize(rag_handle_t h) {
 int rag_set_profiling(rag_handle_t h, int enable) {
     if (!h) return RAG_ERR_ARG;
     h->profiling = enable != 0;
+    h->gemm_events_used = 0;      // (re)start collecting per-launch events of the dominant kernel
     return RAG_OK;
 }
 
@@ -241,12 +242,12 @@ int rag_dense_kernel_ms(rag_handle_t h, float* gemm_ms_out, int* launches_out) {
     return RAG_OK;
 }
 
-int rag_merge_topk_dev(rag_handle_t h, const int64_t* ids_dev, const double* scores_dev, int n_lists, int Q, int k,
-                       int64_t* ids_out_dev, double* scores_out_dev, void* stream) {
+int rag_merge_topk_dev(rag_handle_t h, const int64_t* ids_dev, const double* scores_dev, int n_lists, int64_t list_stride,
+                       int Q, int k, int64_t* ids_out_dev, double* scores_out_dev, void* stream) {
     if (!h) return RAG_ERR_ARG;
     ARG_CHECK(h, ids_dev && scores_dev && ids_out_dev && scores_out_dev, "null pointer");
     HIP_TRY(h, hipSetDevice(h->device));
-    return merge_topk(h, ids_dev, scores_dev, n_lists, Q, k, ids_out_dev, scores_out_dev,
+    return merge_topk(h, ids_dev, scores_dev, n_lists, list_stride, Q, k, ids_out_dev, scores_out_dev,
                       stream ? (hipStream_t)stream : h->stream);
 }
 

@@ -116,7 +116,7 @@ int dense_index_build(rag_ctx* h, const float* emb_dev, int64_t n_rows, hipStrea
 int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev,
                  double* scores_dev, hipStream_t st);
 int dense_free(rag_ctx* h);
-int merge_topk(rag_ctx* h, const int64_t* ids, const double* scores, int n_lists, int Q, int k, int64_t* ids_out,
-               double* scores_out, hipStream_t st);
+int merge_topk(rag_ctx* h, const int64_t* ids, const double* scores, int n_lists, int64_t list_stride, int Q, int k,
+               int64_t* ids_out, double* scores_out, hipStream_t st);
 int pairwise_cosine(rag_ctx* h, const float* a_dev, int m, const float* b_dev, int n, int dim, double* out_dev,
                     hipStream_t st);

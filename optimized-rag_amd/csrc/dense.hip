@@ -612,7 +612,6 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
     const int total_tiles = (int)(round_up(h->n_rows, RAG_TILE) / RAG_TILE);
     const int stage0_tiles = std::min(total_tiles, RAG_STAGE0_ROWS / RAG_TILE);
     int begin = 0, stage = 0;
-    h->gemm_events_used = 0;
     while (begin < total_tiles) {
         int end;
         if (stage == 0) end = stage0_tiles;
@@ -628,7 +627,7 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
         } else {
             HIP_TRY(h, hipMemcpyAsync(tau_last, tau, (size_t)qpad * sizeof(float), hipMemcpyDeviceToDevice, st));
         }
-        if (h->profiling) {
+        if (h->profiling && stage > 0) {      // the thresholded kernel only (stage 0 is 0.2% of the rows)
             if ((int)h->gemm_events.size() <= h->gemm_events_used) {
                 hipEvent_t a, b;
                 HIP_TRY(h, hipEventCreate(&a));
@@ -644,7 +643,7 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
             hipLaunchKernelGGL(dense_emit_kernel<false>, dim3(grid), dim3(512), 4 * TILE_BYTES, st, h->emb16, h->q16,
                                h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant);
         HIP_TRY(h, hipGetLastError());
-        if (h->profiling) {
+        if (h->profiling && stage > 0) {
             HIP_TRY(h, hipEventRecord(h->gemm_events[h->gemm_events_used].second, st));
             h->gemm_events_used++;
         }
@@ -699,8 +698,8 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
 // merge of per-shard partial lists (multi-GPU exchange step): [L][Q][k] -> [Q][k], score desc, id asc
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void merge_topk_kernel(const int64_t* __restrict__ ids, const double* __restrict__ scores,
-                                                          int n_lists, int Q, int k, int64_t* __restrict__ ids_out,
-                                                          double* __restrict__ scores_out) {
+                                                          int n_lists, int64_t list_stride, int Q, int k,
+                                                          int64_t* __restrict__ ids_out, double* __restrict__ scores_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int total = n_lists * k;
     double* sc = reinterpret_cast<double*>(smem);
@@ -708,8 +707,8 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const int64_t* __restri
     const int q = blockIdx.x, tid = threadIdx.x;
     for (int i = tid; i < total; i += 256) {
         const int l = i / k, j = i % k;
-        sc[i] = scores[((size_t)l * Q + q) * k + j];
-        id[i] = ids[((size_t)l * Q + q) * k + j];
+        sc[i] = scores[(size_t)l * list_stride + (size_t)q * k + j];
+        id[i] = ids[(size_t)l * list_stride + (size_t)q * k + j];
     }
     for (int i = tid; i < k; i += 256) {
         ids_out[(size_t)q * k + i] = -1;
@@ -732,12 +731,14 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const int64_t* __restri
     }
 }
 
-int merge_topk(rag_ctx* h, const int64_t* ids, const double* scores, int n_lists, int Q, int k, int64_t* ids_out,
-               double* scores_out, hipStream_t st) {
+int merge_topk(rag_ctx* h, const int64_t* ids, const double* scores, int n_lists, int64_t list_stride, int Q, int k,
+               int64_t* ids_out, double* scores_out, hipStream_t st) {
     ARG_CHECK(h, n_lists > 0 && Q > 0 && k > 0, "merge: sizes must be positive");
     const size_t lds = (size_t)n_lists * k * 16;
     ARG_CHECK(h, lds <= 64 * 1024, "merge: n_lists*k too large (max 4096 entries)");
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(Q), dim3(256), lds, st, ids, scores, n_lists, Q, k, ids_out, scores_out);
+    ARG_CHECK(h, list_stride >= (int64_t)Q * k, "merge: list_stride < Q*k");
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(Q), dim3(256), lds, st, ids, scores, n_lists, list_stride, Q, k, ids_out,
+                       scores_out);
     HIP_TRY(h, hipGetLastError());
     return RAG_OK;
 }
