@@ -1,0 +1,361 @@
+// K4: BM25 over CSR postings. Replaces BM25Okapi(tokenized_corpus).get_scores(tokenized_query) and the /max
+// normalisation of /root/reference/rag/retrieval.py:324-347 (rank-bm25 0.2.2 semantics, float64).
+//
+// HBM-bound integer/gather work, not a GEMM:
+//   load   : per-posting weight w = tf*(k1+1) / (tf + k1*(1 - b + b*dl/avgdl)) precomputed once in float64 with
+//            rank-bm25's operation order -> postings are (doc int32, w float64): 12 B each, no doc_len gather later.
+//   score  : one workgroup per (query, 16384-doc range). The range's float64 accumulators live in LDS (128 KiB);
+//            for each query token IN ORDER the block binary-searches the term's posting list for its doc range and
+//            adds idf*w (docs are unique inside one posting list -> no atomics, and per-document summation order
+//            is the query-token order, exactly as `score += ...` in get_scores -> bit-identical float64).
+//            Algorithmic traffic per query = sum over tokens of df*12 B; accumulators never touch HBM.
+//   select : per-range exact top-k by 8-pass radix select on order-preserving keys (ties -> lower doc id, i.e.
+//            Python's stable sort), then a per-query merge of the n_ranges*k partials.
+#include "common.h"
+
+#define BM_RANGE 16384
+#define BM_THREADS 512
+#define BM_SEG (BM_RANGE / BM_THREADS)      // 32 contiguous docs per thread
+
+struct rag_bm25_index {
+    int64_t n_docs = 0, n_terms = 0, nnz = 0;
+    int64_t* indptr = nullptr;
+    int32_t* doc = nullptr;
+    double* w = nullptr;
+    double* idf = nullptr;
+    double avgdl = 0, k1 = 1.5, b = 0.75;
+};
+
+__global__ void bm25_weights_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ doc,
+                                    const int32_t* __restrict__ tf, const int32_t* __restrict__ doc_len, int64_t nnz,
+                                    double avgdl, double k1, double b, double* __restrict__ w) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    const double f = (double)tf[p];
+    const double dl = (double)doc_len[doc[p]];
+    // q_freq * (k1 + 1) / (q_freq + k1 * (1 - b + b * doc_len / avgdl))   -- same association as rank-bm25
+    const double num = f * (k1 + 1.0);
+    const double t1 = (b * dl) / avgdl;
+    const double t2 = (1.0 - b) + t1;
+    const double den = f + k1 * t2;
+    w[p] = num / den;
+}
+
+__device__ __forceinline__ int64_t lower_bound_doc(const int32_t* __restrict__ doc, int64_t lo, int64_t hi, int target) {
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (doc[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// mode 0: per-range top-k partials; mode 1: dense scores out[q][doc]
+__global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ doc,
+                                                                 const double* __restrict__ w, const double* __restrict__ idf,
+                                                                 const int32_t* __restrict__ term_ptr, const int32_t* __restrict__ terms,
+                                                                 int64_t n_docs, int64_t n_terms, int k, int mode,
+                                                                 double* __restrict__ dense_out, uint64_t* __restrict__ part_key,
+                                                                 uint32_t* __restrict__ part_row) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sc = reinterpret_cast<double*>(smem);                       // [BM_RANGE]
+    int* hist = reinterpret_cast<int*>(smem + BM_RANGE * 8);            // [256]
+    int* wsum = hist + 256;                                             // [16] scratch
+    const int q = blockIdx.y, r = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int64_t base = (int64_t)r * BM_RANGE;
+    const int lim = (int)min((int64_t)BM_RANGE, n_docs - base);
+    for (int i = tid; i < BM_RANGE; i += BM_THREADS) sc[i] = 0.0;
+    __syncthreads();
+    const int t0 = term_ptr[q], t1 = term_ptr[q + 1];
+    for (int ti = t0; ti < t1; ++ti) {
+        const int t = terms[ti];
+        if (t < 0 || t >= n_terms) continue;                 // out-of-vocabulary token: idf.get(q) is None -> 0
+        const double f = idf[t];
+        if (f == 0.0) continue;                              // (idf or 0) * x == 0: adds nothing
+        const int64_t lo = indptr[t], hi = indptr[t + 1];
+        const int64_t a = lower_bound_doc(doc, lo, hi, (int)base);
+        const int64_t e = lower_bound_doc(doc, a, hi, (int)(base + lim));
+        for (int64_t p = a + tid; p < e; p += BM_THREADS) sc[doc[p] - (int)base] += f * w[p];
+        __syncthreads();
+    }
+    if (mode == 1) {
+        for (int i = tid; i < lim; i += BM_THREADS) dense_out[(size_t)q * n_docs + base + i] = sc[i];
+        return;
+    }
+    // ---- exact top-k of sc[0..lim): radix select of the k-th largest key, ties by lower doc ------------
+    const size_t po = ((size_t)q * gridDim.x + r) * k;
+    if (lim <= k) {
+        for (int i = tid; i < k; i += BM_THREADS) {
+            part_key[po + i] = i < lim ? f64_orderable(sc[i]) : 0ull;
+            part_row[po + i] = (uint32_t)(base + i);
+        }
+        return;
+    }
+    const int seg0 = tid * BM_SEG;
+    uint64_t prefix = 0ull;          // matched high bytes of the pivot
+    int remaining = k;               // the pivot is the `remaining`-th largest among keys matching `prefix`
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        int cur = -1, run = 0;
+        for (int j = 0; j < BM_SEG; ++j) {
+            const int i = seg0 + j;
+            if (i >= lim) break;
+            const uint64_t key = f64_orderable(sc[i]);
+            const bool match = pass == 0 || (key >> (shift + 8)) == prefix;
+            if (!match) continue;
+            const int d = (int)((key >> shift) & 0xFF);
+            if (d == cur) { ++run; } else {
+                if (run) atomicAdd(&hist[cur], run);
+                cur = d; run = 1;
+            }
+        }
+        if (run) atomicAdd(&hist[cur], run);
+        __syncthreads();
+        // suffix sums over the 256 bins (4 waves x 64 bins), find the bin holding the `remaining`-th largest
+        int suf = 0;
+        if (tid < 256) {
+            int v = hist[tid];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_down(v, o);
+                if (lane + o < 64) v += up;
+            }
+            suf = v;                                     // sum of bins [tid .. end of this wave's 64]
+            if (lane == 0) wsum[wv] = v;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            for (int u = wv + 1; u < 4; ++u) suf += wsum[u];      // bins of higher waves
+            const int above = suf - hist[tid];                    // count of keys in bins > tid
+            if (above < remaining && remaining <= suf) {          // exactly one bin satisfies this
+                wsum[8] = tid;
+                wsum[9] = remaining - above;
+            }
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | (uint64_t)wsum[8];
+        remaining = wsum[9];
+        __syncthreads();
+    }
+    const uint64_t pivot = prefix;                      // exact key of the k-th largest
+    const int need_ties = remaining;                    // how many keys == pivot belong to the top-k (lowest docs first)
+    // ordered collection: every key > pivot, plus the first `need_ties` keys == pivot in doc order
+    int n_gt = 0, n_eq = 0;
+    for (int j = 0; j < BM_SEG; ++j) {
+        const int i = seg0 + j;
+        if (i >= lim) break;
+        const uint64_t key = f64_orderable(sc[i]);
+        n_gt += key > pivot;
+        n_eq += key == pivot;
+    }
+    // block exclusive scans of n_gt and n_eq (thread order == doc order)
+    int s_gt = n_gt, s_eq = n_eq;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int a1 = __shfl_up(s_gt, o), a2 = __shfl_up(s_eq, o);
+        if (lane >= o) { s_gt += a1; s_eq += a2; }
+    }
+    if (lane == 63) { hist[wv] = s_gt; hist[16 + wv] = s_eq; }
+    __syncthreads();
+    int off_gt = s_gt - n_gt, off_eq = s_eq - n_eq, total_gt = 0;
+    for (int u = 0; u < BM_THREADS / 64; ++u) {
+        if (u < wv) { off_gt += hist[u]; off_eq += hist[16 + u]; }
+        total_gt += hist[u];
+    }
+    for (int j = 0; j < BM_SEG; ++j) {
+        const int i = seg0 + j;
+        if (i >= lim) break;
+        const uint64_t key = f64_orderable(sc[i]);
+        if (key > pivot) {
+            part_key[po + off_gt] = key;
+            part_row[po + off_gt] = (uint32_t)(base + i);
+            ++off_gt;
+        } else if (key == pivot) {
+            if (off_eq < need_ties) {
+                part_key[po + total_gt + off_eq] = key;
+                part_row[po + total_gt + off_eq] = (uint32_t)(base + i);
+            }
+            ++off_eq;
+        }
+    }
+}
+
+#define BM_MERGE 2048
+__device__ __forceinline__ void bm_sort_pairs(uint64_t* k1, uint32_t* k2, int P, int tid, int nthreads) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += nthreads) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool first_block = ((i & k) == 0);
+                    const bool a_before_b = k1[i] > k1[ixj] || (k1[i] == k1[ixj] && k2[i] < k2[ixj]);
+                    if (first_block ? !a_before_b : a_before_b) {
+                        const uint64_t t1 = k1[i]; k1[i] = k1[ixj]; k1[ixj] = t1;
+                        const uint32_t t2 = k2[i]; k2[i] = k2[ixj]; k2[ixj] = t2;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bm25_merge_kernel(const uint64_t* __restrict__ part_key, const uint32_t* __restrict__ part_row,
+                                                          int n_ranges, int k, int64_t* __restrict__ ids_out,
+                                                          int32_t* __restrict__ rows_out, double* __restrict__ scores_out,
+                                                          double* __restrict__ raw_max_out) {
+    __shared__ uint64_t sk[BM_MERGE];
+    __shared__ uint32_t sr[BM_MERGE];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int total = n_ranges * k;
+    const uint64_t* pk = part_key + (size_t)q * total;
+    const uint32_t* pr = part_row + (size_t)q * total;
+    for (int i = tid; i < BM_MERGE; i += 256) { sk[i] = 0ull; sr[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    int pos = 0;
+    while (pos < total) {
+        const int room = BM_MERGE - k;
+        const int take = min(room, total - pos);
+        for (int i = tid; i < room; i += 256) {
+            sk[k + i] = i < take ? pk[pos + i] : 0ull;
+            sr[k + i] = i < take ? pr[pos + i] : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        bm_sort_pairs(sk, sr, BM_MERGE, tid, 256);
+        pos += take;
+    }
+    // top-1 raw score -> divisor (max if > 0 else 1.0), retrieval.py:344
+    uint64_t u0 = sk[0];
+    double mx = 1.0;
+    if (u0 != 0ull) {
+        u0 = (u0 & 0x8000000000000000ull) ? (u0 & 0x7fffffffffffffffull) : ~u0;
+        const double top = __builtin_bit_cast(double, u0);
+        if (top > 0.0) mx = top;
+    }
+    if (tid == 0 && raw_max_out) raw_max_out[q] = mx;
+    for (int i = tid; i < k; i += 256) {
+        const bool ok = sk[i] != 0ull;
+        uint64_t u = sk[i];
+        u = (u & 0x8000000000000000ull) ? (u & 0x7fffffffffffffffull) : ~u;
+        const double s = __builtin_bit_cast(double, u);
+        ids_out[(size_t)q * k + i] = ok ? (int64_t)sr[i] : -1;
+        if (rows_out) rows_out[(size_t)q * k + i] = ok ? (int32_t)sr[i] : -1;
+        scores_out[(size_t)q * k + i] = ok ? s / mx : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+void bm25_free(rag_ctx* h) {
+    if (!h->bm25) return;
+    hipFree(h->bm25->indptr); hipFree(h->bm25->doc); hipFree(h->bm25->w); hipFree(h->bm25->idf);
+    delete h->bm25;
+    h->bm25 = nullptr;
+}
+
+int bm25_load_host(rag_ctx* h, const int64_t* indptr, const int32_t* doc, const int32_t* tf, const int32_t* doc_len,
+                   const double* idf, int64_t n_docs, int64_t n_terms, double avgdl, double k1, double b) {
+    ARG_CHECK(h, n_docs > 0 && n_terms >= 0 && n_docs < 0x7fffffff, "bm25_load: bad sizes");
+    ARG_CHECK(h, indptr && doc_len && (n_terms == 0 || idf), "bm25_load: null pointer");
+    const int64_t nnz = n_terms ? indptr[n_terms] : 0;
+    ARG_CHECK(h, nnz == 0 || (doc && tf), "bm25_load: null postings");
+    bm25_free(h);
+    rag_bm25_index* ix = new rag_bm25_index();
+    h->bm25 = ix;
+    ix->n_docs = n_docs; ix->n_terms = n_terms; ix->nnz = nnz; ix->avgdl = avgdl; ix->k1 = k1; ix->b = b;
+    hipStream_t st = h->stream;
+    int32_t *tfd = nullptr, *dld = nullptr;
+    HIP_TRY(h, hipMalloc(&ix->indptr, (size_t)(n_terms + 1) * sizeof(int64_t)));
+    HIP_TRY(h, hipMalloc(&ix->doc, std::max<size_t>(1, nnz) * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc(&ix->w, std::max<size_t>(1, nnz) * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&ix->idf, std::max<size_t>(1, n_terms) * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&tfd, std::max<size_t>(1, nnz) * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc(&dld, (size_t)n_docs * sizeof(int32_t)));
+    HIP_TRY(h, hipMemcpyAsync(ix->indptr, indptr, (size_t)(n_terms + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    if (nnz) {
+        HIP_TRY(h, hipMemcpyAsync(ix->doc, doc, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipMemcpyAsync(tfd, tf, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    }
+    if (n_terms) HIP_TRY(h, hipMemcpyAsync(ix->idf, idf, (size_t)n_terms * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(dld, doc_len, (size_t)n_docs * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (nnz) {
+        hipLaunchKernelGGL(bm25_weights_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, ix->indptr, ix->doc, tfd,
+                           dld, nnz, avgdl, k1, b, ix->w);
+        HIP_TRY(h, hipGetLastError());
+    }
+    HIP_TRY(h, hipStreamSynchronize(st));
+    hipFree(tfd); hipFree(dld);
+    return RAG_OK;
+}
+
+static int bm25_run(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, int k, int mode, int64_t* ids_out,
+                    int32_t* rows_out, double* scores_out, double* raw_max_out, double* dense_out) {
+    ARG_CHECK(h, h->bm25 != nullptr, "no BM25 index loaded");
+    ARG_CHECK(h, Q > 0 && Q <= 65535 && term_ptr, "bm25: 1 <= n_queries <= 65535");
+    rag_bm25_index* ix = h->bm25;
+    const int n_terms_q = term_ptr[Q];
+    ARG_CHECK(h, n_terms_q >= 0 && (n_terms_q == 0 || terms), "bm25: bad term arrays");
+    if (mode == 0) ARG_CHECK(h, k > 0 && k <= BM_MERGE / 2 && k <= BM_RANGE, "bm25: 0 < k <= 1024");
+    hipStream_t st = h->stream;
+    const int n_ranges = (int)((ix->n_docs + BM_RANGE - 1) / BM_RANGE);
+    static bool attr = false;
+    if (!attr) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bm25_range_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, BM_RANGE * 8 + 2048));
+        attr = true;
+    }
+    int32_t *tp = nullptr, *tm = nullptr;
+    uint64_t* pk = nullptr;
+    uint32_t* pr = nullptr;
+    int64_t* idd = nullptr;
+    int32_t* rwd = nullptr;
+    double *scd = nullptr, *mxd = nullptr, *dd = nullptr;
+    hipError_t e = hipMalloc(&tp, (size_t)(Q + 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&tm, std::max<size_t>(1, n_terms_q) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(tp, term_ptr, (size_t)(Q + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_terms_q) e = hipMemcpyAsync(tm, terms, (size_t)n_terms_q * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (mode == 0) {
+        if (e == hipSuccess) e = hipMalloc(&pk, (size_t)Q * n_ranges * k * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMalloc(&pr, (size_t)Q * n_ranges * k * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&idd, (size_t)Q * k * sizeof(int64_t));
+        if (e == hipSuccess) e = hipMalloc(&rwd, (size_t)Q * k * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc(&scd, (size_t)Q * k * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc(&mxd, (size_t)Q * sizeof(double));
+    } else {
+        if (e == hipSuccess) e = hipMalloc(&dd, (size_t)Q * ix->n_docs * sizeof(double));
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(bm25_range_kernel, dim3(n_ranges, Q), dim3(BM_THREADS), BM_RANGE * 8 + 2048, st, ix->indptr, ix->doc,
+                           ix->w, ix->idf, tp, tm, ix->n_docs, ix->n_terms, k, mode, dd, pk, pr);
+        if (mode == 0)
+            hipLaunchKernelGGL(bm25_merge_kernel, dim3(Q), dim3(256), 0, st, pk, pr, n_ranges, k, idd, rwd, scd, mxd);
+        e = hipGetLastError();
+    }
+    if (mode == 0) {
+        if (e == hipSuccess) e = hipMemcpyAsync(ids_out, idd, (size_t)Q * k * sizeof(int64_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && rows_out) e = hipMemcpyAsync(rows_out, rwd, (size_t)Q * k * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(scores_out, scd, (size_t)Q * k * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && raw_max_out) e = hipMemcpyAsync(raw_max_out, mxd, (size_t)Q * sizeof(double), hipMemcpyDeviceToHost, st);
+    } else if (e == hipSuccess) {
+        e = hipMemcpyAsync(dense_out, dd, (size_t)Q * ix->n_docs * sizeof(double), hipMemcpyDeviceToHost, st);
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
+    hipFree(tp); hipFree(tm); hipFree(pk); hipFree(pr); hipFree(idd); hipFree(rwd); hipFree(scd); hipFree(mxd); hipFree(dd);
+    if (e != hipSuccess || e2 != hipSuccess) {
+        h->err = std::string("bm25: ") + hipGetErrorString(e != hipSuccess ? e : e2);
+        return RAG_ERR_HIP;
+    }
+    return RAG_OK;
+}
+
+int bm25_topk_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, int k, int64_t* ids_out,
+                   int32_t* rows_out, double* scores_out, double* raw_max_out) {
+    ARG_CHECK(h, ids_out && scores_out, "bm25_topk: null output");
+    return bm25_run(h, term_ptr, terms, Q, k, 0, ids_out, rows_out, scores_out, raw_max_out, nullptr);
+}
+
+int bm25_scores_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, double* out) {
+    ARG_CHECK(h, out, "bm25_scores: null output");
+    return bm25_run(h, term_ptr, terms, Q, 1, 1, nullptr, nullptr, nullptr, nullptr, out);
+}

@@ -424,33 +424,51 @@ __device__ __forceinline__ void bitonic_sort_pairs(uint64_t* k1, uint32_t* k2, i
     }
 }
 
+// flagged queries are rare: a 1-block kernel compacts them into a list so the scan launches a corpus-sized grid
+// (one block per 2048-row chunk, looping over the list) instead of Q x chunks early-exit blocks.
+__global__ __launch_bounds__(256) void scan_list_kernel(const int* __restrict__ flag, int Q, int* __restrict__ list,
+                                                         int* __restrict__ count) {
+    __shared__ int n;
+    if (threadIdx.x == 0) n = 0;
+    __syncthreads();
+    for (int q = threadIdx.x; q < Q; q += 256)
+        if (flag[q] == 2) list[atomicAdd(&n, 1)] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) *count = n;
+}
+
 __global__ __launch_bounds__(256) void scan_chunk_kernel(const float* __restrict__ q32, const float* __restrict__ emb32,
                                                           const int32_t* __restrict__ tenants, int tenant, int64_t n_rows,
-                                                          int dim, int k, const int* __restrict__ flag,
-                                                          uint64_t* __restrict__ part_key, uint32_t* __restrict__ part_row) {
+                                                          int dim, int k, const int* __restrict__ list,
+                                                          const int* __restrict__ count, uint64_t* __restrict__ part_key,
+                                                          uint32_t* __restrict__ part_row) {
     __shared__ uint64_t sk[SCAN_CHUNK];
     __shared__ uint32_t sr[SCAN_CHUNK];
-    const int q = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (flag[q] != 2) return;
+    const int chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n_flagged = *count;
     const int64_t base = (int64_t)chunk * SCAN_CHUNK;
-    for (int i = wv; i < SCAN_CHUNK; i += 4) {
-        const int64_t row = base + i;
-        uint64_t key = 0ull;          // 0 = empty (below every real score: orderable(-inf) > 0)
-        if (row < n_rows && (tenants == nullptr || tenants[row] == tenant)) {
-            const double v = exact_cosine_wave(q32 + (size_t)q * dim, emb32 + (size_t)row * dim, dim, lane);
-            key = f64_orderable(v);
+    for (int f = 0; f < n_flagged; ++f) {
+        const int q = list[f];
+        for (int i = wv; i < SCAN_CHUNK; i += 4) {
+            const int64_t row = base + i;
+            uint64_t key = 0ull;          // 0 = empty (below every real score: orderable(-inf) > 0)
+            if (row < n_rows && (tenants == nullptr || tenants[row] == tenant)) {
+                const double v = exact_cosine_wave(q32 + (size_t)q * dim, emb32 + (size_t)row * dim, dim, lane);
+                key = f64_orderable(v);
+            }
+            if (lane == 0) {
+                sk[i] = key;
+                sr[i] = (uint32_t)row;
+            }
         }
-        if (lane == 0) {
-            sk[i] = key;
-            sr[i] = (uint32_t)row;
+        __syncthreads();
+        bitonic_sort_pairs(sk, sr, SCAN_CHUNK, tid, 256);
+        const size_t o = ((size_t)q * gridDim.x + chunk) * k;
+        for (int i = tid; i < k; i += 256) {
+            part_key[o + i] = sk[i];
+            part_row[o + i] = sr[i];
         }
-    }
-    __syncthreads();
-    bitonic_sort_pairs(sk, sr, SCAN_CHUNK, tid, 256);
-    const size_t o = ((size_t)q * gridDim.x + chunk) * k;
-    for (int i = tid; i < k; i += 256) {
-        part_key[o + i] = sk[i];
-        part_row[o + i] = sr[i];
+        __syncthreads();
     }
 }
 
@@ -679,8 +697,11 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
         }
         uint64_t* pk = reinterpret_cast<uint64_t*>(h->scan_scores);
         uint32_t* pr = reinterpret_cast<uint32_t*>(pk + need);
-        hipLaunchKernelGGL(scan_chunk_kernel, dim3(n_chunks, Q), dim3(256), 0, st, q_dev, h->emb32, tenants, tenant,
-                           h->n_rows, h->dim, k, h->flag, pk, pr);
+        int* scan_list = h->n_sorted;                 // free after the wide kernel; [Q] ints
+        int* scan_count = h->stats + 7;
+        hipLaunchKernelGGL(scan_list_kernel, dim3(1), dim3(256), 0, st, h->flag, Q, scan_list, scan_count);
+        hipLaunchKernelGGL(scan_chunk_kernel, dim3(n_chunks), dim3(256), 0, st, q_dev, h->emb32, tenants, tenant,
+                           h->n_rows, h->dim, k, scan_list, scan_count, pk, pr);
         hipLaunchKernelGGL(scan_merge_kernel, dim3(Q), dim3(256), 0, st, pk, pr, n_chunks, k, h->ids, h->id_base, h->flag,
                            ids_dev, rows_dev, scores_dev, h->stats);
         HIP_TRY(h, hipGetLastError());

@@ -1,0 +1,356 @@
+"""GPU parity for fusion (RRF, linear), BM25 and the Python mirror classes: HIP path through the C-ABI vs the
+golden vectors generated from the reference and vs the CPU oracle. Integer ranks / id lists bit-exact; float64
+scores bit-exact where the operation order is reproduced (RRF, BM25, linear fusion), else within 1e-12."""
+import json
+import os
+from datetime import datetime
+
+import numpy as np
+import pytest
+
+from oracle import rag_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from optimized_rag_amd import RagEngine
+    e = RagEngine(dim=1536, device=0)
+    yield e
+    e.close()
+
+
+def load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+# ---------------------------------------------------------------------------------------- RRF
+def test_rrf_golden_bit_exact(eng, golden_dir):
+    from optimized_rag_amd.reranker import ReciprocalRankFusion
+    g = load(golden_dir, "rrf.json")
+    for c in g["cases"]:
+        lists = [[{"content": f"doc-{i}", "id": i} for i in l] for l in c["lists"]]
+        fused = ReciprocalRankFusion(k=c["k"], engine=eng).fuse(lists, top_k=c["top_k"])
+        assert [d["id"] for d in fused] == c["expected_ids"]
+        assert [d["rrf_score"] for d in fused] == c["expected_scores"]          # bit-exact float64
+    d = g["dup"]
+    lists = [[({"content": x} if x is not None else {}) for x in l] for l in d["lists"]]
+    fused = ReciprocalRankFusion(k=60, engine=eng).fuse(lists, top_k=10)
+    assert [x.get("content", "") for x in fused] == d["expected_contents"]
+    assert [x["rrf_score"] for x in fused] == d["expected_scores"]
+    assert ReciprocalRankFusion(engine=eng).fuse([[], []]) == []
+
+
+def test_rrf_batched_ranks_vs_oracle(eng):
+    """BASELINE config 3 shape: Q queries x 2 lists (dense, bm25) x K'=100 -> top-20, ranks bit-exact."""
+    rng = np.random.default_rng(1)
+    Q, L, ln, k = 64, 2, 100, 20
+    lists = np.stack([np.stack([rng.permutation(400)[:ln] for _ in range(L)]) for _ in range(Q)]).astype(np.int64)
+    lists[3, 1, 60:] = -1                                      # ragged list
+    lists[4, 0, :] = -1                                        # empty list
+    keys, scores, ranks = eng.rrf_fuse(lists, rrf_k=60, top_k=k)
+    for q in range(Q):
+        ls = [[int(x) for x in lists[q, l] if x >= 0] for l in range(L)]
+        okeys, oscores, oranks = O.rrf_fuse(ls, k=60, top_k=k)
+        n = len(okeys)
+        assert keys[q, :n].tolist() == okeys and (keys[q, n:] == -1).all()
+        assert scores[q, :n].tolist() == oscores
+        assert ranks[q, :n].tolist() == oranks
+
+
+# ---------------------------------------------------------------------------------------- hybrid_search
+def _hr(eng, c):
+    from optimized_rag_amd.retrieval import HybridRetriever
+    a, b, g_ = c["alpha_beta_gamma_default"]
+    hr = HybridRetriever(None, None, "agent-x", a, b, g_, use_adaptive_weights=c["use_adaptive_weights"], engine=eng)
+    hr._now = lambda: datetime.fromisoformat(c["now"])
+    return hr
+
+
+def test_hybrid_search_golden_keyword_path(eng, golden_dir):
+    """The fixture was produced by the reference with rank_bm25 absent (keyword-overlap path)."""
+    g = load(golden_dir, "hybrid_search.json")
+    for c in g["cases"]:
+        hr = _hr(eng, c)
+        hr.bm25_available = False
+        emb = [[float(np.float32(x)) for x in row] for row in c["embeddings"]]
+        out = hr.hybrid_search(c["query"], c["corpus"], emb, [float(np.float32(x)) for x in c["query_embedding"]],
+                               top_k=c["top_k"], documents_metadata=c["metadata"], query_intent=c["intent"])
+        assert [r["content"] for r in out] == [c["corpus"][i] for i in c["expected_idx"]]
+        for r, e, hm in zip(out, c["expected"], c["expected_has_metadata"]):
+            for key in e:
+                assert abs(r[key] - e[key]) < 1e-12, key
+            assert ("metadata" in r) == hm
+        # identity of the returned rows (duplicates keep input order)
+        assert [r["embedding"] is emb[i] for r, i in zip(out, c["expected_idx"])] == [True] * len(out)
+    for kc in g["keyword"]:
+        assert _hr(eng, g["cases"][0])._simple_keyword_scores(kc["query"], kc["corpus"]) == kc["expected"]
+
+
+def test_hybrid_search_bm25_path_vs_oracle(eng):
+    import tools_textgen as T
+    rng = np.random.default_rng(11)
+    corpus = [T.make_doc(rng, int(rng.integers(1, 6))) for _ in range(200)]
+    corpus[7] = corpus[3]
+    corpus[50] = ""
+    emb = rng.standard_normal((200, 256)).astype(np.float32)
+    qe = rng.standard_normal(256).astype(np.float32)
+    from optimized_rag_amd.retrieval import HybridRetriever
+    hr = HybridRetriever(None, None, "a", engine=eng)
+    for query, intent in [("memory vector index", "search"), ("paris paris london", None), ("zzz unknown", "summarization")]:
+        out = hr.hybrid_search(query, corpus, emb.tolist(), qe.tolist(), top_k=15, query_intent=intent)
+        idx, rows = O.hybrid_search(query, corpus, emb, qe, top_k=15, intent=intent, bm25_available=True)
+        assert [r["content"] for r in out] == [corpus[i] for i in idx]
+        for r, e in zip(out, rows):
+            assert r["keyword_score"] == e["keyword_score"]                 # BM25 float64 bit-exact
+            assert abs(r["semantic_score"] - e["semantic_score"]) < 1e-12
+            assert abs(r["hybrid_score"] - e["hybrid_score"]) < 1e-12
+    assert hr._bm25_scores("q", ["", "  "]) == [0.0, 0.0]
+    assert hr.hybrid_search("q", [], [], qe.tolist()) == []
+
+
+# ---------------------------------------------------------------------------------------- BM25 index path
+def synthetic_postings(rng, n_docs, vocab, mean_len):
+    """doc length ~ Poisson(mean_len), tokens Zipf(1.1) over `vocab` ids; returns docs as token-id lists."""
+    lens = rng.poisson(mean_len, n_docs)
+    docs = []
+    for L in lens:
+        t = rng.zipf(1.1, int(L)) - 1
+        docs.append([int(x) % vocab for x in t])
+    return docs
+
+
+def test_bm25_topk_vs_oracle(eng):
+    from optimized_rag_amd.bm25 import Bm25Postings
+    rng = np.random.default_rng(21)
+    n_docs = 40000                                               # 3 doc ranges of 16384
+    docs = synthetic_postings(rng, n_docs, 5000, 30)
+    docs[100] = []                                               # empty doc
+    corpus = [" ".join(f"t{t}" for t in d) for d in docs]
+    post = Bm25Postings.from_corpus(corpus).load(eng)
+    obm = O.BM25Okapi([O.tokenize(c) for c in corpus])
+    np.testing.assert_array_equal(post.idf, [obm.idf[w] for w in post.vocab])          # idf table bit-exact
+    queries = []
+    for _ in range(12):
+        d = docs[int(rng.integers(0, n_docs))] or [1]
+        queries.append(" ".join(f"t{t}" for t in rng.choice(d, size=min(len(d), int(rng.integers(1, 9))))))
+    queries += ["t0 t0 t1", "nosuchtoken", "t4999 nosuchtoken t3"]
+    ptr, terms = post.encode_queries(queries)
+    k = 100
+    ids, rows, scores, mx = eng.bm25_topk(ptr, terms, k)
+    dense = eng.bm25_scores(ptr, terms)
+    for qi, q in enumerate(queries):
+        raw = obm.get_scores(O.tokenize(q))
+        np.testing.assert_array_equal(dense[qi], raw)                                # float64 bit-exact, all docs
+        m = raw.max() if raw.max() > 0 else 1.0
+        assert mx[qi] == m
+        top = O.stable_topk_desc(raw, k)
+        np.testing.assert_array_equal(rows[qi], top.astype(np.int32))
+        np.testing.assert_array_equal(scores[qi], raw[top] / m)
+
+
+def test_bm25_edge_fewer_docs_than_k(eng):
+    from optimized_rag_amd.bm25 import Bm25Postings
+    corpus = ["a b b c", "a d", "b b b b e f", "g"]
+    post = Bm25Postings.from_corpus(corpus).load(eng)
+    ptr, terms = post.encode_queries(["b c c zzz", ""])
+    ids, rows, scores, mx = eng.bm25_topk(ptr, terms, 6)
+    exp = O.bm25_scores("b c c zzz", corpus)                    # idf("b") is exactly 0.0 here: only doc 0 scores
+    order = [int(i) for i in O.stable_topk_desc(exp, 6)]
+    assert rows[0].tolist() == order + [-1, -1]
+    assert scores[0][:4].tolist() == [exp[i] for i in order] and scores[0][0] == 1.0
+    assert rows[1].tolist() == [0, 1, 2, 3, -1, -1] and mx[1] == 1.0              # empty query: all zeros, index order
+
+
+def test_linear_fuse_large_n_ties(eng):
+    rng = np.random.default_rng(31)
+    n = 50000
+    sem = np.round(rng.uniform(-1, 1, n), 2)                      # many exact ties
+    kw = np.round(rng.uniform(0, 1, n), 1)
+    tmp = rng.uniform(0, 0.15, n) * (rng.uniform(size=n) < 0.1)
+    idx, hyb = eng.linear_fuse_topk(sem, kw, tmp, 0.55, 0.35, 0.10, 200)
+    exp = [0.55 * sem[i] + 0.35 * kw[i] + 0.10 * tmp[i] for i in range(n)]
+    assert hyb.tolist() == exp                                    # same float64 operations as CPython
+    assert idx.tolist() == [int(i) for i in O.stable_topk_desc(exp, 200)]
+
+
+# ---------------------------------------------------------------------------------------- MMR, rerankers
+def test_mmr_both_variants_golden(eng, golden_dir):
+    from optimized_rag_amd.nodes_helpers import apply_mmr
+    from optimized_rag_amd.reranker import MMRDiversifier
+    g = load(golden_dir, "mmr.json")
+    for c in g["class"]:
+        docs = [{"content": f"d{i}", "embedding": [float(np.float32(x)) for x in e], "pos": i} for i, e in enumerate(c["emb"])]
+        out = MMRDiversifier(c["lambda"], engine=eng).diversify([float(np.float32(x)) for x in c["q"]], docs, top_k=c["top_k"])
+        assert [d["pos"] for d in out] == c["expected_pos"]
+        np.testing.assert_allclose([d["mmr_score"] for d in out], c["expected_mmr"], atol=1e-12)
+    docs = [{"content": "a", "embedding": [1.0, 0.0]}, {"content": "b", "embedding": []},
+            {"content": "c", "embedding": [float("nan"), 1.0]}, {"content": "d"},
+            {"content": "e", "embedding": [0.6, 0.8]}, {"content": "f", "embedding": [float("inf"), 1.0]},
+            {"content": "g", "embedding": (1.0, 0.0)}]
+    out = MMRDiversifier(0.7, engine=eng).diversify([1.0, 0.2], docs, top_k=5)
+    assert [d["content"] for d in out] == g["invalid"]["expected_contents"]
+    np.testing.assert_allclose([d["mmr_score"] for d in out], g["invalid"]["expected_mmr"], atol=1e-12)
+    out2 = MMRDiversifier(0.7, engine=eng).diversify([1.0, 0.2], [{"content": "b", "embedding": []}, {"content": "d"}], top_k=1)
+    assert [d["content"] for d in out2] == g["invalid"]["none_valid_contents"]
+    for c in g["helper"]:
+        q = [float(np.float32(x)) for x in c["q"]]
+
+        class Svc:
+            def generate_embedding(self, text):
+                return q
+
+        docs = [{"content": f"d{i}", "embedding": [float(np.float32(x)) for x in e], "pos": i} for i, e in enumerate(c["emb"])]
+        out = apply_mmr("the query", docs, c["lambda"], c["k"], Svc(), engine=eng)
+        assert [d["pos"] for d in out] == c["expected_pos"]
+
+
+def test_rerankers_golden(eng, golden_dir):
+    from optimized_rag_amd.reranker import CrossEncoderReranker, OpenAIReranker
+    g = load(golden_dir, "rerankers.json")
+    oai = g["openai"]
+    emb = np.array(oai["emb"], dtype=np.float32)
+
+    class Item:
+        def __init__(self, e):
+            self.embedding = e
+
+    class Client:
+        class embeddings:
+            @staticmethod
+            def create(input, model):
+                class R:
+                    data = [Item([float(x) for x in emb[i]]) for i in range(len(input))]
+                return R()
+
+    res = [dict(d) for d in oai["results"]]
+    out = OpenAIReranker(Client(), "m", engine=eng).rerank("q", res, top_k=oai["top_k"])
+    assert [d["pos"] for d in out] == oai["expected_pos"]
+    np.testing.assert_allclose([d["rerank_score"] for d in out], oai["expected_rerank"], atol=1e-12)
+    assert all("embedding" in d for d in res)
+
+    class Bad:
+        class embeddings:
+            @staticmethod
+            def create(input, model):
+                raise RuntimeError("down")
+
+    assert [d["pos"] for d in OpenAIReranker(Bad(), "m", engine=eng).rerank("q", [dict(d) for d in oai["results"]], top_k=4)] == oai["fail_pos"]
+
+    cr = g["cross"]
+    ce = CrossEncoderReranker(model_name="cross-encoder/ms-marco-MiniLM-L-6-v2", engine=eng)     # not a local dir
+    assert ce.is_available() is False
+    assert [d["pos"] for d in ce.rerank("q", [dict(d) for d in cr["docs"]], top_k=3)] == cr["fallback_pos"]
+    seen = {}
+
+    class Fake:
+        def predict(self, pairs):
+            seen["len"] = [len(p[1]) for p in pairs]
+            return np.array(cr["logits"], dtype=np.float32)
+
+    ce.model = Fake()
+    out = ce.rerank("the query", [dict(d) for d in cr["docs"]], top_k=cr["top_k"])
+    assert seen["len"] == cr["pairs_len"]
+    for d, e in zip(out, cr["expected"]):
+        for key in ("pos", "score", "cross_encoder_score", "cross_encoder_raw_score"):
+            assert d[key] == e[key]
+        assert d.get("embedding_score") == e["embedding_score"]
+
+
+# ---------------------------------------------------------------------------------------- consistency / compressor
+def test_consistency_golden(eng, golden_dir):
+    from optimized_rag_amd.consistency_checker import ConsistencyChecker
+    g = load(golden_dir, "consistency.json")
+    for c in g["cases"]:
+        table = c["embeddings"]
+
+        class Svc:
+            def generate_embeddings_batch(self, texts):
+                return [table[t] for t in texts]
+
+        chk = ConsistencyChecker(Svc(), similarity_threshold=c["threshold"], engine=eng)
+        for d, exp in zip(c["docs"], c["expected_claims"]):
+            assert chk._extract_claims(d["content"]) == exp
+        out = chk.check_consistency([dict(d) for d in c["docs"]], "some query")
+        exp = c["expected"]
+        assert abs(out.pop("confidence") - exp.pop("confidence")) < 1e-12
+        assert out == exp
+    e = g["edge"]
+    chk = ConsistencyChecker(None, engine=eng)
+    assert chk.check_consistency([{"content": "x"}], "q") == e["one_doc"]
+    assert chk.check_consistency([{"content": "Tiny."}, {"content": "Also tiny."}], "q") == e["few_claims"]
+
+    class Boom:
+        def generate_embeddings_batch(self, t):
+            raise RuntimeError("embedding backend down")
+
+    assert ConsistencyChecker(Boom(), engine=eng).check_consistency(e["embed_fail_docs"], "q") == e["embed_fail"]
+    for p in e["is_contradiction"]:
+        assert chk._is_contradiction(p["a"], p["b"]) == p["expected"]
+
+
+def test_compressor_golden(eng, golden_dir):
+    from optimized_rag_amd.context_compressor import ContextCompressor
+    g = load(golden_dir, "compressor.json")
+
+    def svc_for(table):
+        class Svc:
+            def generate_embedding(self, t):
+                return table[t]
+
+            def generate_embeddings_batch(self, ts):
+                return [table[t] for t in ts]
+        return Svc()
+
+    for c in g["cases"]:
+        comp = ContextCompressor(max_tokens=c["max_tokens"], sentences_per_doc=c["sentences_per_doc"],
+                                 embedding_service=svc_for(c["embeddings"]), conservative_mode=c["conservative"], engine=eng)
+        out = comp.compress(c["query"], [dict(d) for d in c["docs"]], query_intent="question_answering", confidence=c["confidence"])
+        assert out == c["expected"]
+        assert comp.get_compression_stats(out) == c["expected_stats"]
+    sh = g["score_hybrid"]
+    comp = ContextCompressor(embedding_service=svc_for(sh["embeddings"]), conservative_mode=False, engine=eng)
+    got = [s for _, s in comp._score_sentences_hybrid(sh["query"], sh["sentences"])]
+    np.testing.assert_allclose(got, sh["expected"], atol=1e-12)
+    for c in g["lexical"]:
+        assert abs(comp._score_sentence_lexical(c["q"], c["s"]) - c["expected"]) < 1e-15
+    for c in g["split"]:
+        assert comp._split_sentences(c["text"]) == c["expected"]
+    lo = g["lexical_only"]
+    nos = ContextCompressor(sentences_per_doc=2, embedding_service=None, conservative_mode=False, engine=eng)
+    assert nos.compress(lo["query"], [dict(d) for d in lo["docs"]]) == lo["expected"]
+
+
+# ---------------------------------------------------------------------------------------- document index
+def test_gpu_document_index_search(eng):
+    from optimized_rag_amd.document_store import GpuDocumentIndex
+    from optimized_rag_amd.retrieval import HybridRetriever
+    rng = np.random.default_rng(41)
+    N, D = 5000, 1536
+    emb = rng.standard_normal((N, D)).astype(np.float32)
+    rows = [{"content": f"chunk {i}", "agent_id": f"agent-{i % 3}", "filename": f"f{i % 7}.pdf", "file_type": "pdf",
+             "metadata": {"i": i}, "id": 10_000 + i} for i in range(N)]
+    q = (emb[1234] + 0.3 * rng.standard_normal(D)).astype(np.float32)
+
+    class Svc:
+        def generate_embedding(self, text):
+            return [float(x) for x in q]
+
+    store = GpuDocumentIndex(Svc(), dim=D, engine=eng)
+    store.bulk_load(rows, emb)
+    tenant = np.array([i % 3 for i in range(N)])
+    out = store.search("agent-1", "whatever", top_k=5)
+    oid, osc = O.dense_topk(emb, q[None], 5, tenant_of_row=tenant, tenant=1)
+    assert [d["metadata"]["i"] for d in out] == oid[0].tolist()
+    np.testing.assert_allclose([d["score"] for d in out], osc[0], atol=1e-9)
+    assert set(out[0]) == {"content", "filename", "file_type", "score", "metadata", "embedding"}
+    assert out[0]["embedding"] == [float(x) for x in emb[oid[0][0]]]
+    assert store.search("no-such-agent", "q") == []
+    arch = store.search_archival_memory("agent-0", [float(x) for x in q], limit=3)
+    oid0, _ = O.dense_topk(emb, q[None], 3, tenant_of_row=tenant, tenant=0)
+    assert [a["id"] for a in arch] == [10_000 + int(i) for i in oid0[0]]
+    hr = HybridRetriever(memory_manager=None, document_store=store, agent_id="agent-1", engine=eng)
+    res = hr.retrieve("whatever", sources=["documents"], top_k=5)
+    assert [d["metadata"]["i"] for d in res] == oid[0].tolist() and all(d["source"] == "documents" for d in res)
