@@ -97,24 +97,11 @@ def main():
     del shard
     torch.cuda.empty_cache()
 
-    ids = torch.empty((Q, k), dtype=torch.int64, device=device)
-    rows = torch.empty((Q, k), dtype=torch.int32, device=device)
-    scores = torch.empty((Q, k), dtype=torch.float64, device=device)
-    if world > 1:
-        send = torch.empty((2, Q, k), dtype=torch.int64, device=device)       # [ids | score bits]
-        recv = torch.empty((world, 2, Q, k), dtype=torch.int64, device=device)
-        out_ids = torch.empty((Q, k), dtype=torch.int64, device=device)
-        out_scores = torch.empty((Q, k), dtype=torch.float64, device=device)
+    from optimized_rag_amd.sharded import ShardedDenseIndex
+    index = ShardedDenseIndex(eng, rank=rank, world=world)
 
     def step():
-        if world == 1:
-            eng.dense_topk_dev(queries, k, ids, rows, scores)
-            return ids, scores
-        eng.dense_topk_dev(queries, k, send[0], None, send[1].view(torch.float64))
-        dist.all_gather_into_tensor(recv, send)
-        eng.merge_topk_dev(recv, recv.view(torch.float64)[:, 1], out_ids, out_scores, n_lists=world,
-                           list_stride=2 * Q * k)
-        return out_ids, out_scores
+        return index.search(queries, k)
 
     def fence():
         if world > 1:
