@@ -1,0 +1,554 @@
+// K7: BertForSequenceClassification forward (ms-marco-MiniLM-L-6-v2 shape: 6 layers, hidden 384, 12 heads x 32,
+// FFN 1536, 1 logit). Replaces `self.model.predict(pairs)` of CrossEncoderReranker.rerank
+// (/root/reference/rag/reranker.py:355); sigmoid and sorting stay in the Python mirror (:359,:373).
+//
+// Numerics: weights and GEMM operands fp16, MFMA accumulation fp32, residual stream / LayerNorm / softmax / GELU
+// (exact erf) / pooler in fp32. Layout: tokens are rows ([M = pairs*L][feature], feature contiguous), weights are
+// nn.Linear [out][in] = K-contiguous, so every GEMM is the "both operands K-contiguous" form MFMA wants.
+//
+// Kernels
+//   ce_embed_ln        word+pos+type gather -> LayerNorm -> x32 (fp32 residual) + x16 (fp16 GEMM operand)
+//   ce_gemm<EPI>       128(out features) x 128(tokens) tile, BK=64, 4 waves (2x2 of 64x64), LDS-DMA double buffer,
+//                      source-swizzled conflict-free ds_read_b128 (same scheme as dense.hip). Output features sit
+//                      on the MFMA ROW so a lane owns 4 consecutive features of one token: bias is 4 registers and
+//                      stores are 8/16-byte. Epilogues: QKV (bias, Q/K token-major, V written TRANSPOSED
+//                      [pair][head][d][L] so P.V's B operand is a contiguous 16-byte load), bias+erf-GELU -> fp16,
+//                      bias+residual -> fp32.
+//   ce_attention<NT>   one wave per (pair, head, 16-query block): S = Q.K^T is ONE mfma_16x16x32 per 16 keys
+//                      (d_head = 32 = MFMA K), softmax in registers (row = 16 lanes, xor-shuffle reduce), P -> LDS
+//                      as fp16 -> A operand of P.V; key padding masked to -inf.
+//   ce_layernorm       one wave per token (384 = 6/lane), fp32 statistics, eps from config
+//   ce_pool_classify   tanh(Wp.x_cls + bp) -> wc.pooled + bc, fp32
+#include "common.h"
+
+#include <cmath>
+#include <cstring>
+
+struct rag_ce_model {
+    rag_ce_config cfg;
+    // embeddings fp32
+    float *word = nullptr, *pos = nullptr, *type = nullptr, *emb_ln_g = nullptr, *emb_ln_b = nullptr;
+    struct Layer {
+        half_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;      // fp16 [out][in]
+        float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+        float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+    };
+    std::vector<Layer> layers;
+    float *wp = nullptr, *bp = nullptr, *wc = nullptr, *bc = nullptr;            // pooler / classifier fp32
+    std::vector<void*> allocs;
+    // activation workspace (sized for ws_tokens)
+    int64_t ws_tokens = 0;
+    int ws_pairs = 0, ws_L = 0;
+    float *x32 = nullptr, *y32 = nullptr;
+    half_t *x16 = nullptr, *qk16 = nullptr, *vt16 = nullptr, *ctx16 = nullptr, *h16 = nullptr;
+    int32_t *ids = nullptr, *tt = nullptr, *lens = nullptr;
+    float* logits = nullptr;
+};
+
+#define CE_BM 128     // output features per tile (MFMA rows)
+#define CE_BN 128     // tokens per tile (MFMA cols)
+#define CE_TILE_BYTES (128 * 64 * 2)
+
+enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2 };
+
+__device__ __forceinline__ void ce_stage(const half_t* __restrict__ gsrc, int ld, char* lds_tile, int wid) {
+    // 128 rows x 128 B = 1024 chunks of 16 B; 256 threads -> 4 pieces/thread; piece j -> chunk j*256 + wid*64 + lane
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + (size_t)j * 32 * ld),
+                                         (__attribute__((address_space(3))) void*)(lds_tile + (j * 256 + wid * 64) * 16), 16, 0, 0);
+}
+
+// C^T[n][m] = sum_k W[n][k] * X[m][k].   W: [N][K] fp16, X: [M_pad][K] fp16.  N % 128 == 0, M_pad % 128 == 0, K % 64 == 0.
+template <int EPI>
+__global__ __launch_bounds__(256) void ce_gemm_kernel(const half_t* __restrict__ W, const half_t* __restrict__ X, int N, int K,
+                                                       const float* __restrict__ bias, const float* __restrict__ resid,
+                                                       float* __restrict__ out32, half_t* __restrict__ out16,
+                                                       half_t* __restrict__ vt16, int L, int hidden, int heads,
+                                                       int64_t m_valid) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int n0 = blockIdx.x * CE_BM;          // feature tile (fast index: all feature tiles of a token tile are adjacent)
+    const int m0 = blockIdx.y * CE_BN;          // token tile
+    const int sr = tid >> 3;
+    const int schunk = (tid & 7) ^ ((sr >> 1) & 7);
+    const half_t* a_src = W + (size_t)(n0 + sr) * K + schunk * 8;
+    const half_t* b_src = X + (size_t)(m0 + sr) * K + schunk * 8;
+    const int fr = lane & 15, fq = lane >> 4, sw = (fr >> 1) & 7;
+    int off_k[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) off_k[kk] = fr * 128 + (((kk * 4 + fq) ^ sw) << 4);
+    const int a_base = wm * 64 * 128, b_base = wn * 64 * 128;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nt = K / 64;
+    ce_stage(a_src, K, smem, wid);
+    ce_stage(b_src, K, smem + CE_TILE_BYTES, wid);
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) {
+            char* nxt = smem + (cur ^ 1) * 2 * CE_TILE_BYTES;
+            ce_stage(a_src + (t + 1) * 64, K, nxt, wid);
+            ce_stage(b_src + (t + 1) * 64, K, nxt + CE_TILE_BYTES, wid);
+        }
+        const char* la = smem + cur * 2 * CE_TILE_BYTES + a_base;
+        const char* lb = smem + cur * 2 * CE_TILE_BYTES + CE_TILE_BYTES + b_base;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const half8*>(la + i * 16 * 128 + off_k[kk]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const half8*>(lb + j * 16 * 128 + off_k[kk]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // epilogue: acc[i][j][r] = C^T[n = n0 + wm*64 + i*16 + fq*4 + r][m = m0 + wn*64 + j*16 + fr]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wm * 64 + i * 16 + fq * 4;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wn * 64 + j * 16 + fr;
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            if (EPI == EPI_RESID) {
+                const float4 rv = *reinterpret_cast<const float4*>(resid + (size_t)m * N + n);
+                *reinterpret_cast<float4*>(out32 + (size_t)m * N + n) = make_float4(v0 + rv.x, v1 + rv.y, v2 + rv.z, v3 + rv.w);
+            } else if (EPI == EPI_GELU) {
+                const float c = 0.70710678118654752440f;
+                v0 = 0.5f * v0 * (1.0f + erff(v0 * c));
+                v1 = 0.5f * v1 * (1.0f + erff(v1 * c));
+                v2 = 0.5f * v2 * (1.0f + erff(v2 * c));
+                v3 = 0.5f * v3 * (1.0f + erff(v3 * c));
+                half4 hv = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+                *reinterpret_cast<half4*>(out16 + (size_t)m * N + n) = hv;
+            } else {   // EPI_QKV: features [0,2*hidden) -> qk16[m][2*hidden]; [2*hidden,3*hidden) -> vt16[pair][head][d][L]
+                if (n < 2 * hidden) {
+                    half4 hv = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+                    *reinterpret_cast<half4*>(out16 + (size_t)m * (2 * hidden) + n) = hv;
+                } else if (m < m_valid) {                         // padded token rows have no (pair, token) slot
+                    const int f = n - 2 * hidden;                 // 4 consecutive d of one head (32 % 4 == 0)
+                    const int dh = hidden / heads;
+                    const int head = f / dh, d = f % dh;
+                    const int pair = m / L, tok = m % L;
+                    half_t* o = vt16 + (((size_t)pair * heads + head) * dh + d) * L + tok;
+                    o[0] = (half_t)v0;
+                    o[(size_t)L] = (half_t)v1;
+                    o[(size_t)2 * L] = (half_t)v2;
+                    o[(size_t)3 * L] = (half_t)v3;
+                }
+            }
+        }
+    }
+}
+
+// ---- LayerNorm helpers: one wave per token row of `hidden` floats (hidden % 64 == 0, <= 1024) --------------
+template <int PER>
+__device__ __forceinline__ void wave_layernorm(float (&v)[PER], const float* __restrict__ g, const float* __restrict__ b,
+                                               int hidden, float eps, int lane, float* __restrict__ o32, half_t* __restrict__ o16) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s += v[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)hidden;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const float d = v[i] - mean; q += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)hidden + eps);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = lane + i * 64;
+        const float y = (v[i] - mean) * rstd * g[c] + b[c];
+        o32[c] = y;
+        o16[c] = (half_t)y;
+    }
+}
+
+template <int PER>
+__global__ __launch_bounds__(256) void ce_embed_ln_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ tt,
+                                                           const float* __restrict__ word, const float* __restrict__ pos,
+                                                           const float* __restrict__ type, const float* __restrict__ g,
+                                                           const float* __restrict__ b, int64_t M, int L, int hidden, int vocab,
+                                                           float eps, float* __restrict__ x32, half_t* __restrict__ x16) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= M) return;
+    int id = ids[tok];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const int ty = tt[tok] != 0;
+    const int p = (int)(tok % L);
+    float v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = lane + i * 64;
+        v[i] = word[(size_t)id * hidden + c] + type[(size_t)ty * hidden + c] + pos[(size_t)p * hidden + c];
+    }
+    wave_layernorm<PER>(v, g, b, hidden, eps, lane, x32 + tok * hidden, x16 + tok * hidden);
+}
+
+template <int PER>
+__global__ __launch_bounds__(256) void ce_layernorm_kernel(const float* __restrict__ y32, const float* __restrict__ g,
+                                                            const float* __restrict__ b, int64_t M, int hidden, float eps,
+                                                            float* __restrict__ x32, half_t* __restrict__ x16) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= M) return;
+    float v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) v[i] = y32[tok * hidden + lane + i * 64];
+    wave_layernorm<PER>(v, g, b, hidden, eps, lane, x32 + tok * hidden, x16 + tok * hidden);
+}
+
+// ---- attention: d_head must be 32. One wave per 16-query block; 4 waves per block. NT = L/16 key tiles. -------
+template <int NT>
+__global__ __launch_bounds__(256) void ce_attention_kernel(const half_t* __restrict__ qk16, const half_t* __restrict__ vt16,
+                                                            const int32_t* __restrict__ lens, int L, int hidden, int heads,
+                                                            half_t* __restrict__ ctx16) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PLD = NT * 16 + 8;                                            // P tile row pitch (halfs)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    half_t (*pl)[PLD] = reinterpret_cast<half_t (*)[PLD]>(smem + (size_t)wv * 16 * PLD * 2);   // this wave's [16 q][L keys]
+    const int pair = blockIdx.z, head = blockIdx.y;
+    const int qb = blockIdx.x * 4 + wv;                  // 16-query block index
+    const int len = max(1, min(lens[pair], L));
+    if (qb * 16 >= L) return;
+    const int fr = lane & 15, fq = lane >> 4;
+    const size_t row0 = (size_t)pair * L;
+    const int ld = 2 * hidden;
+    // A = Q rows (query fr of the block, k = 8*fq..+8), B = K rows (key fr of the tile)
+    const half8 qf = *reinterpret_cast<const half8*>(qk16 + (row0 + qb * 16 + fr) * ld + head * 32 + fq * 8);
+    f32x4 s[NT];
+    const float scale = 0.17677669529663687f;            // 32^-0.5
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const half8 kf = *reinterpret_cast<const half8*>(qk16 + (row0 + t * 16 + fr) * ld + hidden + head * 32 + fq * 8);
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf, kf, z, 0, 0, 0);
+        // C layout: col = fr = key within tile, row = fq*4 + r = query within block
+        const bool valid = (t * 16 + fr) < len;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[t][r] = valid ? s[t][r] * scale : -INFINITY;
+    }
+    // softmax over keys: a query row lives in the 16 lanes sharing fq (xor 1,2,4,8) x NT tiles
+    float mx[4], sum[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) m = fmaxf(m, s[t][r]);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        mx[r] = m;
+        float a = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float e = __expf(s[t][r] - m);
+            s[t][r] = e;
+            a += e;
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) a += __shfl_xor(a, o);
+        sum[r] = a;
+    }
+    // P (unnormalised, fp16) -> LDS [q][key]
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pl[fq * 4 + r][t * 16 + fr] = (half_t)s[t][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's LDS writes done (wave-private tile)
+    __builtin_amdgcn_wave_barrier();
+    // ctx^T? no: ctx[q][d] = sum_key P[q][key] * V[key][d]:  A = P (row q = fr, keys 8*fq..), B = V^T rows (d = fr)
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+    const half_t* vbase = vt16 + ((size_t)pair * heads + head) * 32 * L;
+#pragma unroll
+    for (int kb = 0; kb < NT / 2; ++kb) {          // 32 keys per MFMA
+        const half8 pf = *reinterpret_cast<const half8*>(&pl[fr][kb * 32 + fq * 8]);
+        const half8 v0 = *reinterpret_cast<const half8*>(vbase + (size_t)fr * L + kb * 32 + fq * 8);
+        const half8 v1 = *reinterpret_cast<const half8*>(vbase + (size_t)(16 + fr) * L + kb * 32 + fq * 8);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, v0, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, v1, c1, 0, 0, 0);
+    }
+    // C layout: col = fr = d (c0: d, c1: 16+d), row = fq*4 + r = query. sum[r] is the row sum of that query.
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float inv = 1.0f / sum[r];
+        half_t* o = ctx16 + (row0 + qb * 16 + fq * 4 + r) * hidden + head * 32;
+        o[fr] = (half_t)(c0[r] * inv);
+        o[16 + fr] = (half_t)(c1[r] * inv);
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_pool_classify_kernel(const float* __restrict__ x32, const float* __restrict__ wp,
+                                                                const float* __restrict__ bp, const float* __restrict__ wc,
+                                                                const float* __restrict__ bc, int L, int hidden,
+                                                                float* __restrict__ logits) {
+    __shared__ float xs[1024];
+    __shared__ float part[4];
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* x = x32 + (size_t)pair * L * hidden;           // [CLS] = token 0
+    for (int i = tid; i < hidden; i += 256) xs[i] = x[i];
+    __syncthreads();
+    float acc = 0.f;
+    for (int n = tid; n < hidden; n += 256) {
+        float s = bp[n];
+        const float* w = wp + (size_t)n * hidden;
+        for (int k = 0; k < hidden; ++k) s += w[k] * xs[k];
+        acc += wc[n] * tanhf(s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) part[wv] = acc;
+    __syncthreads();
+    if (tid == 0) logits[pair] = part[0] + part[1] + part[2] + part[3] + bc[0];
+}
+
+__global__ void ce_f32_to_f16_kernel(const float* __restrict__ in, half_t* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (half_t)in[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+static void ce_free_ws(rag_ce_model* m) {
+    hipFree(m->x32); hipFree(m->y32); hipFree(m->x16); hipFree(m->qk16); hipFree(m->vt16); hipFree(m->ctx16);
+    hipFree(m->h16); hipFree(m->ids); hipFree(m->tt); hipFree(m->lens); hipFree(m->logits);
+    m->x32 = m->y32 = nullptr; m->x16 = m->qk16 = m->vt16 = m->ctx16 = m->h16 = nullptr;
+    m->ids = m->tt = m->lens = nullptr; m->logits = nullptr;
+    m->ws_tokens = 0; m->ws_pairs = 0; m->ws_L = 0;
+}
+
+void ce_free(rag_ctx* h) {
+    if (!h->ce) return;
+    for (void* p : h->ce->allocs) hipFree(p);
+    ce_free_ws(h->ce);
+    delete h->ce;
+    h->ce = nullptr;
+}
+
+static int up_f32(rag_ctx* h, rag_ce_model* m, const float* src, size_t n, float** dst) {
+    HIP_TRY(h, hipMalloc(dst, n * sizeof(float)));
+    m->allocs.push_back(*dst);
+    HIP_TRY(h, hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    return RAG_OK;
+}
+
+// rows of several fp32 host matrices (same `cols`) concatenated -> one fp16 device matrix
+static int up_f16_concat(rag_ctx* h, rag_ce_model* m, std::vector<const float*> srcs, size_t rows_each, size_t cols, half_t** dst) {
+    const size_t n_each = rows_each * cols, total = n_each * srcs.size();
+    float* tmp = nullptr;
+    HIP_TRY(h, hipMalloc(&tmp, total * sizeof(float)));
+    HIP_TRY(h, hipMalloc(dst, total * sizeof(half_t)));
+    m->allocs.push_back(*dst);
+    for (size_t i = 0; i < srcs.size(); ++i)
+        HIP_TRY(h, hipMemcpyAsync(tmp + i * n_each, srcs[i], n_each * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(ce_f32_to_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, tmp, *dst, (int64_t)total);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    hipFree(tmp);
+    return RAG_OK;
+}
+
+// Tensor order (HF state-dict names), see optimized-rag_amd/cross_encoder.py::flatten_state_dict:
+//  0 word, 1 position, 2 token_type, 3 emb LN weight, 4 emb LN bias,
+//  per layer (16): q.w q.b k.w k.b v.w v.b attn.out.w attn.out.b attn.LN.w attn.LN.b inter.w inter.b out.w out.b out.LN.w out.LN.b
+//  then pooler.w pooler.b classifier.w classifier.b
+int ce_load_host(rag_ctx* h, const rag_ce_config* cfg, const float* const* T, int n) {
+    ARG_CHECK(h, cfg && T, "ce_load: null");
+    ARG_CHECK(h, cfg->hidden % 128 == 0 && cfg->hidden <= 1024 && cfg->ffn % 128 == 0, "ce_load: hidden/ffn must be multiples of 128");
+    ARG_CHECK(h, cfg->heads > 0 && cfg->hidden / cfg->heads == 32, "ce_load: head dim must be 32");
+    ARG_CHECK(h, n == 5 + 16 * cfg->layers + 4, "ce_load: wrong tensor count");
+    ce_free(h);
+    rag_ce_model* m = new rag_ce_model();
+    h->ce = m;
+    m->cfg = *cfg;
+    const size_t H = cfg->hidden, F = cfg->ffn;
+    int rc;
+    if ((rc = up_f32(h, m, T[0], (size_t)cfg->vocab_size * H, &m->word))) return rc;
+    if ((rc = up_f32(h, m, T[1], (size_t)cfg->max_pos * H, &m->pos))) return rc;
+    if ((rc = up_f32(h, m, T[2], (size_t)cfg->type_vocab * H, &m->type))) return rc;
+    if ((rc = up_f32(h, m, T[3], H, &m->emb_ln_g))) return rc;
+    if ((rc = up_f32(h, m, T[4], H, &m->emb_ln_b))) return rc;
+    m->layers.resize(cfg->layers);
+    for (int l = 0; l < cfg->layers; ++l) {
+        const float* const* t = T + 5 + 16 * l;
+        auto& ly = m->layers[l];
+        if ((rc = up_f16_concat(h, m, {t[0], t[2], t[4]}, H, H, &ly.wqkv))) return rc;
+        std::vector<float> bq(3 * H);
+        std::memcpy(bq.data(), t[1], H * 4); std::memcpy(bq.data() + H, t[3], H * 4); std::memcpy(bq.data() + 2 * H, t[5], H * 4);
+        if ((rc = up_f32(h, m, bq.data(), 3 * H, &ly.bqkv))) return rc;
+        HIP_TRY(h, hipStreamSynchronize(h->stream));          // bq is a stack-lifetime buffer
+        if ((rc = up_f16_concat(h, m, {t[6]}, H, H, &ly.wo))) return rc;
+        if ((rc = up_f32(h, m, t[7], H, &ly.bo))) return rc;
+        if ((rc = up_f32(h, m, t[8], H, &ly.ln1_g))) return rc;
+        if ((rc = up_f32(h, m, t[9], H, &ly.ln1_b))) return rc;
+        if ((rc = up_f16_concat(h, m, {t[10]}, F, H, &ly.w1))) return rc;
+        if ((rc = up_f32(h, m, t[11], F, &ly.b1))) return rc;
+        if ((rc = up_f16_concat(h, m, {t[12]}, H, F, &ly.w2))) return rc;
+        if ((rc = up_f32(h, m, t[13], H, &ly.b2))) return rc;
+        if ((rc = up_f32(h, m, t[14], H, &ly.ln2_g))) return rc;
+        if ((rc = up_f32(h, m, t[15], H, &ly.ln2_b))) return rc;
+    }
+    const float* const* t = T + 5 + 16 * cfg->layers;
+    if ((rc = up_f32(h, m, t[0], H * H, &m->wp))) return rc;
+    if ((rc = up_f32(h, m, t[1], H, &m->bp))) return rc;
+    if ((rc = up_f32(h, m, t[2], H, &m->wc))) return rc;
+    if ((rc = up_f32(h, m, t[3], 1, &m->bc))) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return RAG_OK;
+}
+
+static const int kAttnL[] = {32, 64, 96, 128, 192, 256, 384, 512};
+
+template <int NT>
+static void launch_attention(rag_ce_model* m, int P, int L, hipStream_t st) {
+    const size_t lds = (size_t)4 * 16 * (NT * 16 + 8) * 2;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ce_attention_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(ce_attention_kernel<NT>, dim3((L / 16 + 3) / 4, m->cfg.heads, P), dim3(256), lds, st, m->qk16, m->vt16,
+                       m->lens, L, m->cfg.hidden, m->cfg.heads, m->ctx16);
+}
+
+template <int PER>
+static void launch_ln(rag_ce_model* m, const float* y, const float* g, const float* b, int64_t M, hipStream_t st) {
+    hipLaunchKernelGGL(ce_layernorm_kernel<PER>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, y, g, b, M, m->cfg.hidden,
+                       (float)m->cfg.ln_eps, m->x32, m->x16);
+}
+
+static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t st) {
+    const int H = m->cfg.hidden, F = m->cfg.ffn;
+    const int64_t M = (int64_t)P * L;
+    const int64_t Mp = round_up(M, CE_BN);
+    const int per = H / 64;
+    const float eps = (float)m->cfg.ln_eps;
+#define CE_PER_DISPATCH(CALL)                                                                 \
+    switch (per) {                                                                            \
+        case 2: CALL(2); break; case 4: CALL(4); break; case 6: CALL(6); break;               \
+        case 8: CALL(8); break; case 12: CALL(12); break; case 16: CALL(16); break;           \
+        default: h->err = "ce: unsupported hidden size"; return RAG_ERR_ARG;                  \
+    }
+#define EMB(PER) hipLaunchKernelGGL(ce_embed_ln_kernel<PER>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, m->ids, m->tt, m->word, \
+                                    m->pos, m->type, m->emb_ln_g, m->emb_ln_b, M, L, H, m->cfg.vocab_size, eps, m->x32, m->x16)
+    CE_PER_DISPATCH(EMB)
+    const dim3 blk(256);
+    const size_t lds = 4 * CE_TILE_BYTES;
+    for (int l = 0; l < m->cfg.layers; ++l) {
+        auto& ly = m->layers[l];
+        hipLaunchKernelGGL(ce_gemm_kernel<EPI_QKV>, dim3(3 * H / CE_BM, (unsigned)(Mp / CE_BN)), blk, lds, st, ly.wqkv, m->x16, 3 * H,
+                           H, ly.bqkv, (const float*)nullptr, (float*)nullptr, m->qk16, m->vt16, L, H, m->cfg.heads, M);
+        switch (L / 16) {
+            case 2: launch_attention<2>(m, P, L, st); break;
+            case 4: launch_attention<4>(m, P, L, st); break;
+            case 6: launch_attention<6>(m, P, L, st); break;
+            case 8: launch_attention<8>(m, P, L, st); break;
+            case 12: launch_attention<12>(m, P, L, st); break;
+            case 16: launch_attention<16>(m, P, L, st); break;
+            case 24: launch_attention<24>(m, P, L, st); break;
+            case 32: launch_attention<32>(m, P, L, st); break;
+            default: h->err = "ce: unsupported padded sequence length"; return RAG_ERR_ARG;
+        }
+        hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(H / CE_BM, (unsigned)(Mp / CE_BN)), blk, lds, st, ly.wo, m->ctx16, H, H,
+                           ly.bo, m->x32, m->y32, (half_t*)nullptr, (half_t*)nullptr, L, H, m->cfg.heads, M);
+#define LN1(PER) launch_ln<PER>(m, m->y32, ly.ln1_g, ly.ln1_b, M, st)
+        CE_PER_DISPATCH(LN1)
+        hipLaunchKernelGGL(ce_gemm_kernel<EPI_GELU>, dim3(F / CE_BM, (unsigned)(Mp / CE_BN)), blk, lds, st, ly.w1, m->x16, F, H,
+                           ly.b1, (const float*)nullptr, (float*)nullptr, m->h16, (half_t*)nullptr, L, H, m->cfg.heads, M);
+        hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(H / CE_BM, (unsigned)(Mp / CE_BN)), blk, lds, st, ly.w2, m->h16, H, F,
+                           ly.b2, m->x32, m->y32, (half_t*)nullptr, (half_t*)nullptr, L, H, m->cfg.heads, M);
+#define LN2(PER) launch_ln<PER>(m, m->y32, ly.ln2_g, ly.ln2_b, M, st)
+        CE_PER_DISPATCH(LN2)
+    }
+    hipLaunchKernelGGL(ce_pool_classify_kernel, dim3(P), dim3(256), 0, st, m->x32, m->wp, m->bp, m->wc, m->bc, L, H, m->logits);
+    HIP_TRY(h, hipGetLastError());
+    return RAG_OK;
+}
+
+static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L) {
+    if (P <= m->ws_pairs && L == m->ws_L) return RAG_OK;
+    ce_free_ws(m);
+    const int H = m->cfg.hidden, F = m->cfg.ffn;
+    const int64_t Mp = round_up((int64_t)P * L, CE_BN);
+    HIP_TRY(h, hipMalloc(&m->x32, (size_t)Mp * H * 4));
+    HIP_TRY(h, hipMalloc(&m->y32, (size_t)Mp * H * 4));
+    HIP_TRY(h, hipMalloc(&m->x16, (size_t)Mp * H * 2));
+    HIP_TRY(h, hipMalloc(&m->qk16, (size_t)Mp * 2 * H * 2));
+    HIP_TRY(h, hipMalloc(&m->vt16, (size_t)Mp * H * 2 + 4096));
+    HIP_TRY(h, hipMalloc(&m->ctx16, (size_t)Mp * H * 2));
+    HIP_TRY(h, hipMalloc(&m->h16, (size_t)Mp * F * 2));
+    HIP_TRY(h, hipMalloc(&m->ids, (size_t)Mp * 4));
+    HIP_TRY(h, hipMalloc(&m->tt, (size_t)Mp * 4));
+    HIP_TRY(h, hipMalloc(&m->lens, (size_t)P * 4));
+    HIP_TRY(h, hipMalloc(&m->logits, (size_t)P * 4));
+    // padded token rows are read by the GEMM tiles: keep them finite
+    HIP_TRY(h, hipMemset(m->x16, 0, (size_t)Mp * H * 2));
+    HIP_TRY(h, hipMemset(m->ctx16, 0, (size_t)Mp * H * 2));
+    HIP_TRY(h, hipMemset(m->h16, 0, (size_t)Mp * F * 2));
+    HIP_TRY(h, hipMemset(m->x32, 0, (size_t)Mp * H * 4));
+    m->ws_pairs = P;
+    m->ws_L = L;
+    m->ws_tokens = Mp;
+    return RAG_OK;
+}
+
+// pads [P][L_in] token arrays to the supported attention length L (>= L_in), pad id 0 / type 0
+__global__ void ce_pad_tokens_kernel(const int32_t* __restrict__ in_ids, const int32_t* __restrict__ in_tt, int P, int L_in, int L,
+                                     int32_t* __restrict__ ids, int32_t* __restrict__ tt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)P * L) return;
+    const int p = (int)(i / L), t = (int)(i % L);
+    ids[i] = t < L_in ? in_ids[(size_t)p * L_in + t] : 0;
+    tt[i] = t < L_in ? in_tt[(size_t)p * L_in + t] : 0;
+}
+
+int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L_in, float* out,
+             hipStream_t st, bool host_ptrs) {
+    ARG_CHECK(h, h->ce != nullptr, "no cross-encoder loaded");
+    ARG_CHECK(h, ids && tt && lens && out && P > 0 && L_in > 0, "ce_score: bad arguments");
+    rag_ce_model* m = h->ce;
+    ARG_CHECK(h, L_in <= m->cfg.max_pos && L_in <= 512, "ce_score: sequence longer than max_position_embeddings/512");
+    int L = 0;
+    for (int c : kAttnL) if (c >= L_in) { L = c; break; }
+    const int chunk = std::max(1, std::min(P, (int)(2'000'000 / L)));        // ~2M tokens of activations per chunk (~20 GB)
+    int rc = ce_ensure_ws(h, m, chunk, L);
+    if (rc) return rc;
+    const hipMemcpyKind kin = host_ptrs ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    const hipMemcpyKind kout = host_ptrs ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    int32_t *sid = nullptr, *stt = nullptr;
+    HIP_TRY(h, hipMalloc(&sid, (size_t)chunk * L_in * 4));
+    HIP_TRY(h, hipMalloc(&stt, (size_t)chunk * L_in * 4));
+    for (int p0 = 0; p0 < P; p0 += chunk) {
+        const int pc = std::min(chunk, P - p0);
+        HIP_TRY(h, hipMemcpyAsync(sid, ids + (size_t)p0 * L_in, (size_t)pc * L_in * 4, kin, st));
+        HIP_TRY(h, hipMemcpyAsync(stt, tt + (size_t)p0 * L_in, (size_t)pc * L_in * 4, kin, st));
+        HIP_TRY(h, hipMemcpyAsync(m->lens, lens + p0, (size_t)pc * 4, kin, st));
+        const int64_t n = (int64_t)pc * L;
+        hipLaunchKernelGGL(ce_pad_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sid, stt, pc, L_in, L, m->ids, m->tt);
+        rc = ce_forward_chunk(h, m, pc, L, st);
+        if (rc) break;
+        HIP_TRY(h, hipMemcpyAsync(out + p0, m->logits, (size_t)pc * 4, kout, st));
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    hipFree(sid); hipFree(stt);
+    if (rc) return rc;
+    if (e != hipSuccess) {
+        h->err = std::string("ce_score: ") + hipGetErrorString(e);
+        return RAG_ERR_HIP;
+    }
+    return RAG_OK;
+}

@@ -1,0 +1,97 @@
+"""GPU parity of the cross-encoder forward (K7) against the float64 numpy oracle (pinned to the transformers
+implementation by tests/test_oracle_bert.py) and the committed golden logits. Tolerance: the north star asks for
+rerank scores within 1e-3; logits are checked at 4e-3 absolute (sigmoid' <= 1/4) and sigmoid scores at 1e-3."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bert_oracle as B
+from oracle import rag_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 4e-3
+SCORE_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from optimized_rag_amd import RagEngine
+    e = RagEngine(dim=1536, device=0)
+    yield e
+    e.close()
+
+
+def load_model(eng, cfg, w):
+    from optimized_rag_amd.cross_encoder import flatten_state_dict
+    eng.ce_load(cfg, flatten_state_dict(w, cfg["layers"]))
+
+
+def test_minilm_golden_logits(eng, golden_dir):
+    g = np.load(os.path.join(golden_dir, "bert_minilm.npz"))
+    cfg = B.minilm_config()
+    w = B.seeded_weights(cfg, int(g["seed"]))
+    load_model(eng, cfg, w)
+    got = eng.ce_score(g["input_ids"], g["token_type_ids"], g["lens"])
+    exp = g["logits"]
+    assert np.abs(got - exp).max() < LOGIT_TOL, (got, exp)
+    sg = np.array([O.sigmoid(float(x)) for x in got])
+    se = np.array([O.sigmoid(float(x)) for x in exp])
+    assert np.abs(sg - se).max() < SCORE_TOL
+
+
+@pytest.mark.parametrize("P,L", [(3, 32), (5, 64), (2, 200), (1, 512), (7, 100)])
+def test_minilm_shapes_vs_oracle(eng, P, L):
+    cfg = B.minilm_config()
+    w = B.seeded_weights(cfg, 99)
+    load_model(eng, cfg, w)
+    rng = np.random.default_rng(P * 1000 + L)
+    lens = rng.integers(2, L + 1, P)
+    lens[0] = L
+    ids = np.zeros((P, L), dtype=np.int64)
+    tt = np.zeros((P, L), dtype=np.int64)
+    for p in range(P):
+        n = int(lens[p])
+        ids[p, :n] = rng.integers(1000, cfg["vocab_size"], n)
+        tt[p, n // 3:n] = 1
+    got = eng.ce_score(ids, tt, lens)
+    sel = slice(0, min(P, 3))                      # the float64 oracle is slow at long L: check a few pairs
+    exp = B.forward_logits(w, cfg, ids[sel], tt[sel], lens[sel])
+    assert np.abs(got[sel] - exp).max() < LOGIT_TOL, (got[sel], exp)
+
+
+def test_reranker_from_local_dir(eng, tmp_path):
+    """End to end through the mirror class: local checkpoint dir -> tokeniser -> HIP forward -> sigmoid -> sort."""
+    from safetensors.numpy import save_file
+    from optimized_rag_amd.reranker import CrossEncoderReranker
+    words = ("memory vector index query document retrieval ranking fusion agent graph node embedding cosine score "
+             "keyword search context token model latency cache batch shard kernel").split()
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words + ["##s", "##ing", ".", ","]
+    cfg = dict(vocab_size=len(vocab), hidden=384, layers=2, heads=12, ffn=1536, max_pos=64, type_vocab=2, eps=1e-12)
+    w = B.seeded_weights(cfg, 5)
+    d = tmp_path / "ce"
+    d.mkdir()
+    (d / "vocab.txt").write_text("\n".join(vocab) + "\n")
+    (d / "config.json").write_text(json.dumps(dict(
+        vocab_size=len(vocab), hidden_size=384, num_hidden_layers=2, num_attention_heads=12, intermediate_size=1536,
+        max_position_embeddings=64, type_vocab_size=2, hidden_act="gelu", layer_norm_eps=1e-12)))
+    save_file({k: v for k, v in w.items()}, str(d / "model.safetensors"))
+    ce = CrossEncoderReranker(model_name=str(d), max_length=64, engine=eng)
+    assert ce.is_available()
+    rng = np.random.default_rng(3)
+    docs = [{"content": " ".join(rng.choice(words, size=int(rng.integers(3, 80)))) + ".", "pos": i, "score": 0.1 * i}
+            for i in range(9)]
+    query = "vector index latency"
+    out = ce.rerank(query, [dict(x) for x in docs], top_k=5)
+    ids, tt, lens = ce.model.tokenize_pairs([[query, x["content"]] for x in docs])
+    assert ids.shape[1] <= 64 and ids[0, 0] == 2 and (lens >= 6).all()
+    exp = B.forward_logits(w, cfg, ids.astype(np.int64), tt.astype(np.int64), lens)
+    sig = [O.sigmoid(float(np.float32(x))) for x in exp]
+    order = [int(i) for i in O.stable_topk_desc(sig, 5)]
+    assert [x["pos"] for x in out] == order
+    for x in out:
+        assert abs(x["cross_encoder_score"] - sig[x["pos"]]) < SCORE_TOL
+        assert abs(x["cross_encoder_raw_score"] - exp[x["pos"]]) < LOGIT_TOL
+        assert x["embedding_score"] == 0.1 * x["pos"] and x["score"] == x["cross_encoder_score"]
