@@ -2,8 +2,11 @@
 // FFN 1536, 1 logit). Replaces `self.model.predict(pairs)` of CrossEncoderReranker.rerank
 // (/root/reference/rag/reranker.py:355); sigmoid and sorting stay in the Python mirror (:359,:373).
 //
-// Numerics: weights and GEMM operands fp16, MFMA accumulation fp32, residual stream / LayerNorm / softmax / GELU
-// (exact erf) / pooler in fp32. Layout: tokens are rows ([M = pairs*L][feature], feature contiguous), weights are
+// Numerics: the north star asks for rerank scores within 1e-3. Single fp16 operands give ~2e-2 logit error after
+// 6 layers (measured), so every MFMA operand is a SPLIT fp16 pair x = hi + lo (hi = fp16(x), lo = fp16(x - hi),
+// ~22 significand bits) stored as two planes, and every product is 3 MFMAs: hi*hi + hi*lo + lo*hi with fp32
+// accumulation (3/16 of the f32-MFMA cost for the same accuracy class). Residual stream / LayerNorm / softmax /
+// GELU (exact erf) / pooler are fp32. Layout: tokens are rows ([M = pairs*L][feature], feature contiguous), weights are
 // nn.Linear [out][in] = K-contiguous, so every GEMM is the "both operands K-contiguous" form MFMA wants.
 //
 // Kernels
@@ -51,6 +54,14 @@ struct rag_ce_model {
 
 enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2 };
 
+__device__ __forceinline__ void store_split4(half_t* __restrict__ p, size_t plane, float v0, float v1, float v2, float v3) {
+    const half4 hi = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+    const half4 lo = {(half_t)(v0 - (float)hi[0]), (half_t)(v1 - (float)hi[1]), (half_t)(v2 - (float)hi[2]),
+                      (half_t)(v3 - (float)hi[3])};
+    *reinterpret_cast<half4*>(p) = hi;
+    *reinterpret_cast<half4*>(p + plane) = lo;
+}
+
 __device__ __forceinline__ void ce_stage(const half_t* __restrict__ gsrc, int ld, char* lds_tile, int wid) {
     // 128 rows x 128 B = 1024 chunks of 16 B; 256 threads -> 4 pieces/thread; piece j -> chunk j*256 + wid*64 + lane
 #pragma unroll
@@ -59,13 +70,14 @@ __device__ __forceinline__ void ce_stage(const half_t* __restrict__ gsrc, int ld
                                          (__attribute__((address_space(3))) void*)(lds_tile + (j * 256 + wid * 64) * 16), 16, 0, 0);
 }
 
-// C^T[n][m] = sum_k W[n][k] * X[m][k].   W: [N][K] fp16, X: [M_pad][K] fp16.  N % 128 == 0, M_pad % 128 == 0, K % 64 == 0.
+// C^T[n][m] = sum_k W[n][k] * X[m][k].   W: [2 planes][N][K] fp16, X: [2 planes][M_pad][K] fp16 (hi plane, then lo).
+// N % 128 == 0, M_pad % 128 == 0, K % 64 == 0.  LDS per stage: A_hi | A_lo | B_hi | B_lo (4 x 16 KiB), 2 stages.
 template <int EPI>
-__global__ __launch_bounds__(256) void ce_gemm_kernel(const half_t* __restrict__ W, const half_t* __restrict__ X, int N, int K,
-                                                       const float* __restrict__ bias, const float* __restrict__ resid,
-                                                       float* __restrict__ out32, half_t* __restrict__ out16,
-                                                       half_t* __restrict__ vt16, int L, int hidden, int heads,
-                                                       int64_t m_valid) {
+__global__ __launch_bounds__(256) void ce_gemm_kernel(const half_t* __restrict__ W, size_t w_plane, const half_t* __restrict__ X,
+                                                       size_t x_plane, int N, int K, const float* __restrict__ bias,
+                                                       const float* __restrict__ resid, float* __restrict__ out32,
+                                                       half_t* __restrict__ out16, size_t out_plane, half_t* __restrict__ vt16,
+                                                       size_t vt_plane, int L, int hidden, int heads, int64_t m_valid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,28 +100,42 @@ __global__ __launch_bounds__(256) void ce_gemm_kernel(const half_t* __restrict__
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nt = K / 64;
     ce_stage(a_src, K, smem, wid);
-    ce_stage(b_src, K, smem + CE_TILE_BYTES, wid);
+    ce_stage(a_src + w_plane, K, smem + CE_TILE_BYTES, wid);
+    ce_stage(b_src, K, smem + 2 * CE_TILE_BYTES, wid);
+    ce_stage(b_src + x_plane, K, smem + 3 * CE_TILE_BYTES, wid);
     __syncthreads();
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
         if (t + 1 < nt) {
-            char* nxt = smem + (cur ^ 1) * 2 * CE_TILE_BYTES;
+            char* nxt = smem + (cur ^ 1) * 4 * CE_TILE_BYTES;
             ce_stage(a_src + (t + 1) * 64, K, nxt, wid);
-            ce_stage(b_src + (t + 1) * 64, K, nxt + CE_TILE_BYTES, wid);
+            ce_stage(a_src + w_plane + (t + 1) * 64, K, nxt + CE_TILE_BYTES, wid);
+            ce_stage(b_src + (t + 1) * 64, K, nxt + 2 * CE_TILE_BYTES, wid);
+            ce_stage(b_src + x_plane + (t + 1) * 64, K, nxt + 3 * CE_TILE_BYTES, wid);
         }
-        const char* la = smem + cur * 2 * CE_TILE_BYTES + a_base;
-        const char* lb = smem + cur * 2 * CE_TILE_BYTES + CE_TILE_BYTES + b_base;
+        const char* la = smem + cur * 4 * CE_TILE_BYTES + a_base;
+        const char* lb = smem + cur * 4 * CE_TILE_BYTES + 2 * CE_TILE_BYTES + b_base;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            half8 af[4], bf[4];
+            half8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const half8*>(la + i * 16 * 128 + off_k[kk]);
+            for (int i = 0; i < 4; ++i) {
+                ah[i] = *reinterpret_cast<const half8*>(la + i * 16 * 128 + off_k[kk]);
+                al[i] = *reinterpret_cast<const half8*>(la + CE_TILE_BYTES + i * 16 * 128 + off_k[kk]);
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const half8*>(lb + j * 16 * 128 + off_k[kk]);
+            for (int j = 0; j < 4; ++j) {
+                bh[j] = *reinterpret_cast<const half8*>(lb + j * 16 * 128 + off_k[kk]);
+                bl[j] = *reinterpret_cast<const half8*>(lb + CE_TILE_BYTES + j * 16 * 128 + off_k[kk]);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
         }
         __syncthreads();
         cur ^= 1;
@@ -132,22 +158,23 @@ __global__ __launch_bounds__(256) void ce_gemm_kernel(const half_t* __restrict__
                 v1 = 0.5f * v1 * (1.0f + erff(v1 * c));
                 v2 = 0.5f * v2 * (1.0f + erff(v2 * c));
                 v3 = 0.5f * v3 * (1.0f + erff(v3 * c));
-                half4 hv = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
-                *reinterpret_cast<half4*>(out16 + (size_t)m * N + n) = hv;
+                store_split4(out16 + (size_t)m * N + n, out_plane, v0, v1, v2, v3);
             } else {   // EPI_QKV: features [0,2*hidden) -> qk16[m][2*hidden]; [2*hidden,3*hidden) -> vt16[pair][head][d][L]
                 if (n < 2 * hidden) {
-                    half4 hv = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
-                    *reinterpret_cast<half4*>(out16 + (size_t)m * (2 * hidden) + n) = hv;
+                    store_split4(out16 + (size_t)m * (2 * hidden) + n, out_plane, v0, v1, v2, v3);
                 } else if (m < m_valid) {                         // padded token rows have no (pair, token) slot
                     const int f = n - 2 * hidden;                 // 4 consecutive d of one head (32 % 4 == 0)
                     const int dh = hidden / heads;
                     const int head = f / dh, d = f % dh;
                     const int pair = m / L, tok = m % L;
                     half_t* o = vt16 + (((size_t)pair * heads + head) * dh + d) * L + tok;
-                    o[0] = (half_t)v0;
-                    o[(size_t)L] = (half_t)v1;
-                    o[(size_t)2 * L] = (half_t)v2;
-                    o[(size_t)3 * L] = (half_t)v3;
+                    const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const half_t hi = (half_t)vv[r];
+                        o[(size_t)r * L] = hi;
+                        o[vt_plane + (size_t)r * L] = (half_t)(vv[r] - (float)hi);
+                    }
                 }
             }
         }
@@ -157,7 +184,8 @@ __global__ __launch_bounds__(256) void ce_gemm_kernel(const half_t* __restrict__
 // ---- LayerNorm helpers: one wave per token row of `hidden` floats (hidden % 64 == 0, <= 1024) --------------
 template <int PER>
 __device__ __forceinline__ void wave_layernorm(float (&v)[PER], const float* __restrict__ g, const float* __restrict__ b,
-                                               int hidden, float eps, int lane, float* __restrict__ o32, half_t* __restrict__ o16) {
+                                               int hidden, float eps, int lane, float* __restrict__ o32, half_t* __restrict__ o16,
+                                               size_t plane) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < PER; ++i) s += v[i];
@@ -175,7 +203,9 @@ __device__ __forceinline__ void wave_layernorm(float (&v)[PER], const float* __r
         const int c = lane + i * 64;
         const float y = (v[i] - mean) * rstd * g[c] + b[c];
         o32[c] = y;
-        o16[c] = (half_t)y;
+        const half_t hi = (half_t)y;
+        o16[c] = hi;
+        o16[plane + c] = (half_t)(y - (float)hi);
     }
 }
 
@@ -184,7 +214,7 @@ __global__ __launch_bounds__(256) void ce_embed_ln_kernel(const int32_t* __restr
                                                            const float* __restrict__ word, const float* __restrict__ pos,
                                                            const float* __restrict__ type, const float* __restrict__ g,
                                                            const float* __restrict__ b, int64_t M, int L, int hidden, int vocab,
-                                                           float eps, float* __restrict__ x32, half_t* __restrict__ x16) {
+                                                           float eps, float* __restrict__ x32, half_t* __restrict__ x16, size_t plane) {
     const int lane = threadIdx.x & 63;
     const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= M) return;
@@ -198,31 +228,34 @@ __global__ __launch_bounds__(256) void ce_embed_ln_kernel(const int32_t* __restr
         const int c = lane + i * 64;
         v[i] = word[(size_t)id * hidden + c] + type[(size_t)ty * hidden + c] + pos[(size_t)p * hidden + c];
     }
-    wave_layernorm<PER>(v, g, b, hidden, eps, lane, x32 + tok * hidden, x16 + tok * hidden);
+    wave_layernorm<PER>(v, g, b, hidden, eps, lane, x32 + tok * hidden, x16 + tok * hidden, plane);
 }
 
 template <int PER>
 __global__ __launch_bounds__(256) void ce_layernorm_kernel(const float* __restrict__ y32, const float* __restrict__ g,
                                                             const float* __restrict__ b, int64_t M, int hidden, float eps,
-                                                            float* __restrict__ x32, half_t* __restrict__ x16) {
+                                                            float* __restrict__ x32, half_t* __restrict__ x16, size_t plane) {
     const int lane = threadIdx.x & 63;
     const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= M) return;
     float v[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) v[i] = y32[tok * hidden + lane + i * 64];
-    wave_layernorm<PER>(v, g, b, hidden, eps, lane, x32 + tok * hidden, x16 + tok * hidden);
+    wave_layernorm<PER>(v, g, b, hidden, eps, lane, x32 + tok * hidden, x16 + tok * hidden, plane);
 }
 
 // ---- attention: d_head must be 32. One wave per 16-query block; 4 waves per block. NT = L/16 key tiles. -------
+// All operands are split fp16 (hi plane + lo plane): S and P.V are 3 MFMAs each.
 template <int NT>
-__global__ __launch_bounds__(256) void ce_attention_kernel(const half_t* __restrict__ qk16, const half_t* __restrict__ vt16,
+__global__ __launch_bounds__(256) void ce_attention_kernel(const half_t* __restrict__ qk16, size_t qk_plane,
+                                                            const half_t* __restrict__ vt16, size_t vt_plane,
                                                             const int32_t* __restrict__ lens, int L, int hidden, int heads,
-                                                            half_t* __restrict__ ctx16) {
+                                                            half_t* __restrict__ ctx16, size_t ctx_plane) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PLD = NT * 16 + 8;                                            // P tile row pitch (halfs)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    half_t (*pl)[PLD] = reinterpret_cast<half_t (*)[PLD]>(smem + (size_t)wv * 16 * PLD * 2);   // this wave's [16 q][L keys]
+    half_t (*ph)[PLD] = reinterpret_cast<half_t (*)[PLD]>(smem + (size_t)(2 * wv) * 16 * PLD * 2);       // P hi [16 q][L keys]
+    half_t (*pl)[PLD] = reinterpret_cast<half_t (*)[PLD]>(smem + (size_t)(2 * wv + 1) * 16 * PLD * 2);   // P lo
     const int pair = blockIdx.z, head = blockIdx.y;
     const int qb = blockIdx.x * 4 + wv;                  // 16-query block index
     const int len = max(1, min(lens[pair], L));
@@ -231,21 +264,27 @@ __global__ __launch_bounds__(256) void ce_attention_kernel(const half_t* __restr
     const size_t row0 = (size_t)pair * L;
     const int ld = 2 * hidden;
     // A = Q rows (query fr of the block, k = 8*fq..+8), B = K rows (key fr of the tile)
-    const half8 qf = *reinterpret_cast<const half8*>(qk16 + (row0 + qb * 16 + fr) * ld + head * 32 + fq * 8);
+    const half_t* qp = qk16 + (row0 + qb * 16 + fr) * ld + head * 32 + fq * 8;
+    const half8 qh = *reinterpret_cast<const half8*>(qp);
+    const half8 ql = *reinterpret_cast<const half8*>(qp + qk_plane);
     f32x4 s[NT];
     const float scale = 0.17677669529663687f;            // 32^-0.5
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const half8 kf = *reinterpret_cast<const half8*>(qk16 + (row0 + t * 16 + fr) * ld + hidden + head * 32 + fq * 8);
+        const half_t* kp = qk16 + (row0 + t * 16 + fr) * ld + hidden + head * 32 + fq * 8;
+        const half8 kh = *reinterpret_cast<const half8*>(kp);
+        const half8 kl = *reinterpret_cast<const half8*>(kp + qk_plane);
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf, kf, z, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql, kh, z, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh, kl, z, 0, 0, 0);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh, kh, z, 0, 0, 0);
         // C layout: col = fr = key within tile, row = fq*4 + r = query within block
         const bool valid = (t * 16 + fr) < len;
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[t][r] = valid ? s[t][r] * scale : -INFINITY;
     }
     // softmax over keys: a query row lives in the 16 lanes sharing fq (xor 1,2,4,8) x NT tiles
-    float mx[4], sum[4];
+    float sum[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float m = -INFINITY;
@@ -253,11 +292,10 @@ __global__ __launch_bounds__(256) void ce_attention_kernel(const half_t* __restr
         for (int t = 0; t < NT; ++t) m = fmaxf(m, s[t][r]);
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
-        mx[r] = m;
         float a = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const float e = __expf(s[t][r] - m);
+            const float e = expf(s[t][r] - m);
             s[t][r] = e;
             a += e;
         }
@@ -265,31 +303,46 @@ __global__ __launch_bounds__(256) void ce_attention_kernel(const half_t* __restr
         for (int o = 1; o < 16; o <<= 1) a += __shfl_xor(a, o);
         sum[r] = a;
     }
-    // P (unnormalised, fp16) -> LDS [q][key]
+    // P (unnormalised) -> LDS [q][key] as hi/lo planes
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pl[fq * 4 + r][t * 16 + fr] = (half_t)s[t][r];
-    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's LDS writes done (wave-private tile)
+        for (int r = 0; r < 4; ++r) {
+            const half_t hi = (half_t)s[t][r];
+            ph[fq * 4 + r][t * 16 + fr] = hi;
+            pl[fq * 4 + r][t * 16 + fr] = (half_t)(s[t][r] - (float)hi);
+        }
+    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's LDS writes done (wave-private tiles)
     __builtin_amdgcn_wave_barrier();
-    // ctx^T? no: ctx[q][d] = sum_key P[q][key] * V[key][d]:  A = P (row q = fr, keys 8*fq..), B = V^T rows (d = fr)
+    // ctx[q][d] = sum_key P[q][key] * V[key][d]:  A = P (row q = fr, keys 8*fq..), B = V^T rows (d = fr)
     f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
     const half_t* vbase = vt16 + ((size_t)pair * heads + head) * 32 * L;
 #pragma unroll
     for (int kb = 0; kb < NT / 2; ++kb) {          // 32 keys per MFMA
-        const half8 pf = *reinterpret_cast<const half8*>(&pl[fr][kb * 32 + fq * 8]);
-        const half8 v0 = *reinterpret_cast<const half8*>(vbase + (size_t)fr * L + kb * 32 + fq * 8);
-        const half8 v1 = *reinterpret_cast<const half8*>(vbase + (size_t)(16 + fr) * L + kb * 32 + fq * 8);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, v0, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, v1, c1, 0, 0, 0);
+        const half8 pfh = *reinterpret_cast<const half8*>(&ph[fr][kb * 32 + fq * 8]);
+        const half8 pfl = *reinterpret_cast<const half8*>(&pl[fr][kb * 32 + fq * 8]);
+        const half_t* v0p = vbase + (size_t)fr * L + kb * 32 + fq * 8;
+        const half_t* v1p = vbase + (size_t)(16 + fr) * L + kb * 32 + fq * 8;
+        const half8 v0h = *reinterpret_cast<const half8*>(v0p), v0l = *reinterpret_cast<const half8*>(v0p + vt_plane);
+        const half8 v1h = *reinterpret_cast<const half8*>(v1p), v1l = *reinterpret_cast<const half8*>(v1p + vt_plane);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfl, v0h, c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh, v0l, c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh, v0h, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfl, v1h, c1, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh, v1l, c1, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh, v1h, c1, 0, 0, 0);
     }
     // C layout: col = fr = d (c0: d, c1: 16+d), row = fq*4 + r = query. sum[r] is the row sum of that query.
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float inv = 1.0f / sum[r];
         half_t* o = ctx16 + (row0 + qb * 16 + fq * 4 + r) * hidden + head * 32;
-        o[fr] = (half_t)(c0[r] * inv);
-        o[16 + fr] = (half_t)(c1[r] * inv);
+        const float a0 = c0[r] * inv, a1 = c1[r] * inv;
+        const half_t h0 = (half_t)a0, h1 = (half_t)a1;
+        o[fr] = h0;
+        o[16 + fr] = h1;
+        o[ctx_plane + fr] = (half_t)(a0 - (float)h0);
+        o[ctx_plane + 16 + fr] = (half_t)(a1 - (float)h1);
     }
 }
 
@@ -317,9 +370,13 @@ __global__ __launch_bounds__(256) void ce_pool_classify_kernel(const float* __re
     if (tid == 0) logits[pair] = part[0] + part[1] + part[2] + part[3] + bc[0];
 }
 
-__global__ void ce_f32_to_f16_kernel(const float* __restrict__ in, half_t* __restrict__ out, int64_t n) {
+__global__ void ce_f32_split_kernel(const float* __restrict__ in, half_t* __restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (half_t)in[i];
+    if (i < n) {
+        const half_t hi = (half_t)in[i];
+        out[i] = hi;
+        out[n + i] = (half_t)(in[i] - (float)hi);      // lo plane follows the hi plane
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -351,11 +408,11 @@ static int up_f16_concat(rag_ctx* h, rag_ce_model* m, std::vector<const float*> 
     const size_t n_each = rows_each * cols, total = n_each * srcs.size();
     float* tmp = nullptr;
     HIP_TRY(h, hipMalloc(&tmp, total * sizeof(float)));
-    HIP_TRY(h, hipMalloc(dst, total * sizeof(half_t)));
+    HIP_TRY(h, hipMalloc(dst, 2 * total * sizeof(half_t)));      // hi plane | lo plane
     m->allocs.push_back(*dst);
     for (size_t i = 0; i < srcs.size(); ++i)
         HIP_TRY(h, hipMemcpyAsync(tmp + i * n_each, srcs[i], n_each * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(ce_f32_to_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, tmp, *dst, (int64_t)total);
+    hipLaunchKernelGGL(ce_f32_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, tmp, *dst, (int64_t)total);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     hipFree(tmp);
     return RAG_OK;
@@ -412,31 +469,47 @@ int ce_load_host(rag_ctx* h, const rag_ce_config* cfg, const float* const* T, in
 
 static const int kAttnL[] = {32, 64, 96, 128, 192, 256, 384, 512};
 
+struct ce_planes { size_t x, qk, vt, ctx, h; };
+static ce_planes planes_for(const rag_ce_model* m, int64_t Mp) {
+    const size_t H = m->cfg.hidden, F = m->cfg.ffn;
+    return {(size_t)Mp * H, (size_t)Mp * 2 * H, (size_t)Mp * H + 2048, (size_t)Mp * H, (size_t)Mp * F};
+}
+
 template <int NT>
-static void launch_attention(rag_ce_model* m, int P, int L, hipStream_t st) {
-    const size_t lds = (size_t)4 * 16 * (NT * 16 + 8) * 2;
+static void launch_attention(rag_ce_model* m, int P, int L, const ce_planes& pp, hipStream_t st) {
+    const size_t lds = (size_t)8 * 16 * (NT * 16 + 8) * 2;            // 4 waves x (P hi + P lo)
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ce_attention_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL(ce_attention_kernel<NT>, dim3((L / 16 + 3) / 4, m->cfg.heads, P), dim3(256), lds, st, m->qk16, m->vt16,
-                       m->lens, L, m->cfg.hidden, m->cfg.heads, m->ctx16);
+    hipLaunchKernelGGL(ce_attention_kernel<NT>, dim3((L / 16 + 3) / 4, m->cfg.heads, P), dim3(256), lds, st, m->qk16, pp.qk,
+                       m->vt16, pp.vt, m->lens, L, m->cfg.hidden, m->cfg.heads, m->ctx16, pp.ctx);
 }
 
 template <int PER>
-static void launch_ln(rag_ce_model* m, const float* y, const float* g, const float* b, int64_t M, hipStream_t st) {
+static void launch_ln(rag_ce_model* m, const float* y, const float* g, const float* b, int64_t M, size_t plane, hipStream_t st) {
     hipLaunchKernelGGL(ce_layernorm_kernel<PER>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, y, g, b, M, m->cfg.hidden,
-                       (float)m->cfg.ln_eps, m->x32, m->x16);
+                       (float)m->cfg.ln_eps, m->x32, m->x16, plane);
 }
 
 static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t st) {
     const int H = m->cfg.hidden, F = m->cfg.ffn;
     const int64_t M = (int64_t)P * L;
-    const int64_t Mp = round_up(M, CE_BN);
+    const int64_t Mp = round_up((int64_t)m->ws_pairs * L, CE_BN);      // plane strides follow the ALLOCATED size
+    const int64_t Mt = round_up(M, CE_BN);                            // token tiles actually computed
+    const ce_planes pp = planes_for(m, Mp);
     const int per = H / 64;
     const float eps = (float)m->cfg.ln_eps;
+    static bool attr = false;
+    const size_t lds = 8 * CE_TILE_BYTES;
+    if (!attr) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_kernel<EPI_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_kernel<EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_kernel<EPI_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
 #define CE_PER_DISPATCH(CALL)                                                                 \
     switch (per) {                                                                            \
         case 2: CALL(2); break; case 4: CALL(4); break; case 6: CALL(6); break;               \
@@ -444,36 +517,40 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
         default: h->err = "ce: unsupported hidden size"; return RAG_ERR_ARG;                  \
     }
 #define EMB(PER) hipLaunchKernelGGL(ce_embed_ln_kernel<PER>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, m->ids, m->tt, m->word, \
-                                    m->pos, m->type, m->emb_ln_g, m->emb_ln_b, M, L, H, m->cfg.vocab_size, eps, m->x32, m->x16)
+                                    m->pos, m->type, m->emb_ln_g, m->emb_ln_b, M, L, H, m->cfg.vocab_size, eps, m->x32, m->x16, pp.x)
     CE_PER_DISPATCH(EMB)
     const dim3 blk(256);
-    const size_t lds = 4 * CE_TILE_BYTES;
+    const unsigned mt = (unsigned)(Mt / CE_BN);
+    const half_t* nullh = nullptr;
     for (int l = 0; l < m->cfg.layers; ++l) {
         auto& ly = m->layers[l];
-        hipLaunchKernelGGL(ce_gemm_kernel<EPI_QKV>, dim3(3 * H / CE_BM, (unsigned)(Mp / CE_BN)), blk, lds, st, ly.wqkv, m->x16, 3 * H,
-                           H, ly.bqkv, (const float*)nullptr, (float*)nullptr, m->qk16, m->vt16, L, H, m->cfg.heads, M);
+        hipLaunchKernelGGL(ce_gemm_kernel<EPI_QKV>, dim3(3 * H / CE_BM, mt), blk, lds, st, ly.wqkv, (size_t)3 * H * H, m->x16, pp.x,
+                           3 * H, H, ly.bqkv, (const float*)nullptr, (float*)nullptr, m->qk16, pp.qk, m->vt16, pp.vt, L, H,
+                           m->cfg.heads, M);
         switch (L / 16) {
-            case 2: launch_attention<2>(m, P, L, st); break;
-            case 4: launch_attention<4>(m, P, L, st); break;
-            case 6: launch_attention<6>(m, P, L, st); break;
-            case 8: launch_attention<8>(m, P, L, st); break;
-            case 12: launch_attention<12>(m, P, L, st); break;
-            case 16: launch_attention<16>(m, P, L, st); break;
-            case 24: launch_attention<24>(m, P, L, st); break;
-            case 32: launch_attention<32>(m, P, L, st); break;
+            case 2: launch_attention<2>(m, P, L, pp, st); break;
+            case 4: launch_attention<4>(m, P, L, pp, st); break;
+            case 6: launch_attention<6>(m, P, L, pp, st); break;
+            case 8: launch_attention<8>(m, P, L, pp, st); break;
+            case 12: launch_attention<12>(m, P, L, pp, st); break;
+            case 16: launch_attention<16>(m, P, L, pp, st); break;
+            case 24: launch_attention<24>(m, P, L, pp, st); break;
+            case 32: launch_attention<32>(m, P, L, pp, st); break;
             default: h->err = "ce: unsupported padded sequence length"; return RAG_ERR_ARG;
         }
-        hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(H / CE_BM, (unsigned)(Mp / CE_BN)), blk, lds, st, ly.wo, m->ctx16, H, H,
-                           ly.bo, m->x32, m->y32, (half_t*)nullptr, (half_t*)nullptr, L, H, m->cfg.heads, M);
-#define LN1(PER) launch_ln<PER>(m, m->y32, ly.ln1_g, ly.ln1_b, M, st)
+        hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(H / CE_BM, mt), blk, lds, st, ly.wo, (size_t)H * H, m->ctx16, pp.ctx, H, H,
+                           ly.bo, m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (size_t)0, L, H, m->cfg.heads, M);
+#define LN1(PER) launch_ln<PER>(m, m->y32, ly.ln1_g, ly.ln1_b, M, pp.x, st)
         CE_PER_DISPATCH(LN1)
-        hipLaunchKernelGGL(ce_gemm_kernel<EPI_GELU>, dim3(F / CE_BM, (unsigned)(Mp / CE_BN)), blk, lds, st, ly.w1, m->x16, F, H,
-                           ly.b1, (const float*)nullptr, (float*)nullptr, m->h16, (half_t*)nullptr, L, H, m->cfg.heads, M);
-        hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(H / CE_BM, (unsigned)(Mp / CE_BN)), blk, lds, st, ly.w2, m->h16, H, F,
-                           ly.b2, m->x32, m->y32, (half_t*)nullptr, (half_t*)nullptr, L, H, m->cfg.heads, M);
-#define LN2(PER) launch_ln<PER>(m, m->y32, ly.ln2_g, ly.ln2_b, M, st)
+        hipLaunchKernelGGL(ce_gemm_kernel<EPI_GELU>, dim3(F / CE_BM, mt), blk, lds, st, ly.w1, (size_t)F * H, m->x16, pp.x, F, H,
+                           ly.b1, (const float*)nullptr, (float*)nullptr, m->h16, pp.h, (half_t*)nullptr, (size_t)0, L, H,
+                           m->cfg.heads, M);
+        hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(H / CE_BM, mt), blk, lds, st, ly.w2, (size_t)H * F, m->h16, pp.h, H, F,
+                           ly.b2, m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (size_t)0, L, H, m->cfg.heads, M);
+#define LN2(PER) launch_ln<PER>(m, m->y32, ly.ln2_g, ly.ln2_b, M, pp.x, st)
         CE_PER_DISPATCH(LN2)
     }
+    (void)nullh;
     hipLaunchKernelGGL(ce_pool_classify_kernel, dim3(P), dim3(256), 0, st, m->x32, m->wp, m->bp, m->wc, m->bc, L, H, m->logits);
     HIP_TRY(h, hipGetLastError());
     return RAG_OK;
@@ -486,19 +563,23 @@ static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L) {
     const int64_t Mp = round_up((int64_t)P * L, CE_BN);
     HIP_TRY(h, hipMalloc(&m->x32, (size_t)Mp * H * 4));
     HIP_TRY(h, hipMalloc(&m->y32, (size_t)Mp * H * 4));
-    HIP_TRY(h, hipMalloc(&m->x16, (size_t)Mp * H * 2));
-    HIP_TRY(h, hipMalloc(&m->qk16, (size_t)Mp * 2 * H * 2));
-    HIP_TRY(h, hipMalloc(&m->vt16, (size_t)Mp * H * 2 + 4096));
-    HIP_TRY(h, hipMalloc(&m->ctx16, (size_t)Mp * H * 2));
-    HIP_TRY(h, hipMalloc(&m->h16, (size_t)Mp * F * 2));
+    m->ws_pairs = P;                                     // planes_for() uses the allocated pair count
+    const ce_planes pp = planes_for(m, Mp);
+    HIP_TRY(h, hipMalloc(&m->x16, 2 * pp.x * 2));
+    HIP_TRY(h, hipMalloc(&m->qk16, 2 * pp.qk * 2));
+    HIP_TRY(h, hipMalloc(&m->vt16, 2 * pp.vt * 2));
+    HIP_TRY(h, hipMalloc(&m->ctx16, 2 * pp.ctx * 2));
+    HIP_TRY(h, hipMalloc(&m->h16, 2 * pp.h * 2));
     HIP_TRY(h, hipMalloc(&m->ids, (size_t)Mp * 4));
     HIP_TRY(h, hipMalloc(&m->tt, (size_t)Mp * 4));
     HIP_TRY(h, hipMalloc(&m->lens, (size_t)P * 4));
     HIP_TRY(h, hipMalloc(&m->logits, (size_t)P * 4));
     // padded token rows are read by the GEMM tiles: keep them finite
-    HIP_TRY(h, hipMemset(m->x16, 0, (size_t)Mp * H * 2));
-    HIP_TRY(h, hipMemset(m->ctx16, 0, (size_t)Mp * H * 2));
-    HIP_TRY(h, hipMemset(m->h16, 0, (size_t)Mp * F * 2));
+    HIP_TRY(h, hipMemset(m->x16, 0, 2 * pp.x * 2));
+    HIP_TRY(h, hipMemset(m->ctx16, 0, 2 * pp.ctx * 2));
+    HIP_TRY(h, hipMemset(m->h16, 0, 2 * pp.h * 2));
+    HIP_TRY(h, hipMemset(m->qk16, 0, 2 * pp.qk * 2));
+    HIP_TRY(h, hipMemset(m->vt16, 0, 2 * pp.vt * 2));
     HIP_TRY(h, hipMemset(m->x32, 0, (size_t)Mp * H * 4));
     m->ws_pairs = P;
     m->ws_L = L;
@@ -524,7 +605,7 @@ int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* l
     ARG_CHECK(h, L_in <= m->cfg.max_pos && L_in <= 512, "ce_score: sequence longer than max_position_embeddings/512");
     int L = 0;
     for (int c : kAttnL) if (c >= L_in) { L = c; break; }
-    const int chunk = std::max(1, std::min(P, (int)(2'000'000 / L)));        // ~2M tokens of activations per chunk (~20 GB)
+    const int chunk = std::max(1, std::min(P, (int)(2'000'000 / L)));        // ~2M tokens of activations per chunk (~30 GB)
     int rc = ce_ensure_ws(h, m, chunk, L);
     if (rc) return rc;
     const hipMemcpyKind kin = host_ptrs ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
