@@ -67,19 +67,61 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 // Block -> tile map is XCD aware: the n_qtiles blocks that share one corpus tile run back-to-back on the
 // same XCD (blockIdx % 8), so each corpus tile leaves HBM once and is re-read from that XCD's L2.
 // ------------------------------------------------------------------------------------------------
-#define TILE_BYTES (RAG_TILE * RAG_BK * 2)   // 32 KiB per operand per stage
+#define HALF_BYTES (128 * RAG_BK * 2)         // one half-tile: 128 rows x 64 halfs = 16 KiB
+#define TILE_BYTES (4 * HALF_BYTES)           // one K-step stage: A0 | A1 | B0 | B1
+#define DENSE_LDS_BYTES (2 * TILE_BYTES)      // two stages = 128 KiB
 
-__device__ __forceinline__ void stage_tile(const half_t* __restrict__ gsrc, int ld, char* lds_tile, int tid, int wid) {
-    // 2048 16-byte chunks, 512 threads -> 4 DMA pieces per thread; piece j of this wave lands at
-    // linear chunk j*512 + wid*64 (+lane): wave-uniform base + lane*16, as LDS-DMA requires.
+// One half-tile (128 rows x 128 B = 1024 chunks of 16 B) by LDS-DMA: 512 threads -> 2 pieces per thread; piece j of
+// this wave lands at linear chunk j*512 + wid*64 (+lane): wave-uniform base + lane*16, as LDS-DMA requires.
+__device__ __forceinline__ void stage_half(const half_t* __restrict__ gsrc, int ld, char* lds_half, int wid) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const half_t* g = gsrc + (size_t)j * 64 * ld;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(lds_tile + (j * 512 + wid * 64) * 16),
+    for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + (size_t)j * 64 * ld),
+                                         (__attribute__((address_space(3))) void*)(lds_half + (j * 512 + wid * 64) * 16),
                                          16, 0, 0);
-    }
 }
+
+struct FragA { half8 v[2][4]; };    // one 64-row M-sub of the wave's A half: [kk][i]
+struct FragB { half8 v[2][2]; };    // one 32-col N-sub of the wave's B rows:  [kk][j]
+
+__device__ __forceinline__ void load_fragA(FragA& f, const char* base, const int (&off_k)[2]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f.v[kk][i] = *reinterpret_cast<const half8*>(base + i * 16 * 128 + off_k[kk]);
+}
+__device__ __forceinline__ void load_fragB(FragB& f, const char* base, const int (&off_k)[2]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) f.v[kk][j] = *reinterpret_cast<const half8*>(base + j * 16 * 128 + off_k[kk]);
+}
+
+// Pipeline (per 64-deep K-step t, stage b = t & 1; per wave the 128x64 output is 2 M-subs x 2 N-subs):
+//   phase      MFMA quadrant   fragment read issued first (lands under the MFMAs)   DMA issued (half-tile of step)
+//   ph1(t)     (A0,B0)         B1(t)                                                 B0(t+1 .. see below)
+//   ph2(t)     (A0,B1)         A1(t)
+//   ph3(t)     (A1,B1)         A0(t+1)
+//   ph4(t)     (A1,B0)         B0(t+1)
+// DMA order per step u: A0(u) @ph3(u-2), A1(u) @ph4(u-2), B0(u) @ph1(u-1), B1(u) @ph2(u-1)  (2 glds per thread
+// each). Stage b's A slots are last read in ph2 and its B slots in ph1, and every phase ends with
+// lgkmcnt(0) + s_barrier, so each DMA is issued at least one barrier after the last read of its slot (WAR), and
+// each wave waits its own counted vmcnt before the barrier that precedes the first read of a landed slot (RAW):
+// vmcnt(4) at the end of ph2 (A(t+1) landed, B(t+1) may fly), vmcnt(2) at the end of ph3 (B(t+1) landed). DMA never
+// drains to 0 inside the loop. Register roles of the B sets alternate between even and odd steps, hence the 8-phase
+// (two K-step) loop body. Source steps past the end are clamped (harmless re-loads) so the counts stay exact.
+#define MFMA_QUAD(FA, FB, SA, SB)                                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                           \
+        acc[(SA) * 4 + i][(SB) * 2 + j] =                                                                   \
+            __builtin_amdgcn_mfma_f32_16x16x32_f16(FA.v[kk][i], FB.v[kk][j], acc[(SA) * 4 + i][(SB) * 2 + j], 0, 0, 0);
+
+#define PHASE_END(VMWAIT)                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+    VMWAIT;                                                                                                 \
+    __builtin_amdgcn_s_barrier();                                                                           \
+    __builtin_amdgcn_sched_barrier(0);
 
 template <bool DENSE0>
 __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restrict__ corpus16, const half_t* __restrict__ q16,
@@ -102,22 +144,22 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
     const int row0 = (rtile_begin + rt) * RAG_TILE;
     const int q0 = qt * RAG_TILE;
 
-    // per-thread DMA source: LDS linear chunk i = j*512 + tid -> row r = i>>3 (j*64 + tid>>3), position i&7
+    // per-thread DMA source inside a half-tile: linear chunk i = j*512 + tid -> row j*64 + (tid>>3), position tid&7
     const int sr = tid >> 3;
     const int schunk = (tid & 7) ^ ((sr >> 1) & 7);
-    const half_t* a_src = corpus16 + (size_t)(row0 + sr) * Dp + schunk * 8;
+    const half_t* a_src = corpus16 + (size_t)(row0 + sr) * Dp + schunk * 8;          // + h*128*Dp for half h
     const half_t* b_src = q16 + (size_t)(q0 + sr) * Dp + schunk * 8;
+    const size_t half_rows = (size_t)128 * Dp;
 
-    // LDS: stage b holds A at smem + b*2*TILE_BYTES and B right after it
-
-    // fragment read offsets: row = base + (lane&15), chunk = kk*4 + (lane>>4), swizzled
+    // fragment read offsets: row = base + (lane&15), chunk = kk*4 + (lane>>4), swizzled by ((row>>1)&7)
     const int fr = lane & 15, fq = lane >> 4;
     const int sw = (fr >> 1) & 7;
     int off_k[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) off_k[kk] = fr * 128 + (((kk * 4 + fq) ^ sw) << 4);
-    const int a_base = wm * 128 * 128;   // bytes: wave's first corpus row * 128 B
-    const int b_base = wn * 64 * 128;
+    // this wave reads A from half wm (rows s*64 + i*16 + fr) and B from half wn>>1 (rows (wn&1)*64 + s*32 + j*16 + fr)
+    const int a_off = wm * HALF_BYTES;
+    const int b_off = 2 * HALF_BYTES + (wn >> 1) * HALF_BYTES + (wn & 1) * 64 * 128;
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -125,35 +167,78 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nt = Dp / RAG_BK;
-    stage_tile(a_src, Dp, smem, tid, wid);
-    stage_tile(b_src, Dp, smem + TILE_BYTES, tid, wid);
-    __syncthreads();
-    int cur = 0;
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) {
-            char* nxt = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            stage_tile(a_src + (t + 1) * RAG_BK, Dp, nxt, tid, wid);
-            stage_tile(b_src + (t + 1) * RAG_BK, Dp, nxt + TILE_BYTES, tid, wid);
-        }
-        const char* la = smem + cur * 2 * TILE_BYTES + a_base;
-        const char* lb = smem + cur * 2 * TILE_BYTES + TILE_BYTES + b_base;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            half8 bf[4], af[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const half8*>(lb + j * 16 * 128 + off_k[kk]);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const half8*>(la + i * 16 * 128 + off_k[kk]);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-        cur ^= 1;
+    const int nt = Dp / RAG_BK;            // even (dim_pad is a multiple of 128)
+    const int last = nt - 1;
+#define SRC_STEP(u) (((u) < last ? (u) : last) * RAG_BK)
+#define STAGE_A(h, u) stage_half(a_src + (h) * half_rows + SRC_STEP(u), Dp, smem + ((u) & 1) * TILE_BYTES + (h) * HALF_BYTES, wid)
+#define STAGE_B(h, u) stage_half(b_src + (h) * half_rows + SRC_STEP(u), Dp, smem + ((u) & 1) * TILE_BYTES + (2 + (h)) * HALF_BYTES, wid)
+#define LDS_A(s, u) (smem + ((u) & 1) * TILE_BYTES + a_off + (s) * 64 * 128)
+#define LDS_B(s, u) (smem + ((u) & 1) * TILE_BYTES + b_off + (s) * 32 * 128)
+
+    // prologue: step 0 complete, A halves of step 1 in flight
+    STAGE_A(0, 0); STAGE_A(1, 0); STAGE_B(0, 0); STAGE_B(1, 0);
+    STAGE_A(0, 1); STAGE_A(1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    FragA ax, ay;
+    FragB bx, by;
+    load_fragA(ax, LDS_A(0, 0), off_k);
+    load_fragB(bx, LDS_B(0, 0), off_k);
+
+    for (int t = 0; t < nt; t += 2) {
+        // ---------------- even step t: A0 in ax, B0 in bx ----------------
+        load_fragB(by, LDS_B(1, t), off_k);                 // B1(t)
+        STAGE_B(0, t + 1);
+        __builtin_amdgcn_s_setprio(1);
+        MFMA_QUAD(ax, bx, 0, 0)
+        __builtin_amdgcn_s_setprio(0);
+        PHASE_END((void)0)
+        load_fragA(ay, LDS_A(1, t), off_k);                 // A1(t)
+        STAGE_B(1, t + 1);
+        __builtin_amdgcn_s_setprio(1);
+        MFMA_QUAD(ax, by, 0, 1)
+        __builtin_amdgcn_s_setprio(0);
+        PHASE_END(asm volatile("s_waitcnt vmcnt(4)" ::: "memory"))      // A(t+1) landed
+        load_fragA(ax, LDS_A(0, t + 1), off_k);             // A0(t+1)
+        STAGE_A(0, t + 2);
+        __builtin_amdgcn_s_setprio(1);
+        MFMA_QUAD(ay, by, 1, 1)
+        __builtin_amdgcn_s_setprio(0);
+        PHASE_END(asm volatile("s_waitcnt vmcnt(2)" ::: "memory"))      // B(t+1) landed
+        load_fragB(by, LDS_B(0, t + 1), off_k);             // B0(t+1) -> by (roles swap on odd steps)
+        STAGE_A(1, t + 2);
+        __builtin_amdgcn_s_setprio(1);
+        MFMA_QUAD(ay, bx, 1, 0)
+        __builtin_amdgcn_s_setprio(0);
+        PHASE_END((void)0)
+        // ---------------- odd step t+1: A0 in ax, B0 in by ----------------
+        load_fragB(bx, LDS_B(1, t + 1), off_k);             // B1(t+1)
+        STAGE_B(0, t + 2);
+        __builtin_amdgcn_s_setprio(1);
+        MFMA_QUAD(ax, by, 0, 0)
+        __builtin_amdgcn_s_setprio(0);
+        PHASE_END((void)0)
+        load_fragA(ay, LDS_A(1, t + 1), off_k);             // A1(t+1)
+        STAGE_B(1, t + 2);
+        __builtin_amdgcn_s_setprio(1);
+        MFMA_QUAD(ax, bx, 0, 1)
+        __builtin_amdgcn_s_setprio(0);
+        PHASE_END(asm volatile("s_waitcnt vmcnt(4)" ::: "memory"))      // A(t+2) landed
+        load_fragA(ax, LDS_A(0, t + 2), off_k);             // A0(t+2)
+        STAGE_A(0, t + 3);
+        __builtin_amdgcn_s_setprio(1);
+        MFMA_QUAD(ay, bx, 1, 1)
+        __builtin_amdgcn_s_setprio(0);
+        PHASE_END(asm volatile("s_waitcnt vmcnt(2)" ::: "memory"))      // B(t+2) landed
+        load_fragB(bx, LDS_B(0, t + 2), off_k);             // B0(t+2) -> bx
+        STAGE_A(1, t + 3);
+        __builtin_amdgcn_s_setprio(1);
+        MFMA_QUAD(ay, by, 1, 0)
+        __builtin_amdgcn_s_setprio(0);
+        PHASE_END((void)0)
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // clamped tail re-loads still in flight: retire them
 
     // ---- epilogue: C layout col = lane&15 (query), row = (lane>>4)*4 + reg (corpus row) ----------
     const float scale = 1.0f / (float)(1 << (2 * RAG_SCALE_LOG2));
@@ -618,9 +703,9 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wide_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, RAG_CAND_CAP * 12));
         attr_set = true;
@@ -655,10 +740,10 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
             HIP_TRY(h, hipEventRecord(h->gemm_events[h->gemm_events_used].first, st));
         }
         if (stage == 0)
-            hipLaunchKernelGGL(dense_emit_kernel<true>, dim3(grid), dim3(512), 4 * TILE_BYTES, st, h->emb16, h->q16,
+            hipLaunchKernelGGL(dense_emit_kernel<true>, dim3(grid), dim3(512), DENSE_LDS_BYTES, st, h->emb16, h->q16,
                                h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant);
         else
-            hipLaunchKernelGGL(dense_emit_kernel<false>, dim3(grid), dim3(512), 4 * TILE_BYTES, st, h->emb16, h->q16,
+            hipLaunchKernelGGL(dense_emit_kernel<false>, dim3(grid), dim3(512), DENSE_LDS_BYTES, st, h->emb16, h->q16,
                                h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant);
         HIP_TRY(h, hipGetLastError());
         if (h->profiling && stage > 0) {
