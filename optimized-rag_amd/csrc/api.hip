@@ -46,7 +46,7 @@ int rag_create(int device_id, int dim, rag_handle_t* out) {
     rag_ctx* h = new rag_ctx();
     h->device = device_id;
     h->dim = dim;
-    h->dim_pad = (int)round_up(dim, 2 * RAG_BK);   // even number of 64-deep K-steps (two-step loop body)
+    h->dim_pad = (int)round_up(dim, RAG_BK);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return RAG_ERR_HIP;

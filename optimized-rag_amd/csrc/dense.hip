@@ -97,19 +97,23 @@ __device__ __forceinline__ void load_fragB(FragB& f, const char* base, const int
         for (int j = 0; j < 2; ++j) f.v[kk][j] = *reinterpret_cast<const half8*>(base + j * 16 * 128 + off_k[kk]);
 }
 
-// Pipeline (per 64-deep K-step t, stage b = t & 1; per wave the 128x64 output is 2 M-subs x 2 N-subs):
-//   phase      MFMA quadrant   fragment read issued first (lands under the MFMAs)   DMA issued (half-tile of step)
-//   ph1(t)     (A0,B0)         B1(t)                                                 B0(t+1 .. see below)
-//   ph2(t)     (A0,B1)         A1(t)
-//   ph3(t)     (A1,B1)         A0(t+1)
-//   ph4(t)     (A1,B0)         B0(t+1)
-// DMA order per step u: A0(u) @ph3(u-2), A1(u) @ph4(u-2), B0(u) @ph1(u-1), B1(u) @ph2(u-1)  (2 glds per thread
-// each). Stage b's A slots are last read in ph2 and its B slots in ph1, and every phase ends with
-// lgkmcnt(0) + s_barrier, so each DMA is issued at least one barrier after the last read of its slot (WAR), and
-// each wave waits its own counted vmcnt before the barrier that precedes the first read of a landed slot (RAW):
-// vmcnt(4) at the end of ph2 (A(t+1) landed, B(t+1) may fly), vmcnt(2) at the end of ph3 (B(t+1) landed). DMA never
-// drains to 0 inside the loop. Register roles of the B sets alternate between even and odd steps, hence the 8-phase
-// (two K-step) loop body. Source steps past the end are clamped (harmless re-loads) so the counts stay exact.
+// Pipeline. Per 64-deep K-step t (LDS stage t & 1) a wave's 128x64 output is 2 M-subs x 2 N-subs = 4 phases of 16
+// MFMAs: p1 (A0,B0)  p2 (A1,B0)  p3 (A1,B1)  p4 (A0,B1)   (A0/A1 = 64-row sub-blocks of the wave's OWN corpus half,
+// B0/B1 = 32-query sub-blocks of its own query half). Every phase is an I-part (LDS fragment reads + one half-tile
+// LDS-DMA issue, then lgkmcnt(0)) and an M-part (16 MFMAs), each closed by s_barrier. The two waves that share a
+// SIMD (wave w and w+4, i.e. wm = 0 / 1) run HALF A PHASE APART (waves 4-7 take one extra barrier up front, waves
+// 0-3 one at the end): while one wave's MFMAs own the matrix pipe its partner reads fragments and issues DMA.
+//   reads : I1: A0(t) -> ax    I2: A1(t) -> ay    I3: B1(t) -> by    I4: B0(t+1) -> bx
+//   DMA   : I1: Bh0(t+1)       I2: Bh1(t+1)       I3: Ah0(t+2)       I4: Ah1(t+2)       (h0/h1 = 128-row half-tiles)
+//   slot lifetimes (stage t&1): corpus halves are read in I1,I2 of step t  -> refilled from I3(t)   (WAR ok)
+//                               query  halves are read in I4(t-1), I3(t)   -> refilled from I1(t+1) (WAR ok)
+//           a DMA is always issued in a LATER phase than the slot's last read, reads retire (lgkmcnt(0)) before the
+//           barrier closing their part, and the lagging group is only half a phase behind, so it has retired too.
+//   RAW   : one counted wait per step, s_waitcnt vmcnt(2) in the barrier interval before the leading group's I4:
+//           waves 0-3 at the end of their M3, waves 4-7 at the end of their I3. In-order retirement then guarantees
+//           B(t+1) (issued I1,I2 of t) and A(t+1) (issued I3,I4 of t-1: 4 and 3 phases ahead, the HBM-latency
+//           operand) have landed; only Ah0(t+2) stays in flight. DMA never drains to 0 inside the loop; source
+//           steps past the end are clamped (harmless re-loads) so the count stays exact.
 #define MFMA_QUAD(FA, FB, SA, SB)                                                                           \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
@@ -117,23 +121,66 @@ __device__ __forceinline__ void load_fragB(FragB& f, const char* base, const int
         acc[(SA) * 4 + i][(SB) * 2 + j] =                                                                   \
             __builtin_amdgcn_mfma_f32_16x16x32_f16(FA.v[kk][i], FB.v[kk][j], acc[(SA) * 4 + i][(SB) * 2 + j], 0, 0, 0);
 
-#define PHASE_END(VMWAIT)                                                                                   \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
-    VMWAIT;                                                                                                 \
+// tools/gemm_probe.hip builds this file with DENSE_STAMP to split a phase into I-part / M-part / waits
+// (s_memtime stamps at points where lgkmcnt is already 0; diagnostic build only, never shipped).
+#ifdef DENSE_STAMP
+#define STAMP(IDX)                                                                                          \
+    {                                                                                                       \
+        unsigned long long _t;                                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                         \
+        stamp_acc[IDX] += _t - stamp_prev;                                                                  \
+        stamp_prev = _t;                                                                                    \
+    }
+#define STAMP_ARG , (unsigned long long*)nullptr
+#else
+#define STAMP(IDX)
+#define STAMP_ARG
+#endif
+
+#ifdef PROBE_NOWAIT      // timing experiment only (tools/gemm_probe.hip): results are wrong without the wait
+#define DMA_WAIT asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#else
+#define DMA_WAIT asm volatile("s_waitcnt vmcnt(2)" ::: "memory")
+#endif
+#define BARRIER                                                                                             \
     __builtin_amdgcn_s_barrier();                                                                           \
     __builtin_amdgcn_sched_barrier(0);
+// I-part: the caller has just written this phase's fragment reads and its DMA issue. WAIT = 1 on phase 3 only.
+#define I_END(WAIT)                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+    STAMP(0)                                                                                                \
+    if ((WAIT) && lag) DMA_WAIT;                                                                            \
+    STAMP(1)                                                                                                \
+    BARRIER                                                                                                 \
+    STAMP(2)
+#define M_PART(FA, FB, SA, SB, WAIT)                                                                        \
+    __builtin_amdgcn_s_setprio(1);                                                                          \
+    MFMA_QUAD(FA, FB, SA, SB)                                                                               \
+    __builtin_amdgcn_s_setprio(0);                                                                          \
+    STAMP(3)                                                                                                \
+    if ((WAIT) && !lag) DMA_WAIT;                                                                           \
+    STAMP(1)                                                                                                \
+    BARRIER                                                                                                 \
+    STAMP(2)
 
 template <bool DENSE0>
 __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restrict__ corpus16, const half_t* __restrict__ q16,
                                                           int Dp, int rtile_begin, int n_rtiles, int n_qtiles,
                                                           int n_rows_valid, int q_valid, const float* __restrict__ tau,
                                                           unsigned* __restrict__ cnt, uint64_t* __restrict__ cand,
-                                                          const int32_t* __restrict__ tenants, int tenant) {
+                                                          const int32_t* __restrict__ tenants, int tenant
+#ifdef DENSE_STAMP
+                                                          , unsigned long long* __restrict__ stamp_out
+#endif
+) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
+#ifdef DENSE_STAMP
+    unsigned long long stamp_acc[4] = {0ull, 0ull, 0ull, 0ull}, stamp_prev = 0ull;
+#endif
 
     // XCD-aware tile assignment (speed only; any placement is correct)
     const int b = blockIdx.x;
@@ -175,70 +222,33 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
 #define LDS_A(s, u) (smem + ((u) & 1) * TILE_BYTES + a_off + (s) * 64 * 128)
 #define LDS_B(s, u) (smem + ((u) & 1) * TILE_BYTES + b_off + (s) * 32 * 128)
 
-    // prologue: step 0 complete, A halves of step 1 in flight
-    STAGE_A(0, 0); STAGE_A(1, 0); STAGE_B(0, 0); STAGE_B(1, 0);
+    // prologue: step 0 complete, corpus halves of step 1 in flight
+    const bool lag = wm != 0;               // waves 4-7 run half a phase behind waves 0-3 (wave-uniform: from readfirstlane)
+    STAGE_B(0, 0); STAGE_B(1, 0); STAGE_A(0, 0); STAGE_A(1, 0);
     STAGE_A(0, 1); STAGE_A(1, 1);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
+    BARRIER
     FragA ax, ay;
     FragB bx, by;
-    load_fragA(ax, LDS_A(0, 0), off_k);
-    load_fragB(bx, LDS_B(0, 0), off_k);
+    load_fragB(bx, LDS_B(0, 0), off_k);                      // B0(0) (normally read in I4 of the previous step)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef DENSE_STAMP
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+    if (lag) { BARRIER }
 
-    for (int t = 0; t < nt; t += 2) {
-        // ---------------- even step t: A0 in ax, B0 in bx ----------------
-        load_fragB(by, LDS_B(1, t), off_k);                 // B1(t)
-        STAGE_B(0, t + 1);
-        __builtin_amdgcn_s_setprio(1);
-        MFMA_QUAD(ax, bx, 0, 0)
-        __builtin_amdgcn_s_setprio(0);
-        PHASE_END((void)0)
-        load_fragA(ay, LDS_A(1, t), off_k);                 // A1(t)
-        STAGE_B(1, t + 1);
-        __builtin_amdgcn_s_setprio(1);
-        MFMA_QUAD(ax, by, 0, 1)
-        __builtin_amdgcn_s_setprio(0);
-        PHASE_END(asm volatile("s_waitcnt vmcnt(4)" ::: "memory"))      // A(t+1) landed
-        load_fragA(ax, LDS_A(0, t + 1), off_k);             // A0(t+1)
-        STAGE_A(0, t + 2);
-        __builtin_amdgcn_s_setprio(1);
-        MFMA_QUAD(ay, by, 1, 1)
-        __builtin_amdgcn_s_setprio(0);
-        PHASE_END(asm volatile("s_waitcnt vmcnt(2)" ::: "memory"))      // B(t+1) landed
-        load_fragB(by, LDS_B(0, t + 1), off_k);             // B0(t+1) -> by (roles swap on odd steps)
-        STAGE_A(1, t + 2);
-        __builtin_amdgcn_s_setprio(1);
-        MFMA_QUAD(ay, bx, 1, 0)
-        __builtin_amdgcn_s_setprio(0);
-        PHASE_END((void)0)
-        // ---------------- odd step t+1: A0 in ax, B0 in by ----------------
-        load_fragB(bx, LDS_B(1, t + 1), off_k);             // B1(t+1)
-        STAGE_B(0, t + 2);
-        __builtin_amdgcn_s_setprio(1);
-        MFMA_QUAD(ax, by, 0, 0)
-        __builtin_amdgcn_s_setprio(0);
-        PHASE_END((void)0)
-        load_fragA(ay, LDS_A(1, t + 1), off_k);             // A1(t+1)
-        STAGE_B(1, t + 2);
-        __builtin_amdgcn_s_setprio(1);
-        MFMA_QUAD(ax, bx, 0, 1)
-        __builtin_amdgcn_s_setprio(0);
-        PHASE_END(asm volatile("s_waitcnt vmcnt(4)" ::: "memory"))      // A(t+2) landed
-        load_fragA(ax, LDS_A(0, t + 2), off_k);             // A0(t+2)
-        STAGE_A(0, t + 3);
-        __builtin_amdgcn_s_setprio(1);
-        MFMA_QUAD(ay, bx, 1, 1)
-        __builtin_amdgcn_s_setprio(0);
-        PHASE_END(asm volatile("s_waitcnt vmcnt(2)" ::: "memory"))      // B(t+2) landed
-        load_fragB(bx, LDS_B(0, t + 2), off_k);             // B0(t+2) -> bx
-        STAGE_A(1, t + 3);
-        __builtin_amdgcn_s_setprio(1);
-        MFMA_QUAD(ay, by, 1, 0)
-        __builtin_amdgcn_s_setprio(0);
-        PHASE_END((void)0)
+    for (int t = 0; t < nt; ++t) {
+        load_fragA(ax, LDS_A(0, t), off_k);      STAGE_B(0, t + 1);   I_END(0)   M_PART(ax, bx, 0, 0, 0)
+        load_fragA(ay, LDS_A(1, t), off_k);      STAGE_B(1, t + 1);   I_END(0)   M_PART(ay, bx, 1, 0, 0)
+        load_fragB(by, LDS_B(1, t), off_k);      STAGE_A(0, t + 2);   I_END(1)   M_PART(ay, by, 1, 1, 1)
+        load_fragB(bx, LDS_B(0, t + 1), off_k);  STAGE_A(1, t + 2);   I_END(0)   M_PART(ax, by, 0, 1, 0)
     }
+    if (!lag) { BARRIER }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // clamped tail re-loads still in flight: retire them
+#ifdef DENSE_STAMP
+    if (lane == 0 && stamp_out)
+        for (int i = 0; i < 4; ++i) stamp_out[((size_t)blockIdx.x * 8 + wid) * 4 + i] = stamp_acc[i];
+#endif
 
     // ---- epilogue: C layout col = lane&15 (query), row = (lane>>4)*4 + reg (corpus row) ----------
     const float scale = 1.0f / (float)(1 << (2 * RAG_SCALE_LOG2));
@@ -741,10 +751,10 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
         }
         if (stage == 0)
             hipLaunchKernelGGL(dense_emit_kernel<true>, dim3(grid), dim3(512), DENSE_LDS_BYTES, st, h->emb16, h->q16,
-                               h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant);
+                               h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant STAMP_ARG);
         else
             hipLaunchKernelGGL(dense_emit_kernel<false>, dim3(grid), dim3(512), DENSE_LDS_BYTES, st, h->emb16, h->q16,
-                               h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant);
+                               h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant STAMP_ARG);
         HIP_TRY(h, hipGetLastError());
         if (h->profiling && stage > 0) {
             HIP_TRY(h, hipEventRecord(h->gemm_events[h->gemm_events_used].second, st));
