@@ -286,75 +286,121 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: per-query select. One workgroup per query: bitonic sort (descending) of the candidate keys in
-// LDS; keys are unique (row is part of the key) so the order is total: score desc, row asc.
+// K2: per-query select as a PER-WAVEFRONT bitwise radix select (one wave per query, 4 queries per workgroup).
+// Keys are unique 64-bit values (orderable score << 32 | ~row), so "the keep-th largest key" is a total-order
+// pivot: build it MSB-first, one bit per step, counting keys >= candidate with ballot + popcount (no atomics, no
+// sort, no cross-lane reduction). Stops as soon as a candidate has exactly `keep` keys above it. Survivors are
+// compacted to the front of cand[] with ballot prefix sums; nothing downstream needs them sorted (rescore /
+// finalize rank by the exact float64 score).
 //   n_in   = dense0_rows (stage 0: slots 0..rows-1, empty slots are 0) or min(cnt, cap)
-//   keep   = K' : cand[0..m) sorted, cnt = m, tau = score of the K'-th key (or -inf when fewer exist)
-//   final  : additionally leaves ALL sorted candidates in cand[], n_sorted = their count,
-//            bound = max(tau_in, score of the best candidate beyond the shortlist)
+//   keep   = K' : cand[0..m) = the m = min(valid, K') best keys, cnt = m, tau = score of the K'-th best
+//   final  : the other valid keys follow at cand[m..n_valid), n_sorted = n_valid,
+//            bound = max(tau_in, best score beyond the shortlist), +inf if the buffer ever overflowed
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bitonic_sort_desc_u64(uint64_t* s, int P, int tid, int nthreads) {
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P; i += nthreads) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const uint64_t a = s[i], b = s[ixj];
-                    const bool desc_block = ((i & k) == 0);
-                    if (desc_block ? (a < b) : (a > b)) {
-                        s[i] = b;
-                        s[ixj] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
+#define SEL_REG 32                      // keys held in registers per lane (covers 2048 candidates)
+#define SELECT_LDS_BYTES (4 * (RAG_CAND_CAP - SEL_REG * 64) * 8)
 __global__ __launch_bounds__(256) void select_kernel(uint64_t* __restrict__ cand, unsigned* __restrict__ cnt,
                                                       float* __restrict__ tau, float* __restrict__ bound,
-                                                      int* __restrict__ n_sorted, int* __restrict__ stats,
+                                                      int* __restrict__ n_sorted, int* __restrict__ stats, int n_queries,
                                                       int dense0_rows, int keep, int final_stage) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* s = reinterpret_cast<uint64_t*>(smem);
-    const int q = blockIdx.x, tid = threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wv;
+    if (q >= n_queries) return;                              // whole wave exits; no block-level sync is used
+    uint64_t* spill = reinterpret_cast<uint64_t*>(smem) + (size_t)wv * (RAG_CAND_CAP - SEL_REG * 64);
     uint64_t* c = cand + (size_t)q * RAG_CAND_CAP;
     const unsigned emitted = cnt[q];
-    int n_in = dense0_rows > 0 ? dense0_rows : (int)min(emitted, (unsigned)RAG_CAND_CAP);
-    if (dense0_rows == 0 && emitted > RAG_CAND_CAP && tid == 0) atomicAdd(&stats[4], 1);   // overflow
-    int P = 64;
-    while (P < n_in) P <<= 1;
-    for (int i = tid; i < P; i += 256) s[i] = i < n_in ? c[i] : 0ull;
-    __syncthreads();
-    bitonic_sort_desc_u64(s, P, tid, 256);
-    // count non-empty keys (sorted descending: zeros at the end)
-    __shared__ int n_valid_sh;
-    if (tid == 0) n_valid_sh = 0;
-    __syncthreads();
-    int local = 0;
-    for (int i = tid; i < n_in; i += 256) local += (s[i] != 0ull);
-    if (local) atomicAdd(&n_valid_sh, local);
-    __syncthreads();
-    const int n_valid = n_valid_sh;
+    const bool overflow = dense0_rows == 0 && emitted > RAG_CAND_CAP;
+    const int n_in = dense0_rows > 0 ? dense0_rows : (int)min(emitted, (unsigned)RAG_CAND_CAP);
+    if (overflow && lane == 0) atomicAdd(&stats[4], 1);
+    // keys: first SEL_REG*64 in registers (element e*64 + lane), the rest (rare) in this wave's LDS slice
+    uint64_t kreg[SEL_REG];
+#pragma unroll
+    for (int e = 0; e < SEL_REG; ++e) {
+        const int i = e * 64 + lane;
+        kreg[e] = i < n_in ? c[i] : 0ull;
+    }
+    const int n_spill = max(0, n_in - SEL_REG * 64);
+    for (int i = lane; i < n_spill; i += 64) spill[i] = c[SEL_REG * 64 + i];
+    int n_valid = 0;
+#pragma unroll
+    for (int e = 0; e < SEL_REG; ++e) n_valid += __popcll(__ballot(kreg[e] != 0ull));
+    for (int i = lane; i < ((n_spill + 63) & ~63); i += 64) n_valid += __popcll(__ballot(i < n_spill && spill[i] != 0ull));
     const int m = min(n_valid, keep);
-    const int n_write = final_stage ? n_valid : m;
-    for (int i = tid; i < n_write; i += 256) c[i] = s[i];
-    if (tid == 0) {
+    uint64_t pivot = 1ull;                                   // every valid key is >= 1
+    if (n_valid > keep) {
+        pivot = 0ull;
+        for (int bit = 63; bit >= 0; --bit) {
+            const uint64_t trial = pivot | (1ull << bit);
+            int ge = 0;
+#pragma unroll
+            for (int e = 0; e < SEL_REG; ++e) ge += __popcll(__ballot(kreg[e] >= trial));
+            for (int i = lane; i < ((n_spill + 63) & ~63); i += 64) ge += __popcll(__ballot(i < n_spill && spill[i] >= trial));
+            if (ge >= keep) pivot = trial;
+            if (ge == keep) break;                           // exactly `keep` keys are >= pivot: done
+        }
+    }
+    // compaction: keys >= pivot first (exactly m of them), the others after (final stage only); track best dropped
+    uint64_t best_dropped = 0ull;
+    int n_top = 0;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int e = 0; e < SEL_REG; ++e) {
+        const uint64_t k = kreg[e];
+        const bool top = k != 0ull && k >= pivot;
+        const uint64_t bt = __ballot(top);
+        if (top) c[n_top + __popcll(bt & lt_mask)] = k;
+        if (k != 0ull && k < pivot) best_dropped = best_dropped > k ? best_dropped : k;
+        n_top += __popcll(bt);
+    }
+    for (int i0 = 0; i0 < n_spill; i0 += 64) {
+        const int i = i0 + lane;
+        const uint64_t k = i < n_spill ? spill[i] : 0ull;
+        const bool top = k != 0ull && k >= pivot;
+        const uint64_t bt = __ballot(top);
+        if (top) c[n_top + __popcll(bt & lt_mask)] = k;
+        if (k != 0ull && k < pivot) best_dropped = best_dropped > k ? best_dropped : k;
+        n_top += __popcll(bt);
+    }
+    if (final_stage) {                                       // second pass: append the non-shortlisted valid keys
+        int pos = m;
+#pragma unroll
+        for (int e = 0; e < SEL_REG; ++e) {
+            const uint64_t k = kreg[e];
+            const bool rest = k != 0ull && k < pivot;
+            const uint64_t br = __ballot(rest);
+            if (rest) c[pos + __popcll(br & lt_mask)] = k;
+            pos += __popcll(br);
+        }
+        for (int i0 = 0; i0 < n_spill; i0 += 64) {
+            const int i = i0 + lane;
+            const uint64_t k = i < n_spill ? spill[i] : 0ull;
+            const bool rest = k != 0ull && k < pivot;
+            const uint64_t br = __ballot(rest);
+            if (rest) c[pos + __popcll(br & lt_mask)] = k;
+            pos += __popcll(br);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t other = __shfl_xor(best_dropped, o);
+        best_dropped = best_dropped > other ? best_dropped : other;
+    }
+    if (lane == 0) {
         const float tau_in = tau[q];
         // bound[] starts at -inf; an overflow at ANY stage lost candidates for good -> sticky +inf:
         // nothing can be proven from the buffer, the query goes to the exact scan.
         float bnd = bound[q];
-        if (dense0_rows == 0 && emitted > RAG_CAND_CAP) bnd = INFINITY;
+        if (overflow) bnd = INFINITY;
         if (final_stage) {
             bnd = fmaxf(bnd, tau_in);
-            if (n_valid > m) bnd = fmaxf(bnd, key_score(s[m]));
+            if (n_valid > m) bnd = fmaxf(bnd, key_score(best_dropped));
             n_sorted[q] = n_valid;
         }
         bound[q] = bnd;
         cnt[q] = (unsigned)m;
         // the K'-th best score seen so far is a lower bound of the final K'-th best: safe emission threshold
-        tau[q] = (m == keep) ? fmaxf(key_score(s[keep - 1]), tau_in) : tau_in;
+        tau[q] = (m == keep) ? fmaxf(key_score(pivot), tau_in) : tau_in;
     }
 }
 
@@ -678,7 +724,7 @@ static double fp16_pass_eps(int dim_pad) {
 }
 
 static int shortlist_for(int k) {
-    int kp = std::max(64, (int)round_up(2 * k + 24, 32));
+    int kp = std::max(32, (int)round_up(2 * k + 8, 16));        // k=20 -> 48: gap to the 48th neighbour >> eps on typical data
     return std::min(kp, RAG_MAX_K);
 }
 
@@ -716,6 +762,8 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wide_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, RAG_CAND_CAP * 12));
         attr_set = true;
@@ -761,15 +809,15 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
             h->gemm_events_used++;
         }
         const bool last = end == total_tiles;
-        hipLaunchKernelGGL(select_kernel, dim3(Q), dim3(256), RAG_CAND_CAP * sizeof(uint64_t), st, h->cand, h->cnt, tau,
-                           h->bound, h->n_sorted, h->stats, stage == 0 ? stage0_tiles * RAG_TILE : 0, keep, last ? 1 : 0);
+        hipLaunchKernelGGL(select_kernel, dim3((Q + 3) / 4), dim3(256), SELECT_LDS_BYTES, st, h->cand, h->cnt, tau, h->bound,
+                           h->n_sorted, h->stats, Q, stage == 0 ? stage0_tiles * RAG_TILE : 0, keep, last ? 1 : 0);
         HIP_TRY(h, hipGetLastError());
         begin = end;
         ++stage;
     }
     if (total_tiles == 0) {   // empty index: nothing found
-        hipLaunchKernelGGL(select_kernel, dim3(Q), dim3(256), RAG_CAND_CAP * sizeof(uint64_t), st, h->cand, h->cnt, tau,
-                           h->bound, h->n_sorted, h->stats, 0, keep, 1);
+        hipLaunchKernelGGL(select_kernel, dim3((Q + 3) / 4), dim3(256), SELECT_LDS_BYTES, st, h->cand, h->cnt, tau, h->bound,
+                           h->n_sorted, h->stats, Q, 0, keep, 1);
     }
 
     hipLaunchKernelGGL(rescore_kernel, dim3((keep + 3) / 4, Q), dim3(256), 0, st, q_dev, h->emb32, h->cand, h->n_sorted,
