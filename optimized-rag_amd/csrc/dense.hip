@@ -264,22 +264,42 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
                 mx = fmaxf(mx, fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3])));
             if (__ballot(q_ok && mx * scale >= thr) == 0ull) continue;
         }
+        // Emission is aggregated per lane: count this lane's hits in the column block first, reserve that many slots
+        // with ONE returning atomic, then write. (One atomic per hit serialised a wave on the atomic round trip:
+        // 100 us on the 224-workgroup stage.)
+        if (DENSE0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float s = acc[i][j][r] * scale;
-                const int row = row0 + wm * 128 + i * 16 + fq * 4 + r;
-                if (q_ok && row < n_rows_valid && s >= thr) {
-                    if (tenants == nullptr || tenants[row] == tenant) {
-                        if (DENSE0) {
-                            cand[(size_t)q * RAG_CAND_CAP + row] = make_key(s, (uint32_t)row);
-                        } else {
-                            const unsigned slot = atomicAdd(&cnt[q], 1u);
-                            if (slot < RAG_CAND_CAP) cand[(size_t)q * RAG_CAND_CAP + slot] = make_key(s, (uint32_t)row);
-                        }
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + wm * 128 + i * 16 + fq * 4 + r;
+                    if (q_ok && row < n_rows_valid && (tenants == nullptr || tenants[row] == tenant))
+                        cand[(size_t)q * RAG_CAND_CAP + row] = make_key(acc[i][j][r] * scale, (uint32_t)row);
                 }
+        } else {
+            unsigned hits = 0u;                       // bit (i*4 + r) set = that accumulator is a candidate
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + wm * 128 + i * 16 + fq * 4 + r;
+                    const bool hit = q_ok && row < n_rows_valid && acc[i][j][r] * scale >= thr &&
+                                     (tenants == nullptr || tenants[row] == tenant);
+                    hits |= hit ? (1u << (i * 4 + r)) : 0u;
+                }
+            if (hits) {
+                const unsigned n_hit = __popc(hits);
+                unsigned slot = atomicAdd(&cnt[q], n_hit);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (hits & (1u << (i * 4 + r))) {
+                            const int row = row0 + wm * 128 + i * 16 + fq * 4 + r;
+                            if (slot < RAG_CAND_CAP)
+                                cand[(size_t)q * RAG_CAND_CAP + slot] = make_key(acc[i][j][r] * scale, (uint32_t)row);
+                            ++slot;
+                        }
             }
         }
     }
