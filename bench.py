@@ -65,10 +65,15 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000, help="total corpus rows (sharded over the ranks)")
     ap.add_argument("--queries", type=int, default=1024)
     ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--mode", default="dense", choices=["dense", "hybrid", "rerank"],
+                    help="dense = the headline metric (default); hybrid / rerank = BASELINE configs[2] / [3], single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-queries", type=int, default=128)
     args = ap.parse_args()
 
+    if args.mode != "dense":
+        from bench_modes import run_mode
+        return run_mode(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -1,0 +1,143 @@
+"""Secondary bench modes (not the driver's headline line): BASELINE.json configs[2] (hybrid: dense + BM25(CSR) + RRF)
+and configs[3] (cross-encoder rerank of the hybrid top-100). Single GPU. Prints one JSON line each.
+
+  python bench.py --mode hybrid  [--rows 1000000 --queries 1024]
+  python bench.py --mode rerank  [--queries 256]
+"""
+import json
+import time
+
+import numpy as np
+import torch
+
+DIM = 1536
+
+
+def synthetic_csr(n_docs, vocab, mean_len, seed=99):
+    """doc length ~ Poisson(mean_len), tokens Zipf(1.1) over `vocab` ids -> term-major CSR (docs ascending)."""
+    rng = np.random.default_rng(seed)
+    lens = rng.poisson(mean_len, n_docs).astype(np.int64)
+    total = int(lens.sum())
+    tok = (rng.zipf(1.1, total) - 1) % vocab
+    doc = np.repeat(np.arange(n_docs, dtype=np.int64), lens)
+    key = tok.astype(np.int64) * n_docs + doc
+    uk, tf = np.unique(key, return_counts=True)
+    term = (uk // n_docs).astype(np.int64)
+    d = (uk % n_docs).astype(np.int32)
+    indptr = np.zeros(vocab + 1, dtype=np.int64)
+    np.add.at(indptr, term + 1, 1)
+    indptr = np.cumsum(indptr)
+    return indptr, d, tf.astype(np.int32), lens.astype(np.int32), tok, np.concatenate([[0], np.cumsum(lens)])
+
+
+def timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def run_mode(args):
+    from optimized_rag_amd import RagEngine
+    from optimized_rag_amd.bm25 import Bm25Postings
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    eng = RagEngine(dim=DIM, device=0)
+    out = {"mode": args.mode, "n_gpus": 1, "data": "synthetic"}
+    if args.mode == "hybrid":
+        N, Q, k, pool = args.rows, args.queries, args.k, 100
+        g = torch.Generator(device=device)
+        g.manual_seed(1234)
+        corpus = torch.randn((N, DIM), generator=g, device=device)
+        corpus /= corpus.norm(dim=1, keepdim=True)
+        eng.index_load(corpus)
+        rows = torch.randint(0, N, (Q,), generator=torch.Generator().manual_seed(4321))
+        q = corpus[rows.to(device)] + torch.randn((Q, DIM), generator=g, device=device) * (0.5 / DIM ** 0.5)
+        q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+        del corpus
+        t0 = time.perf_counter()
+        indptr, d, tf, dl, tok, doc_ptr = synthetic_csr(N, 100_000, 120)
+        post = Bm25Postings(indptr, d, tf, dl, Bm25Postings.idf_table(np.diff(indptr).clip(min=0), N), float(dl.sum()) / N)
+        post.idf[np.diff(indptr) == 0] = 0.0
+        post.load(eng)
+        build_s = time.perf_counter() - t0
+        rng = np.random.default_rng(7)
+        ptr, terms = [0], []
+        for i in range(Q):                                   # 4-12 tokens sampled from a random doc
+            di = int(rng.integers(0, N))
+            toks = tok[doc_ptr[di]:doc_ptr[di + 1]]
+            n = int(rng.integers(4, 13))
+            terms.extend(int(x) for x in (rng.choice(toks, n) if len(toks) else [0] * n))
+            ptr.append(len(terms))
+        ptr, terms = np.asarray(ptr, np.int32), np.asarray(terms, np.int32)
+        ids_d = torch.empty((Q, pool), dtype=torch.int64, device=device)
+        rows_d = torch.empty((Q, pool), dtype=torch.int32, device=device)
+        sc_d = torch.empty((Q, pool), dtype=torch.float64, device=device)
+        res = {}
+
+        def dense():
+            eng.dense_topk_dev(q, pool, ids_d, rows_d, sc_d)
+
+        def bm25():
+            res["bm25"] = eng.bm25_topk(ptr, terms, pool)
+
+        def fuse():
+            lists = np.stack([res["dense_ids"], res["bm25"][0]], axis=1)
+            res["fused"] = eng.rrf_fuse(lists, rrf_k=60, top_k=k)
+
+        t_dense = timed(dense, args.steps, args.warmup)
+        res["dense_ids"] = ids_d.cpu().numpy()
+        t_bm25 = timed(bm25, max(2, args.steps // 4), 1)
+        t_fuse = timed(fuse, args.steps, 1)
+        nnz_touched = float(sum(int(indptr[t + 1] - indptr[t]) for t in terms if t >= 0))
+        total = t_dense + t_bm25 + t_fuse
+        out.update({
+            "metric": "queries/sec (hybrid: dense top-100 + BM25 top-100 + RRF -> top-20)", "value": round(Q / total, 1),
+            "unit": "queries/sec", "ms_per_step": round(total * 1e3, 3), "higher_is_better": True,
+            "config": {"workload": f"{N} docs hybrid: dense + BM25(CSR, nnz={int(indptr[-1])}) + RRF(k=60), pool=100, top-k={k}, "
+                                   f"batch={Q} (BASELINE.json configs[2])"},
+            "stages_ms": {"dense_top100_dev": round(t_dense * 1e3, 3), "bm25_top100_host_api": round(t_bm25 * 1e3, 3),
+                          "rrf_fuse_host_api": round(t_fuse * 1e3, 3)},
+            "bm25": {"postings_touched_per_batch": nnz_touched,
+                     "algorithmic_GBs": round(nnz_touched * 12 / t_bm25 / 1e9, 1), "index_build_s": round(build_s, 1)},
+            "note": "bm25/rrf entry points take host pointers: their times include H2D/D2H of terms and results",
+        })
+    else:
+        from oracle import bert_oracle as B          # weights only (seeded); the forward measured here is the HIP one
+        from optimized_rag_amd.cross_encoder import flatten_state_dict
+        cfg = B.minilm_config()
+        eng.ce_load(cfg, flatten_state_dict(B.seeded_weights(cfg, 2024), cfg["layers"]))
+        Q, pool, L = min(args.queries, 256), 100, 256
+        P = Q * pool
+        rng = np.random.default_rng(5)
+        lens = (16 + 2 + rng.integers(96, 225, P)).astype(np.int32).clip(max=L)
+        ids = rng.integers(1000, cfg["vocab_size"], (P, L)).astype(np.int32)
+        tt = (np.arange(L)[None, :] >= 18).astype(np.int32).repeat(P, 0)
+        ids_d = torch.from_numpy(ids).to(device)
+        tt_d = torch.from_numpy(tt).to(device)
+        lens_d = torch.from_numpy(lens).to(device)
+        out_d = torch.empty((P,), dtype=torch.float32, device=device)
+        import ctypes as C
+
+        def fwd():
+            eng._check(eng.lib.rag_ce_score_dev(eng.h, C.c_void_p(ids_d.data_ptr()), C.c_void_p(tt_d.data_ptr()),
+                                                C.c_void_p(lens_d.data_ptr()), P, L, C.c_void_p(out_d.data_ptr()),
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rag_ce_score_dev")
+
+        t = timed(fwd, max(1, args.steps // 10), 1)
+        flops = P * 6.0 * L * (3.539e6 + 1536.0 * L)            # SURVEY §8d per-pair formula
+        out.update({
+            "metric": "queries/sec (cross-encoder rerank of 100 candidates, L=256)", "value": round(Q / t, 2),
+            "unit": "queries/sec", "ms_per_step": round(t * 1e3, 2), "higher_is_better": True,
+            "config": {"workload": f"{Q} queries x {pool} pairs x L={L} tokens, ms-marco-MiniLM-L-6 shape, seeded weights "
+                                   f"(BASELINE.json configs[3])"},
+            "pairs_per_sec": round(P / t, 1),
+            "roofline": {"bound": "mfma", "achieved": round(flops / t / 1e12, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(flops / t / 1e12 / 2500.0, 4),
+                         "note": "algorithmic fp16 FLOPs; the split-fp16 path issues 3 MFMAs per product"},
+        })
+    print(json.dumps(out))

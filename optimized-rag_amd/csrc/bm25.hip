@@ -4,6 +4,8 @@
 // HBM-bound integer/gather work, not a GEMM:
 //   load   : per-posting weight w = tf*(k1+1) / (tf + k1*(1 - b + b*dl/avgdl)) precomputed once in float64 with
 //            rank-bm25's operation order -> postings are (doc int32, w float64): 12 B each, no doc_len gather later.
+//            A per-term range table (first posting of each 16384-doc range, built once on the GPU) replaces the
+//            two 20-step dependent binary searches per (block, token) that dominated the first version (36 ms/batch).
 //   score  : one workgroup per (query, 16384-doc range). The range's float64 accumulators live in LDS (128 KiB);
 //            for each query token IN ORDER the block binary-searches the term's posting list for its doc range and
 //            adds idf*w (docs are unique inside one posting list -> no atomics, and per-document summation order
@@ -16,6 +18,11 @@
 #define BM_RANGE 16384
 #define BM_THREADS 512
 #define BM_SEG (BM_RANGE / BM_THREADS)      // 32 contiguous docs per thread
+// accumulator i lives at LDS double i + i/32: a thread's 32 contiguous docs then start one bank-pair further than its
+// neighbour's, so the per-thread segment reads are conflict-free (unpadded: every lane on the same bank, 32-way)
+#define SC_IDX(i) ((i) + ((i) >> 5))
+#define BM_SC_DOUBLES (BM_RANGE + BM_RANGE / 32)
+#define BM_LDS_BYTES (BM_SC_DOUBLES * 8 + 4096)
 
 struct rag_bm25_index {
     int64_t n_docs = 0, n_terms = 0, nnz = 0;
@@ -23,6 +30,8 @@ struct rag_bm25_index {
     int32_t* doc = nullptr;
     double* w = nullptr;
     double* idf = nullptr;
+    int32_t* range_off = nullptr;      // [n_terms][n_ranges+1]: first posting of term t with doc >= r*BM_RANGE (rel. to indptr[t])
+    int n_ranges = 0;
     double avgdl = 0, k1 = 1.5, b = 0.75;
 };
 
@@ -49,49 +58,100 @@ __device__ __forceinline__ int64_t lower_bound_doc(const int32_t* __restrict__ d
     return lo;
 }
 
+__global__ void bm25_range_table_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ doc, int64_t n_terms,
+                                        int n_ranges, int32_t* __restrict__ range_off) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = n_terms * (int64_t)(n_ranges + 1);
+    if (i >= total) return;
+    const int64_t t = i / (n_ranges + 1);
+    const int r = (int)(i % (n_ranges + 1));
+    const int64_t lo = indptr[t], hi = indptr[t + 1];
+    const int64_t target = (int64_t)r * BM_RANGE;
+    range_off[i] = target > 0x7fffffff ? (int32_t)(hi - lo) : (int32_t)(lower_bound_doc(doc, lo, hi, (int)target) - lo);
+}
+
 // mode 0: per-range top-k partials; mode 1: dense scores out[q][doc]
 __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ doc,
                                                                  const double* __restrict__ w, const double* __restrict__ idf,
+                                                                 const int32_t* __restrict__ range_off, int n_ranges,
                                                                  const int32_t* __restrict__ term_ptr, const int32_t* __restrict__ terms,
                                                                  int64_t n_docs, int64_t n_terms, int k, int mode,
                                                                  double* __restrict__ dense_out, uint64_t* __restrict__ part_key,
                                                                  uint32_t* __restrict__ part_row) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sc = reinterpret_cast<double*>(smem);                       // [BM_RANGE]
-    int* hist = reinterpret_cast<int*>(smem + BM_RANGE * 8);            // [256]
+    int* hist = reinterpret_cast<int*>(smem + BM_SC_DOUBLES * 8);       // [256]
     int* wsum = hist + 256;                                             // [16] scratch
     const int q = blockIdx.y, r = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int64_t base = (int64_t)r * BM_RANGE;
     const int lim = (int)min((int64_t)BM_RANGE, n_docs - base);
-    for (int i = tid; i < BM_RANGE; i += BM_THREADS) sc[i] = 0.0;
+    for (int i = tid; i < BM_SC_DOUBLES; i += BM_THREADS) sc[i] = 0.0;
     __syncthreads();
+    // per-token metadata (idf, posting sub-range of this doc range) is fetched for up to 64 tokens IN PARALLEL into
+    // LDS first: fetched inside the token loop it was ~4 dependent global round trips per token per block.
+    double* m_idf = reinterpret_cast<double*>(wsum + 16);              // [64]
+    int64_t* m_a = reinterpret_cast<int64_t*>(m_idf + 64);             // [64]
+    int* m_n = reinterpret_cast<int*>(m_a + 64);                       // [64]
     const int t0 = term_ptr[q], t1 = term_ptr[q + 1];
-    for (int ti = t0; ti < t1; ++ti) {
-        const int t = terms[ti];
-        if (t < 0 || t >= n_terms) continue;                 // out-of-vocabulary token: idf.get(q) is None -> 0
-        const double f = idf[t];
-        if (f == 0.0) continue;                              // (idf or 0) * x == 0: adds nothing
-        const int64_t lo = indptr[t], hi = indptr[t + 1];
-        const int64_t a = lower_bound_doc(doc, lo, hi, (int)base);
-        const int64_t e = lower_bound_doc(doc, a, hi, (int)(base + lim));
-        for (int64_t p = a + tid; p < e; p += BM_THREADS) sc[doc[p] - (int)base] += f * w[p];
+    for (int tb = t0; tb < t1; tb += 64) {
+        const int nb = min(64, t1 - tb);
+        if (tid < nb) {
+            const int t = terms[tb + tid];
+            double f = 0.0;
+            int64_t a = 0;
+            int n = 0;
+            if (t >= 0 && t < n_terms) {                     // out-of-vocabulary token: idf.get(q) is None -> 0
+                f = idf[t];
+                const int32_t* ro = range_off + (size_t)t * (n_ranges + 1) + r;
+                a = indptr[t] + ro[0];
+                n = ro[1] - ro[0];
+            }
+            m_idf[tid] = f;
+            m_a[tid] = a;
+            m_n[tid] = f == 0.0 ? 0 : n;                     // (idf or 0) * x == 0: adds nothing
+        }
         __syncthreads();
+        for (int ti = 0; ti < nb; ++ti) {
+            const int n = m_n[ti];
+            if (n == 0) continue;
+            const double f = m_idf[ti];
+            const int64_t a = m_a[ti];
+            // docs are unique inside one posting list: exactly one add per accumulator per token, so a no-return LDS
+            // atomic (ds_add_f64) gives the same float64 result as load-add-store without the dependent round trip
+            const int32_t* dp = doc + a;
+            const double* wp = w + a;
+            int p = tid;
+            for (; p + 3 * BM_THREADS < n; p += 4 * BM_THREADS) {        // 4 independent loads in flight per thread
+                const int d0 = dp[p], d1 = dp[p + BM_THREADS], d2 = dp[p + 2 * BM_THREADS], d3 = dp[p + 3 * BM_THREADS];
+                const double w0 = wp[p], w1 = wp[p + BM_THREADS], w2 = wp[p + 2 * BM_THREADS], w3 = wp[p + 3 * BM_THREADS];
+                __hip_atomic_fetch_add(&sc[SC_IDX(d0 - (int)base)], f * w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&sc[SC_IDX(d1 - (int)base)], f * w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&sc[SC_IDX(d2 - (int)base)], f * w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&sc[SC_IDX(d3 - (int)base)], f * w3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            for (; p < n; p += BM_THREADS)
+                __hip_atomic_fetch_add(&sc[SC_IDX(dp[p] - (int)base)], f * wp[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __syncthreads();                                 // token order = per-document summation order
+        }
     }
     if (mode == 1) {
-        for (int i = tid; i < lim; i += BM_THREADS) dense_out[(size_t)q * n_docs + base + i] = sc[i];
+        for (int i = tid; i < lim; i += BM_THREADS) dense_out[(size_t)q * n_docs + base + i] = sc[SC_IDX(i)];
         return;
     }
     // ---- exact top-k of sc[0..lim): radix select of the k-th largest key, ties by lower doc ------------
     const size_t po = ((size_t)q * gridDim.x + r) * k;
     if (lim <= k) {
         for (int i = tid; i < k; i += BM_THREADS) {
-            part_key[po + i] = i < lim ? f64_orderable(sc[i]) : 0ull;
+            part_key[po + i] = i < lim ? f64_orderable(sc[SC_IDX(i)]) : 0ull;
             part_row[po + i] = (uint32_t)(base + i);
         }
         return;
     }
     const int seg0 = tid * BM_SEG;
+    uint64_t keys[BM_SEG];           // this thread's 32 docs, read once (conflict-free thanks to the padding)
+#pragma unroll
+    for (int j = 0; j < BM_SEG; ++j) keys[j] = (seg0 + j) < lim ? f64_orderable(sc[SC_IDX(seg0 + j)]) : 0ull;
     uint64_t prefix = 0ull;          // matched high bytes of the pivot
     int remaining = k;               // the pivot is the `remaining`-th largest among keys matching `prefix`
     for (int pass = 0; pass < 8; ++pass) {
@@ -99,11 +159,11 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         int cur = -1, run = 0;
+#pragma unroll
         for (int j = 0; j < BM_SEG; ++j) {
             const int i = seg0 + j;
-            if (i >= lim) break;
-            const uint64_t key = f64_orderable(sc[i]);
-            const bool match = pass == 0 || (key >> (shift + 8)) == prefix;
+            const uint64_t key = keys[j];
+            const bool match = i < lim && (pass == 0 || (key >> (shift + 8)) == prefix);
             if (!match) continue;
             const int d = (int)((key >> shift) & 0xFF);
             if (d == cur) { ++run; } else {
@@ -143,12 +203,11 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
     const int need_ties = remaining;                    // how many keys == pivot belong to the top-k (lowest docs first)
     // ordered collection: every key > pivot, plus the first `need_ties` keys == pivot in doc order
     int n_gt = 0, n_eq = 0;
+#pragma unroll
     for (int j = 0; j < BM_SEG; ++j) {
-        const int i = seg0 + j;
-        if (i >= lim) break;
-        const uint64_t key = f64_orderable(sc[i]);
-        n_gt += key > pivot;
-        n_eq += key == pivot;
+        const bool in = (seg0 + j) < lim;
+        n_gt += in && keys[j] > pivot;
+        n_eq += in && keys[j] == pivot;
     }
     // block exclusive scans of n_gt and n_eq (thread order == doc order)
     int s_gt = n_gt, s_eq = n_eq;
@@ -164,10 +223,11 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
         if (u < wv) { off_gt += hist[u]; off_eq += hist[16 + u]; }
         total_gt += hist[u];
     }
+#pragma unroll
     for (int j = 0; j < BM_SEG; ++j) {
         const int i = seg0 + j;
-        if (i >= lim) break;
-        const uint64_t key = f64_orderable(sc[i]);
+        if (i >= lim) continue;
+        const uint64_t key = keys[j];
         if (key > pivot) {
             part_key[po + off_gt] = key;
             part_row[po + off_gt] = (uint32_t)(base + i);
@@ -249,7 +309,7 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(const uint64_t* __restr
 // ------------------------------------------------------------------------------------------------
 void bm25_free(rag_ctx* h) {
     if (!h->bm25) return;
-    hipFree(h->bm25->indptr); hipFree(h->bm25->doc); hipFree(h->bm25->w); hipFree(h->bm25->idf);
+    hipFree(h->bm25->indptr); hipFree(h->bm25->doc); hipFree(h->bm25->w); hipFree(h->bm25->idf); hipFree(h->bm25->range_off);
     delete h->bm25;
     h->bm25 = nullptr;
 }
@@ -284,6 +344,14 @@ int bm25_load_host(rag_ctx* h, const int64_t* indptr, const int32_t* doc, const 
                            dld, nnz, avgdl, k1, b, ix->w);
         HIP_TRY(h, hipGetLastError());
     }
+    ix->n_ranges = (int)((n_docs + BM_RANGE - 1) / BM_RANGE);
+    const int64_t n_tab = n_terms * (int64_t)(ix->n_ranges + 1);
+    HIP_TRY(h, hipMalloc(&ix->range_off, std::max<size_t>(1, (size_t)n_tab) * sizeof(int32_t)));
+    if (n_tab) {
+        hipLaunchKernelGGL(bm25_range_table_kernel, dim3((unsigned)((n_tab + 255) / 256)), dim3(256), 0, st, ix->indptr, ix->doc,
+                           n_terms, ix->n_ranges, ix->range_off);
+        HIP_TRY(h, hipGetLastError());
+    }
     HIP_TRY(h, hipStreamSynchronize(st));
     hipFree(tfd); hipFree(dld);
     return RAG_OK;
@@ -302,7 +370,7 @@ static int bm25_run(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, i
     static bool attr = false;
     if (!attr) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bm25_range_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, BM_RANGE * 8 + 2048));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, BM_LDS_BYTES));
         attr = true;
     }
     int32_t *tp = nullptr, *tm = nullptr;
@@ -326,8 +394,8 @@ static int bm25_run(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, i
         if (e == hipSuccess) e = hipMalloc(&dd, (size_t)Q * ix->n_docs * sizeof(double));
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(bm25_range_kernel, dim3(n_ranges, Q), dim3(BM_THREADS), BM_RANGE * 8 + 2048, st, ix->indptr, ix->doc,
-                           ix->w, ix->idf, tp, tm, ix->n_docs, ix->n_terms, k, mode, dd, pk, pr);
+        hipLaunchKernelGGL(bm25_range_kernel, dim3(n_ranges, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc,
+                           ix->w, ix->idf, ix->range_off, ix->n_ranges, tp, tm, ix->n_docs, ix->n_terms, k, mode, dd, pk, pr);
         if (mode == 0)
             hipLaunchKernelGGL(bm25_merge_kernel, dim3(Q), dim3(256), 0, st, pk, pr, n_ranges, k, idd, rwd, scd, mxd);
         e = hipGetLastError();
