@@ -161,10 +161,18 @@ def main():
     achieved_tflops = flops_per_step * args.steps / (gemm_ms * 1e-3) / 1e12
     bytes_per_step = (n_local - stage0_rows) * dim_pad * 2.0 + launches_per_step * qpad * dim_pad * 2.0
     achieved_gbs = bytes_per_step * args.steps / (gemm_ms * 1e-3) / 1e9
+    # HBM traffic per launch: from the committed rocprofv3 --pmc passes of this same command (profiles/), which
+    # cannot be collected from inside the timed run. FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950).
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_c_dense_pmc.json")
+    if world == 1 and args.rows == 1_000_000 and Q == 1024 and os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            traffic = json.load(f)["kernels"]["dense_emit_kernel<false>"]["hbm_traffic_bytes_per_launch"]["total"]
     roofline = {
         "bound": "mfma", "kernel": "dense_emit_kernel<false>", "achieved": round(achieved_tflops, 2),
         "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_MFMA_TFLOPS, 4),
-        "traffic": None,
+        "traffic": traffic, "traffic_source": "profiles/r01_c_dense_pmc.json (bytes per launch; algorithmic: "
+        f"{bytes_per_step / launches_per_step:.4g})" if traffic else None,
         "launches_per_step": launches_per_step, "avg_launch_ms": round(avg_launch_ms, 4),
         "algorithmic_flops_per_launch": flops_per_step / launches_per_step,
         "hbm_view": {"algorithmic_bytes_per_step": bytes_per_step, "achieved_GBs": round(achieved_gbs, 1),

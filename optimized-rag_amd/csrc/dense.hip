@@ -97,23 +97,25 @@ __device__ __forceinline__ void load_fragB(FragB& f, const char* base, const int
         for (int j = 0; j < 2; ++j) f.v[kk][j] = *reinterpret_cast<const half8*>(base + j * 16 * 128 + off_k[kk]);
 }
 
-// Pipeline. Per 64-deep K-step t (LDS stage t & 1) a wave's 128x64 output is 2 M-subs x 2 N-subs = 4 phases of 16
-// MFMAs: p1 (A0,B0)  p2 (A1,B0)  p3 (A1,B1)  p4 (A0,B1)   (A0/A1 = 64-row sub-blocks of the wave's OWN corpus half,
-// B0/B1 = 32-query sub-blocks of its own query half). Every phase is an I-part (LDS fragment reads + one half-tile
-// LDS-DMA issue, then lgkmcnt(0)) and an M-part (16 MFMAs), each closed by s_barrier. The two waves that share a
-// SIMD (wave w and w+4, i.e. wm = 0 / 1) run HALF A PHASE APART (waves 4-7 take one extra barrier up front, waves
-// 0-3 one at the end): while one wave's MFMAs own the matrix pipe its partner reads fragments and issues DMA.
-//   reads : I1: A0(t) -> ax    I2: A1(t) -> ay    I3: B1(t) -> by    I4: B0(t+1) -> bx
-//   DMA   : I1: Bh0(t+1)       I2: Bh1(t+1)       I3: Ah0(t+2)       I4: Ah1(t+2)       (h0/h1 = 128-row half-tiles)
-//   slot lifetimes (stage t&1): corpus halves are read in I1,I2 of step t  -> refilled from I3(t)   (WAR ok)
-//                               query  halves are read in I4(t-1), I3(t)   -> refilled from I1(t+1) (WAR ok)
-//           a DMA is always issued in a LATER phase than the slot's last read, reads retire (lgkmcnt(0)) before the
-//           barrier closing their part, and the lagging group is only half a phase behind, so it has retired too.
-//   RAW   : one counted wait per step, s_waitcnt vmcnt(2) in the barrier interval before the leading group's I4:
-//           waves 0-3 at the end of their M3, waves 4-7 at the end of their I3. In-order retirement then guarantees
-//           B(t+1) (issued I1,I2 of t) and A(t+1) (issued I3,I4 of t-1: 4 and 3 phases ahead, the HBM-latency
-//           operand) have landed; only Ah0(t+2) stays in flight. DMA never drains to 0 inside the loop; source
-//           steps past the end are clamped (harmless re-loads) so the count stays exact.
+// Pipeline. Per 64-deep K-step t (LDS stage t & 1) a wave's 128x64 output is 2 M-subs x 2 N-subs (A0/A1 = 64-row
+// sub-blocks of the wave's OWN corpus half, B0/B1 = 32-query sub-blocks of its own query half), done as TWO phases
+// of 32 MFMAs: pA = (A0,B0),(A1,B0)   pB = (A1,B1),(A0,B1). Every phase is an I-part (LDS fragment reads + two
+// half-tile LDS-DMA issues, then lgkmcnt(0)) and an M-part (32 MFMAs), each closed by s_barrier. The two waves that
+// share a SIMD (wave w and w+4, i.e. wm = 0 / 1) run HALF A PHASE APART (waves 4-7 take one extra barrier up front,
+// waves 0-3 one at the end): while one wave's MFMAs own the matrix pipe its partner reads fragments and issues DMA.
+// (History, measured with tools/gemm_probe.hip: lock-step 4x16-MFMA phases 1131 TFLOP/s, staggered 4x16 1196;
+// a barrier interval costs ~150 cycles beyond its 16 MFMAs = 256 cycles, hence 32-MFMA parts.)
+//   reads : IA: A0(t) -> ax, A1(t) -> ay, B0(t) -> bx        IB: B1(t) -> by
+//   DMA   : IA: Bh0(t+1), Bh1(t+1)                           IB: Ah0(t+2), Ah1(t+2)     (h0/h1 = 128-row half-tiles)
+//   slot lifetimes (stage t&1): corpus halves are read in IA(t) only        -> refilled from IB(t)     (WAR ok)
+//                               query  halves are read in IA(t) and IB(t)   -> refilled from IA(t+1)   (WAR ok)
+//           a DMA is always issued in a LATER part than the slot's last read, reads retire (lgkmcnt(0)) before the
+//           barrier closing their part, and the lagging group is only one barrier interval behind.
+//   RAW   : one counted wait per step, s_waitcnt vmcnt(4) in the barrier interval before the leading group's
+//           IA(t+1): waves 0-3 at the end of their MB(t), waves 4-7 at the end of their IB(t). In-order retirement
+//           then guarantees A(t+1) (issued IB(t-1): three parts ahead, the HBM-latency operand) and B(t+1) (issued
+//           IA(t)) have landed; only A(t+2) stays in flight. DMA never drains to 0 inside the loop; source steps
+//           past the end are clamped (harmless re-loads) so the count stays exact.
 #define MFMA_QUAD(FA, FB, SA, SB)                                                                           \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
@@ -138,9 +140,9 @@ __device__ __forceinline__ void load_fragB(FragB& f, const char* base, const int
 #endif
 
 #ifdef PROBE_NOWAIT      // timing experiment only (tools/gemm_probe.hip): results are wrong without the wait
-#define DMA_WAIT asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define DMA_WAIT asm volatile("s_waitcnt vmcnt(12)" ::: "memory")
 #else
-#define DMA_WAIT asm volatile("s_waitcnt vmcnt(2)" ::: "memory")
+#define DMA_WAIT asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
 #endif
 #define BARRIER                                                                                             \
     __builtin_amdgcn_s_barrier();                                                                           \
@@ -153,9 +155,10 @@ __device__ __forceinline__ void load_fragB(FragB& f, const char* base, const int
     STAMP(1)                                                                                                \
     BARRIER                                                                                                 \
     STAMP(2)
-#define M_PART(FA, FB, SA, SB, WAIT)                                                                        \
+#define M_PART(FA0, FB0, SA0, SB0, FA1, FB1, SA1, SB1, WAIT)                                               \
     __builtin_amdgcn_s_setprio(1);                                                                          \
-    MFMA_QUAD(FA, FB, SA, SB)                                                                               \
+    MFMA_QUAD(FA0, FB0, SA0, SB0)                                                                           \
+    MFMA_QUAD(FA1, FB1, SA1, SB1)                                                                           \
     __builtin_amdgcn_s_setprio(0);                                                                          \
     STAMP(3)                                                                                                \
     if ((WAIT) && !lag) DMA_WAIT;                                                                           \
@@ -230,18 +233,20 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
     BARRIER
     FragA ax, ay;
     FragB bx, by;
-    load_fragB(bx, LDS_B(0, 0), off_k);                      // B0(0) (normally read in I4 of the previous step)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef DENSE_STAMP
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
     if (lag) { BARRIER }
 
     for (int t = 0; t < nt; ++t) {
-        load_fragA(ax, LDS_A(0, t), off_k);      STAGE_B(0, t + 1);   I_END(0)   M_PART(ax, bx, 0, 0, 0)
-        load_fragA(ay, LDS_A(1, t), off_k);      STAGE_B(1, t + 1);   I_END(0)   M_PART(ay, bx, 1, 0, 0)
-        load_fragB(by, LDS_B(1, t), off_k);      STAGE_A(0, t + 2);   I_END(1)   M_PART(ay, by, 1, 1, 1)
-        load_fragB(bx, LDS_B(0, t + 1), off_k);  STAGE_A(1, t + 2);   I_END(0)   M_PART(ax, by, 0, 1, 0)
+        load_fragA(ax, LDS_A(0, t), off_k);  load_fragA(ay, LDS_A(1, t), off_k);  load_fragB(bx, LDS_B(0, t), off_k);
+        STAGE_B(0, t + 1);  STAGE_B(1, t + 1);
+        I_END(0)
+        M_PART(ax, bx, 0, 0, ay, bx, 1, 0, 0)
+        load_fragB(by, LDS_B(1, t), off_k);
+        STAGE_A(0, t + 2);  STAGE_A(1, t + 2);
+        I_END(1)
+        M_PART(ay, by, 1, 1, ax, by, 0, 1, 1)
     }
     if (!lag) { BARRIER }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // clamped tail re-loads still in flight: retire them

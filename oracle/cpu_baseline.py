@@ -12,10 +12,22 @@ import time
 import numpy as np
 
 
+def effective_cores():
+    """CPU threads this process may really use: min(affinity mask, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def dense_topk_blas(corpus_unit, queries_unit, k, threads=None):
     """corpus_unit [N,D] float32 unit rows (torch CPU tensor), queries_unit [Q,D]. Returns (idx [Q,k], seconds)."""
     import torch
-    threads = threads or len(os.sched_getaffinity(0))
+    threads = threads or effective_cores()
     torch.set_num_threads(threads)
     t0 = time.perf_counter()
     s = queries_unit @ corpus_unit.T                        # [Q,N] float32, BLAS on all cores
