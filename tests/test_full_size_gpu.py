@@ -1,0 +1,90 @@
+"""BASELINE.json configs[1] at FULL size (1M x 1536-d, 1024 queries, top-20) through size-independent properties:
+planted neighbours, shard-merge invariance, proof counters, ordering, and a float64 spot check of a query subset."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, D, Q, K = 1_000_000, 1536, 1024, 20
+
+
+@pytest.fixture(scope="module")
+def world():
+    import torch
+    from optimized_rag_amd import RagEngine
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    corpus = torch.randn((N, D), generator=g, device=dev)
+    corpus *= (0.5 + torch.rand((N, 1), generator=g, device=dev))            # un-normalised rows
+    rows = torch.randint(0, N, (Q,), generator=torch.Generator().manual_seed(3))
+    q = corpus[rows.to(dev)] * 0.37 + torch.randn((Q, D), generator=g, device=dev) * 0.3
+    q[5] = corpus[rows[5]]                                                     # exact copy of a row: cosine 1.0
+    whole = RagEngine(dim=D, device=0)
+    whole.index_load(corpus)
+    yield dict(torch=torch, dev=dev, corpus=corpus, q=q.contiguous(), rows=rows, whole=whole, RagEngine=RagEngine)
+    whole.close()
+
+
+def search(torch, eng, q, k):
+    ids = torch.empty((q.shape[0], k), dtype=torch.int64, device=q.device)
+    rows = torch.empty((q.shape[0], k), dtype=torch.int32, device=q.device)
+    sc = torch.empty((q.shape[0], k), dtype=torch.float64, device=q.device)
+    eng.dense_topk_dev(q, k, ids, rows, sc)
+    torch.cuda.synchronize()
+    return ids, sc
+
+
+def test_planted_neighbours_order_and_proof(world):
+    torch = world["torch"]
+    ids, sc = search(torch, world["whole"], world["q"], K)
+    ids_h, sc_h = ids.cpu().numpy(), sc.cpu().numpy()
+    assert (ids_h[:, 0] == world["rows"].numpy()).all()                      # the planted row is the nearest neighbour
+    assert abs(sc_h[5, 0] - 1.0) < 1e-12                                      # identical vector: cosine exactly ~1
+    assert (np.diff(sc_h, axis=1) <= 0).all()                                 # sorted by cosine, descending
+    assert (ids_h >= 0).all() and all(len(set(r)) == K for r in ids_h)        # k distinct rows
+    st = world["whole"].dense_stats()
+    assert st["proven_fast"] + st["proven_wide"] + st["exact_scan"] == Q and st["overflowed"] == 0
+    world["ids"], world["sc"] = ids, sc
+
+
+def test_shard_merge_invariance(world):
+    """search(whole corpus) == merge(search(first 437,000 rows), search(the rest)): bit-identical ids and scores."""
+    torch = world["torch"]
+    cut = 437_000
+    parts = []
+    for lo, hi in ((0, cut), (cut, N)):
+        e = world["RagEngine"](dim=D, device=0)
+        e.index_load(world["corpus"][lo:hi].contiguous(), id_base=lo)
+        parts.append(search(torch, e, world["q"], K))
+        e.close()
+    ids = torch.stack([p[0] for p in parts]).contiguous()
+    sc = torch.stack([p[1] for p in parts]).contiguous()
+    out_i = torch.empty((Q, K), dtype=torch.int64, device=world["dev"])
+    out_s = torch.empty((Q, K), dtype=torch.float64, device=world["dev"])
+    world["whole"].merge_topk_dev(ids, sc, out_i, out_s)
+    torch.cuda.synchronize()
+    if "ids" not in world:
+        world["ids"], world["sc"] = search(torch, world["whole"], world["q"], K)
+    assert torch.equal(out_i, world["ids"])
+    assert torch.equal(out_s, world["sc"])                                     # same float64 kernel, same rows: identical bits
+
+
+def test_float64_spot_check_of_a_query_subset(world):
+    """8 queries: float32 BLAS shortlist of 200 on the host, re-scored in float64 = the oracle's exact top-20."""
+    torch = world["torch"]
+    from oracle import rag_oracle as O
+    sel = [0, 5, 17, 300, 511, 512, 800, 1023]
+    hc = world["corpus"].cpu().numpy()
+    hq = world["q"][sel].cpu().numpy()
+    unit = hc / np.linalg.norm(hc, axis=1, keepdims=True)
+    s32 = (hq / np.linalg.norm(hq, axis=1, keepdims=True)) @ unit.T
+    if "ids" not in world:
+        world["ids"], world["sc"] = search(torch, world["whole"], world["q"], K)
+    got_i, got_s = world["ids"].cpu().numpy(), world["sc"].cpu().numpy()
+    for j, qi in enumerate(sel):
+        short = np.argpartition(-s32[j], 200)[:200]
+        exact = O.cosine_matrix(hq[j:j + 1], hc[short])[0]
+        order = np.lexsort((short, -exact))[:K]
+        np.testing.assert_array_equal(got_i[qi], short[order])
+        np.testing.assert_allclose(got_s[qi], exact[order], atol=1e-9)
