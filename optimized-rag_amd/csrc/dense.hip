@@ -257,56 +257,77 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
 
     // ---- epilogue: C layout col = lane&15 (query), row = (lane>>4)*4 + reg (corpus row) ----------
     const float scale = 1.0f / (float)(1 << (2 * RAG_SCALE_LOG2));
+    if (DENSE0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + wn * 64 + j * 16 + fr;
+            if (q >= q_valid) continue;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + wm * 128 + i * 16 + fq * 4 + r;
+                    if (row < n_rows_valid && (tenants == nullptr || tenants[row] == tenant))
+                        cand[(size_t)q * RAG_CAND_CAP + row] = make_key(acc[i][j][r] * scale, (uint32_t)row);
+                }
+        }
+        return;
+    }
+    // Thresholded emission, aggregated per lane:
+    //  (1) per column block: max of the lane's 32 scores against the threshold (cheap reject, ~45 % of blocks have
+    //      no hit at all), hit mask only for lanes that have one;
+    //  (2) rare fix-ups (rows past the end of the corpus in the last tile, tenant filter) in a rolled loop over set bits;
+    //  (3) ONE returning atomic per (lane, column block), all four issued before any result is consumed;
+    //  (4) key stores. The compare is done on raw accumulators against tau * 2^14 (exact: power-of-two scale).
+    unsigned hits[4], slot[4];
+    const bool fixups = (row0 + RAG_TILE > n_rows_valid) || (tenants != nullptr);       // block-uniform
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int q = q0 + wn * 64 + j * 16 + fr;
-        const bool q_ok = q < q_valid;
-        float thr = DENSE0 ? -INFINITY : (q_ok ? tau[q] : INFINITY);
-        if (!DENSE0) {
-            float mx = -INFINITY;
+        const float thr = (q < q_valid ? tau[q] : INFINITY) * (float)(1 << (2 * RAG_SCALE_LOG2));
+        float mx = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                mx = fmaxf(mx, fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3])));
-            if (__ballot(q_ok && mx * scale >= thr) == 0ull) continue;
-        }
-        // Emission is aggregated per lane: count this lane's hits in the column block first, reserve that many slots
-        // with ONE returning atomic, then write. (One atomic per hit serialised a wave on the atomic round trip:
-        // 100 us on the 224-workgroup stage.)
-        if (DENSE0) {
+        for (int i = 0; i < 8; ++i)
+            mx = fmaxf(mx, fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3])));
+        unsigned h = 0u;
+        if (mx >= thr) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = row0 + wm * 128 + i * 16 + fq * 4 + r;
-                    if (q_ok && row < n_rows_valid && (tenants == nullptr || tenants[row] == tenant))
-                        cand[(size_t)q * RAG_CAND_CAP + row] = make_key(acc[i][j][r] * scale, (uint32_t)row);
+                for (int r = 0; r < 4; ++r) h |= (acc[i][j][r] >= thr) ? (1u << (i * 4 + r)) : 0u;
+            if (fixups) {
+                unsigned rem = h;
+#pragma unroll 1
+                while (rem) {
+                    const int bit = __ffs(rem) - 1;
+                    rem &= rem - 1;
+                    const int row = row0 + wm * 128 + (bit >> 2) * 16 + fq * 4 + (bit & 3);
+                    if (row >= n_rows_valid || (tenants != nullptr && tenants[row] != tenant)) h &= ~(1u << bit);
                 }
-        } else {
-            unsigned hits = 0u;                       // bit (i*4 + r) set = that accumulator is a candidate
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = row0 + wm * 128 + i * 16 + fq * 4 + r;
-                    const bool hit = q_ok && row < n_rows_valid && acc[i][j][r] * scale >= thr &&
-                                     (tenants == nullptr || tenants[row] == tenant);
-                    hits |= hit ? (1u << (i * 4 + r)) : 0u;
-                }
-            if (hits) {
-                const unsigned n_hit = __popc(hits);
-                unsigned slot = atomicAdd(&cnt[q], n_hit);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (hits & (1u << (i * 4 + r))) {
-                            const int row = row0 + wm * 128 + i * 16 + fq * 4 + r;
-                            if (slot < RAG_CAND_CAP)
-                                cand[(size_t)q * RAG_CAND_CAP + slot] = make_key(acc[i][j][r] * scale, (uint32_t)row);
-                            ++slot;
-                        }
             }
         }
+        hits[j] = h;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = q0 + wn * 64 + j * 16 + fr;
+        slot[j] = hits[j] ? atomicAdd(&cnt[q], (unsigned)__popc(hits[j])) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (!hits[j]) continue;
+        const int q = q0 + wn * 64 + j * 16 + fr;
+        uint64_t* dst = cand + (size_t)q * RAG_CAND_CAP;
+        unsigned s_ = slot[j];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (hits[j] & (1u << (i * 4 + r))) {
+                    if (s_ < RAG_CAND_CAP)
+                        dst[s_] = make_key(acc[i][j][r] * scale, (uint32_t)(row0 + wm * 128 + i * 16 + fq * 4 + r));
+                    ++s_;
+                }
     }
 }
 

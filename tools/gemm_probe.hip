@@ -12,6 +12,7 @@
 
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 917504, Q = argc > 2 ? atoi(argv[2]) : 1024, D = 1536, iters = 5;
+    const float tau_v = argc > 3 ? (float)atof(argv[3]) : INFINITY;      // emission threshold (inf = nothing emitted)
     const int n_rt = N / 256, n_qt = Q / 256;
     std::vector<half_t> hc((size_t)4096 * D), hq((size_t)Q * D);
     std::mt19937 rng(1);
@@ -30,7 +31,7 @@ int main(int argc, char** argv) {
     for (size_t r = 0; r < (size_t)N; r += 4096)       // random rows (tiled copy of 4096 distinct rows)
         CK(hipMemcpy(c + r * D, hc.data(), std::min<size_t>(4096, N - r) * D * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(q, hq.data(), (size_t)Q * D * 2, hipMemcpyHostToDevice));
-    std::vector<float> ht(Q, INFINITY);
+    std::vector<float> ht(Q, tau_v);
     CK(hipMemcpy(tau, ht.data(), Q * 4, hipMemcpyHostToDevice));
     CK(hipMemset(cnt, 0, Q * 4));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -49,6 +50,7 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e1));
     float best = 1e9f;
     for (int it = 0; it < iters; ++it) {
+        CK(hipMemset(cnt, 0, Q * 4));
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL(dense_emit_kernel<false>, dim3(grid), dim3(512), DENSE_LDS_BYTES, 0, c, q, D, 0, n_rt, n_qt, N, Q, tau, cnt,
                            cand, (const int32_t*)nullptr, 0 EXTRA);
@@ -88,7 +90,10 @@ int main(int argc, char** argv) {
         }
     }
     const double tf = 2.0 * Q * (double)N * D / (best * 1e-3) / 1e12;
-    printf("N=%d Q=%d  best %.3f ms  %.1f TFLOP/s  (%d WGs)\n", N, Q, best, tf, n_rt * n_qt);
+    unsigned hc0[4];
+    CK(hipMemcpy(hc0, cnt, 16, hipMemcpyDeviceToHost));
+    printf("N=%d Q=%d tau=%.4f  best %.3f ms  %.1f TFLOP/s  (%d WGs)  emitted/query ~ %u %u %u\n", N, Q, tau_v, best, tf, n_rt * n_qt,
+           hc0[0], hc0[1], hc0[2]);
 #ifdef DENSE_STAMP
     std::vector<unsigned long long> hs((size_t)grid * 8 * 4);
     CK(hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost));
