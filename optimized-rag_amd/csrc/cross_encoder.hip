@@ -49,8 +49,12 @@ struct rag_ce_model {
 };
 
 #define CE_BM 128     // output features per tile (MFMA rows)
-#define CE_BN 128     // tokens per tile (MFMA cols)
-#define CE_TILE_BYTES (128 * 64 * 2)
+#define CE_BN 256     // tokens per tile (MFMA cols)
+#define CE_BK 32      // K per LDS stage = one mfma_16x16x32 k-step
+#define CE_W_BYTES (CE_BM * CE_BK * 2)                    // one plane of the weight tile: 8 KiB
+#define CE_X_BYTES (CE_BN * CE_BK * 2)                    // one plane of the token tile: 16 KiB
+#define CE_STAGE_BYTES (2 * CE_W_BYTES + 2 * CE_X_BYTES)  // W_hi | W_lo | X_hi | X_lo = 48 KiB
+#define CE_GEMM_LDS (3 * CE_STAGE_BYTES)                  // three stages = 144 KiB
 
 enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2 };
 
@@ -62,18 +66,23 @@ __device__ __forceinline__ void store_split4(half_t* __restrict__ p, size_t plan
     *reinterpret_cast<half4*>(p + plane) = lo;
 }
 
-__device__ __forceinline__ void ce_stage(const half_t* __restrict__ gsrc, int ld, char* lds_tile, int wid) {
-    // 128 rows x 128 B = 1024 chunks of 16 B; 256 threads -> 4 pieces/thread; piece j -> chunk j*256 + wid*64 + lane
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + (size_t)j * 32 * ld),
-                                         (__attribute__((address_space(3))) void*)(lds_tile + (j * 256 + wid * 64) * 16), 16, 0, 0);
+// LDS rows are 64 B (32 halfs = 4 chunks of 16 B). Chunk c of row r is stored at position c ^ ((-(r>>2)) & 3): with
+// that swizzle every 16-lane group of a ds_read_b128 fragment read covers all 16 bank slots once (conflict-free);
+// as in dense.hip it is applied on the DMA SOURCE address, the LDS destination stays lane-linear.
+__device__ __forceinline__ void ce_dma(const half_t* __restrict__ g, char* lds, int wid) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(lds + wid * 64 * 16), 16, 0, 0);
 }
 
 // C^T[n][m] = sum_k W[n][k] * X[m][k].   W: [2 planes][N][K] fp16, X: [2 planes][M_pad][K] fp16 (hi plane, then lo).
-// N % 128 == 0, M_pad % 128 == 0, K % 64 == 0.  LDS per stage: A_hi | A_lo | B_hi | B_lo (4 x 16 KiB), 2 stages.
+// N % 128 == 0, M_pad % 256 == 0, K % 32 == 0, K >= 64.
+// 128 (features) x 256 (tokens) tile, 8 waves (2 x 4, each 64 x 64), BK = 32, THREE LDS stages filled by LDS-DMA two
+// K-steps ahead. Same staggered structure as dense.hip: per K-step an I-part (16 fragment reads + 6 DMA pieces,
+// lgkmcnt(0)) and an M-part (48 MFMAs = 16 products x {lo*hi, hi*lo, hi*hi}), each closed by s_barrier; waves 4-7 run
+// half a phase behind waves 0-3 so one group's MFMAs cover the other's reads. RAW: one counted s_waitcnt vmcnt(6)
+// per K-step (step t+1 landed, step t+2 in flight); WAR: stage (t+2)%3 was last read in I(t-1).
 template <int EPI>
-__global__ __launch_bounds__(256) void ce_gemm_kernel(const half_t* __restrict__ W, size_t w_plane, const half_t* __restrict__ X,
+__global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__ W, size_t w_plane, const half_t* __restrict__ X,
                                                        size_t x_plane, int N, int K, const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ out32,
                                                        half_t* __restrict__ out16, size_t out_plane, half_t* __restrict__ vt16,
@@ -81,65 +90,77 @@ __global__ __launch_bounds__(256) void ce_gemm_kernel(const half_t* __restrict__
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid >> 2, wn = wid & 3;
+    const bool lag = wm != 0;
     const int n0 = blockIdx.x * CE_BM;          // feature tile (fast index: all feature tiles of a token tile are adjacent)
     const int m0 = blockIdx.y * CE_BN;          // token tile
-    const int sr = tid >> 3;
-    const int schunk = (tid & 7) ^ ((sr >> 1) & 7);
-    const half_t* a_src = W + (size_t)(n0 + sr) * K + schunk * 8;
-    const half_t* b_src = X + (size_t)(m0 + sr) * K + schunk * 8;
-    const int fr = lane & 15, fq = lane >> 4, sw = (fr >> 1) & 7;
-    int off_k[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) off_k[kk] = fr * 128 + (((kk * 4 + fq) ^ sw) << 4);
-    const int a_base = wm * 64 * 128, b_base = wn * 64 * 128;
+    // DMA source per thread: linear chunk i = tid (+512): row i>>2, position i&3 -> source chunk (i&3) ^ ((-(row>>2))&3)
+    const int sr = tid >> 2;                                          // 0..127
+    const int schunk = (tid & 3) ^ ((-(sr >> 2)) & 3);                // (row+128)>>2 has the same low 2 bits
+    const half_t* w_src = W + (size_t)(n0 + sr) * K + schunk * 8;
+    const half_t* x_src = X + (size_t)(m0 + sr) * K + schunk * 8;     // rows 0..127 of the token tile; +128*K for the rest
+    const size_t x_half = (size_t)128 * K;
+    const int fr = lane & 15, fq = lane >> 4;
+    // fragment row r = base16 + fr (base16 multiple of 16 -> (r>>2)&3 == (fr>>2)&3): byte offset inside a plane tile
+    const int off = fr * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
+    const int a_base = wm * 64 * 64, b_base = wn * 64 * 64;
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nt = K / 64;
-    ce_stage(a_src, K, smem, wid);
-    ce_stage(a_src + w_plane, K, smem + CE_TILE_BYTES, wid);
-    ce_stage(b_src, K, smem + 2 * CE_TILE_BYTES, wid);
-    ce_stage(b_src + x_plane, K, smem + 3 * CE_TILE_BYTES, wid);
-    __syncthreads();
-    int cur = 0;
+    const int nt = K / CE_BK;
+    const int last = nt - 1;
+#define CE_STEP(u) (((u) < last ? (u) : last) * CE_BK)
+#define CE_ISSUE(u)                                                                                               \
+    {                                                                                                             \
+        char* st_ = smem + ((u) % 3) * CE_STAGE_BYTES;                                                            \
+        const int ko_ = CE_STEP(u);                                                                               \
+        ce_dma(w_src + ko_, st_, wid);                                                                            \
+        ce_dma(w_src + w_plane + ko_, st_ + CE_W_BYTES, wid);                                                     \
+        ce_dma(x_src + ko_, st_ + 2 * CE_W_BYTES, wid);                                                           \
+        ce_dma(x_src + x_half + ko_, st_ + 2 * CE_W_BYTES + 512 * 16, wid);                                       \
+        ce_dma(x_src + x_plane + ko_, st_ + 2 * CE_W_BYTES + CE_X_BYTES, wid);                                    \
+        ce_dma(x_src + x_plane + x_half + ko_, st_ + 2 * CE_W_BYTES + CE_X_BYTES + 512 * 16, wid);                \
+    }
+#define CE_BAR __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+    CE_ISSUE(0)
+    CE_ISSUE(1)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    CE_BAR
+    if (lag) { CE_BAR }
     for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) {
-            char* nxt = smem + (cur ^ 1) * 4 * CE_TILE_BYTES;
-            ce_stage(a_src + (t + 1) * 64, K, nxt, wid);
-            ce_stage(a_src + w_plane + (t + 1) * 64, K, nxt + CE_TILE_BYTES, wid);
-            ce_stage(b_src + (t + 1) * 64, K, nxt + 2 * CE_TILE_BYTES, wid);
-            ce_stage(b_src + x_plane + (t + 1) * 64, K, nxt + 3 * CE_TILE_BYTES, wid);
+        const char* st = smem + (t % 3) * CE_STAGE_BYTES;
+        half8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[i] = *reinterpret_cast<const half8*>(st + a_base + i * 16 * 64 + off);
+            al[i] = *reinterpret_cast<const half8*>(st + CE_W_BYTES + a_base + i * 16 * 64 + off);
         }
-        const char* la = smem + cur * 4 * CE_TILE_BYTES + a_base;
-        const char* lb = smem + cur * 4 * CE_TILE_BYTES + 2 * CE_TILE_BYTES + b_base;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            half8 ah[4], al[4], bh[4], bl[4];
+        for (int j = 0; j < 4; ++j) {
+            bh[j] = *reinterpret_cast<const half8*>(st + 2 * CE_W_BYTES + b_base + j * 16 * 64 + off);
+            bl[j] = *reinterpret_cast<const half8*>(st + 2 * CE_W_BYTES + CE_X_BYTES + b_base + j * 16 * 64 + off);
+        }
+        CE_ISSUE(t + 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lag) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        CE_BAR
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ah[i] = *reinterpret_cast<const half8*>(la + i * 16 * 128 + off_k[kk]);
-                al[i] = *reinterpret_cast<const half8*>(la + CE_TILE_BYTES + i * 16 * 128 + off_k[kk]);
-            }
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                bh[j] = *reinterpret_cast<const half8*>(lb + j * 16 * 128 + off_k[kk]);
-                bl[j] = *reinterpret_cast<const half8*>(lb + CE_TILE_BYTES + j * 16 * 128 + off_k[kk]);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
-        }
-        __syncthreads();
-        cur ^= 1;
+        __builtin_amdgcn_s_setprio(0);
+        if (!lag) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        CE_BAR
     }
+    if (!lag) { CE_BAR }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // epilogue: acc[i][j][r] = C^T[n = n0 + wm*64 + i*16 + fq*4 + r][m = m0 + wn*64 + j*16 + fr]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -244,9 +265,12 @@ __global__ __launch_bounds__(256) void ce_layernorm_kernel(const float* __restri
     wave_layernorm<PER>(v, g, b, hidden, eps, lane, x32 + tok * hidden, x16 + tok * hidden, plane);
 }
 
-// ---- attention: d_head must be 32. One wave per 16-query block; 4 waves per block. NT = L/16 key tiles. -------
-// All operands are split fp16 (hi plane + lo plane): S and P.V are 3 MFMAs each.
-template <int NT>
+// ---- attention: d_head must be 32. NT = L/16 key tiles; one wave owns QB consecutive 16-query blocks so every K / V
+// fragment it loads from L2 is used QB times. All operands are split fp16 (hi plane + lo plane): S and P.V are 3 MFMAs
+// each. S is computed TRANSPOSED (A = K rows, B = Q rows): the accumulator then has the query on the lane column and
+// 4 consecutive KEYS in a lane's registers, so P goes to LDS as packed 8-byte writes (not 2-byte scatters) and the
+// softmax row reduction is registers + two xor-shuffles.
+template <int NT, int QB>
 __global__ __launch_bounds__(256) void ce_attention_kernel(const half_t* __restrict__ qk16, size_t qk_plane,
                                                             const half_t* __restrict__ vt16, size_t vt_plane,
                                                             const int32_t* __restrict__ lens, int L, int hidden, int heads,
@@ -254,95 +278,113 @@ __global__ __launch_bounds__(256) void ce_attention_kernel(const half_t* __restr
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PLD = NT * 16 + 8;                                            // P tile row pitch (halfs)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    half_t (*ph)[PLD] = reinterpret_cast<half_t (*)[PLD]>(smem + (size_t)(2 * wv) * 16 * PLD * 2);       // P hi [16 q][L keys]
-    half_t (*pl)[PLD] = reinterpret_cast<half_t (*)[PLD]>(smem + (size_t)(2 * wv + 1) * 16 * PLD * 2);   // P lo
+    // per wave: QB x (P hi [16 q][L keys] | P lo)
+    half_t (*pbase)[PLD] = reinterpret_cast<half_t (*)[PLD]>(smem + (size_t)wv * QB * 2 * 16 * PLD * 2);
     const int pair = blockIdx.z, head = blockIdx.y;
-    const int qb = blockIdx.x * 4 + wv;                  // 16-query block index
+    const int qb0 = (blockIdx.x * 4 + wv) * QB;          // first 16-query block of this wave
     const int len = max(1, min(lens[pair], L));
-    if (qb * 16 >= L) return;
+    if (qb0 * 16 >= L) return;
     const int fr = lane & 15, fq = lane >> 4;
     const size_t row0 = (size_t)pair * L;
     const int ld = 2 * hidden;
-    // A = Q rows (query fr of the block, k = 8*fq..+8), B = K rows (key fr of the tile)
-    const half_t* qp = qk16 + (row0 + qb * 16 + fr) * ld + head * 32 + fq * 8;
-    const half8 qh = *reinterpret_cast<const half8*>(qp);
-    const half8 ql = *reinterpret_cast<const half8*>(qp + qk_plane);
-    f32x4 s[NT];
     const float scale = 0.17677669529663687f;            // 32^-0.5
+    // B operand = Q rows (query fr of block b, k = 8*fq..+8); rows past L are clamped (results discarded)
+    half8 qh[QB], ql[QB];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const int qrow = min((qb0 + b) * 16 + fr, L - 1);
+        const half_t* qp = qk16 + (row0 + qrow) * ld + head * 32 + fq * 8;
+        qh[b] = *reinterpret_cast<const half8*>(qp);
+        ql[b] = *reinterpret_cast<const half8*>(qp + qk_plane);
+    }
+    f32x4 s[QB][NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+        // A operand = K rows (key fr of tile t)
         const half_t* kp = qk16 + (row0 + t * 16 + fr) * ld + hidden + head * 32 + fq * 8;
         const half8 kh = *reinterpret_cast<const half8*>(kp);
         const half8 kl = *reinterpret_cast<const half8*>(kp + qk_plane);
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql, kh, z, 0, 0, 0);
-        z = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh, kl, z, 0, 0, 0);
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh, kh, z, 0, 0, 0);
-        // C layout: col = fr = key within tile, row = fq*4 + r = query within block
-        const bool valid = (t * 16 + fr) < len;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[t][r] = valid ? s[t][r] * scale : -INFINITY;
+        for (int b = 0; b < QB; ++b) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            z = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[b], z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[b], z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[b], z, 0, 0, 0);
+            // C layout: col = fr = query, row = fq*4 + r = key within the tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[b][t][r] = (t * 16 + fq * 4 + r) < len ? z[r] * scale : -INFINITY;
+        }
     }
-    // softmax over keys: a query row lives in the 16 lanes sharing fq (xor 1,2,4,8) x NT tiles
-    float sum[4];
+    float inv_sum[QB];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int b = 0; b < QB; ++b) {
+        // softmax over keys of query fr: this lane's NT*4 values, then the 4 lanes sharing fr (xor 16, 32)
         float m = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) m = fmaxf(m, s[t][r]);
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        for (int t = 0; t < NT; ++t) m = fmaxf(m, fmaxf(fmaxf(s[b][t][0], s[b][t][1]), fmaxf(s[b][t][2], s[b][t][3])));
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
         float a = 0.f;
+        half_t (*ph)[PLD] = pbase + (size_t)(2 * b) * 16;
+        half_t (*pl)[PLD] = pbase + (size_t)(2 * b + 1) * 16;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const float e = expf(s[t][r] - m);
-            s[t][r] = e;
-            a += e;
-        }
+            float e[4];
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) a += __shfl_xor(a, o);
-        sum[r] = a;
+            for (int r = 0; r < 4; ++r) { e[r] = expf(s[b][t][r] - m); a += e[r]; }
+            const half4 hi = {(half_t)e[0], (half_t)e[1], (half_t)e[2], (half_t)e[3]};
+            const half4 lo = {(half_t)(e[0] - (float)hi[0]), (half_t)(e[1] - (float)hi[1]), (half_t)(e[2] - (float)hi[2]),
+                              (half_t)(e[3] - (float)hi[3])};
+            *reinterpret_cast<half4*>(&ph[fr][t * 16 + fq * 4]) = hi;      // P[query fr][4 consecutive keys]
+            *reinterpret_cast<half4*>(&pl[fr][t * 16 + fq * 4]) = lo;
+        }
+        a += __shfl_xor(a, 16);
+        a += __shfl_xor(a, 32);
+        inv_sum[b] = 1.0f / a;
     }
-    // P (unnormalised) -> LDS [q][key] as hi/lo planes
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const half_t hi = (half_t)s[t][r];
-            ph[fq * 4 + r][t * 16 + fr] = hi;
-            pl[fq * 4 + r][t * 16 + fr] = (half_t)(s[t][r] - (float)hi);
-        }
     __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's LDS writes done (wave-private tiles)
     __builtin_amdgcn_wave_barrier();
     // ctx[q][d] = sum_key P[q][key] * V[key][d]:  A = P (row q = fr, keys 8*fq..), B = V^T rows (d = fr)
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 c0[QB], c1[QB];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) { c0[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; c1[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const half_t* vbase = vt16 + ((size_t)pair * heads + head) * 32 * L;
 #pragma unroll
     for (int kb = 0; kb < NT / 2; ++kb) {          // 32 keys per MFMA
-        const half8 pfh = *reinterpret_cast<const half8*>(&ph[fr][kb * 32 + fq * 8]);
-        const half8 pfl = *reinterpret_cast<const half8*>(&pl[fr][kb * 32 + fq * 8]);
         const half_t* v0p = vbase + (size_t)fr * L + kb * 32 + fq * 8;
         const half_t* v1p = vbase + (size_t)(16 + fr) * L + kb * 32 + fq * 8;
         const half8 v0h = *reinterpret_cast<const half8*>(v0p), v0l = *reinterpret_cast<const half8*>(v0p + vt_plane);
         const half8 v1h = *reinterpret_cast<const half8*>(v1p), v1l = *reinterpret_cast<const half8*>(v1p + vt_plane);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfl, v0h, c0, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh, v0l, c0, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh, v0h, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfl, v1h, c1, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh, v1l, c1, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh, v1h, c1, 0, 0, 0);
-    }
-    // C layout: col = fr = d (c0: d, c1: 16+d), row = fq*4 + r = query. sum[r] is the row sum of that query.
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float inv = 1.0f / sum[r];
-        half_t* o = ctx16 + (row0 + qb * 16 + fq * 4 + r) * hidden + head * 32;
-        const float a0 = c0[r] * inv, a1 = c1[r] * inv;
-        const half_t h0 = (half_t)a0, h1 = (half_t)a1;
-        o[fr] = h0;
-        o[16 + fr] = h1;
-        o[ctx_plane + fr] = (half_t)(a0 - (float)h0);
-        o[ctx_plane + 16 + fr] = (half_t)(a1 - (float)h1);
+        for (int b = 0; b < QB; ++b) {
+            half_t (*ph)[PLD] = pbase + (size_t)(2 * b) * 16;
+            half_t (*pl)[PLD] = pbase + (size_t)(2 * b + 1) * 16;
+            const half8 pfh = *reinterpret_cast<const half8*>(&ph[fr][kb * 32 + fq * 8]);
+            const half8 pfl = *reinterpret_cast<const half8*>(&pl[fr][kb * 32 + fq * 8]);
+            c0[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfl, v0h, c0[b], 0, 0, 0);
+            c0[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh, v0l, c0[b], 0, 0, 0);
+            c0[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh, v0h, c0[b], 0, 0, 0);
+            c1[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfl, v1h, c1[b], 0, 0, 0);
+            c1[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh, v1l, c1[b], 0, 0, 0);
+            c1[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh, v1h, c1[b], 0, 0, 0);
+        }
+    }
+    // C layout: col = fr = d (c0: d, c1: 16+d), row = fq*4 + r = query; 1/sum of that query lives in lane (fq*4+r)
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qrow = (qb0 + b) * 16 + fq * 4 + r;
+            const float inv = __shfl(inv_sum[b], fq * 4 + r);
+            if (qrow >= L) continue;
+            half_t* o = ctx16 + (row0 + qrow) * hidden + head * 32;
+            const float a0 = c0[b][r] * inv, a1 = c1[b][r] * inv;
+            const half_t h0 = (half_t)a0, h1 = (half_t)a1;
+            o[fr] = h0;
+            o[16 + fr] = h1;
+            o[ctx_plane + fr] = (half_t)(a0 - (float)h0);
+            o[ctx_plane + 16 + fr] = (half_t)(a1 - (float)h1);
+        }
     }
 }
 
@@ -477,15 +519,17 @@ static ce_planes planes_for(const rag_ce_model* m, int64_t Mp) {
 
 template <int NT>
 static void launch_attention(rag_ce_model* m, int P, int L, const ce_planes& pp, hipStream_t st) {
-    const size_t lds = (size_t)8 * 16 * (NT * 16 + 8) * 2;            // 4 waves x (P hi + P lo)
+    constexpr int QB = NT <= 16 ? 2 : 1;                               // 16-query blocks per wave (register budget)
+    const size_t lds = (size_t)4 * QB * 2 * 16 * (NT * 16 + 8) * 2;    // 4 waves x QB x (P hi + P lo)
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ce_attention_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ce_attention_kernel<NT, QB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL(ce_attention_kernel<NT>, dim3((L / 16 + 3) / 4, m->cfg.heads, P), dim3(256), lds, st, m->qk16, pp.qk,
-                       m->vt16, pp.vt, m->lens, L, m->cfg.hidden, m->cfg.heads, m->ctx16, pp.ctx);
+    const int qblocks = L / 16;
+    hipLaunchKernelGGL((ce_attention_kernel<NT, QB>), dim3((qblocks + 4 * QB - 1) / (4 * QB), m->cfg.heads, P), dim3(256), lds, st,
+                       m->qk16, pp.qk, m->vt16, pp.vt, m->lens, L, m->cfg.hidden, m->cfg.heads, m->ctx16, pp.ctx);
 }
 
 template <int PER>
@@ -503,7 +547,7 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     const int per = H / 64;
     const float eps = (float)m->cfg.ln_eps;
     static bool attr = false;
-    const size_t lds = 8 * CE_TILE_BYTES;
+    const size_t lds = CE_GEMM_LDS;
     if (!attr) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_kernel<EPI_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_kernel<EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -519,7 +563,7 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
 #define EMB(PER) hipLaunchKernelGGL(ce_embed_ln_kernel<PER>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, m->ids, m->tt, m->word, \
                                     m->pos, m->type, m->emb_ln_g, m->emb_ln_b, M, L, H, m->cfg.vocab_size, eps, m->x32, m->x16, pp.x)
     CE_PER_DISPATCH(EMB)
-    const dim3 blk(256);
+    const dim3 blk(512);
     const unsigned mt = (unsigned)(Mt / CE_BN);
     const half_t* nullh = nullptr;
     for (int l = 0; l < m->cfg.layers; ++l) {
