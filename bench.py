@@ -140,6 +140,22 @@ def main():
         lat.append((time.perf_counter() - a) * 1e3)
     p50 = float(np.median(lat))
 
+    # single-query latency (what one agent turn sees): Q = 1 through the same entry point, synchronised
+    lat1 = None
+    if world == 1:
+        q1 = queries[:1].contiguous()
+        i1 = torch.empty((1, k), dtype=torch.int64, device=device)
+        s1 = torch.empty((1, k), dtype=torch.float64, device=device)
+        l1 = []
+        for it in range(25):
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            eng.dense_topk_dev(q1, k, i1, None, s1)
+            torch.cuda.synchronize()
+            if it >= 5:
+                l1.append((time.perf_counter() - a) * 1e3)
+        lat1 = float(np.median(l1))
+
     final_ids, final_scores = step()
     torch.cuda.synchronize()
     got_ids = final_ids.cpu().numpy()
@@ -201,7 +217,7 @@ def main():
                                f"batch={Q} queries (BASELINE.json configs[1])",
                    "corpus_rows": args.rows, "rows_per_gpu": n_local, "batch_queries": Q, "k": k,
                    "parallelism": f"row-sharded x{world}" + (" + RCCL all-gather merge" if world > 1 else "")},
-        "p50_batch_latency_ms": round(p50, 4),
+        "p50_batch_latency_ms": round(p50, 4), "p50_single_query_latency_ms": None if lat1 is None else round(lat1, 4),
         "exactness": {**stats, "planted_neighbour_at_rank1": planted_hit},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,

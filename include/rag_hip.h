@@ -111,6 +111,21 @@ int rag_rrf_fuse_host(rag_handle_t h, const int64_t* lists_host, int n_queries, 
                       int rrf_k, int top_k, int64_t* keys_out_host, double* scores_out_host,
                       int32_t* ranks_out_host);
 
+/* Device-pointer forms of the fusion / BM25 entry points (asynchronous on `stream`), and the whole hybrid path of
+ * BASELINE.json configs[2] in one call: dense top-`pool` + BM25 top-`pool` -> RRF(rrf_k) -> top-k, nothing leaves HBM.
+ * rag_rrf_fuse_dev: lists_dev is [Q][n_lists][list_len]. rag_hybrid_rrf_dev: lists_ws_dev is caller scratch
+ * [2][Q][pool] int64, scores_ws_dev [Q][pool] float64; keys are doc ids (BM25 rows use the dense index's id mapping,
+ * the two indexes must be row-aligned). */
+int rag_rrf_fuse_dev(rag_handle_t h, const int64_t* lists_dev, int n_queries, int n_lists, int list_len, int rrf_k,
+                     int top_k, int64_t* keys_out_dev, double* scores_out_dev, int32_t* ranks_out_dev, void* stream);
+int rag_bm25_topk_dev(rag_handle_t h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int n_queries, int k,
+                      int64_t* ids_out_dev, int32_t* rows_out_dev, double* scores_out_dev, double* raw_max_out_dev,
+                      void* stream);
+int rag_hybrid_rrf_dev(rag_handle_t h, const float* q_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev,
+                       int n_queries, int pool, int k, int rrf_k, int tenant, int64_t* lists_ws_dev,
+                       double* scores_ws_dev, int64_t* keys_out_dev, double* rrf_out_dev, int32_t* ranks_out_dev,
+                       void* stream);
+
 /* ---- BM25 over CSR postings: replaces BM25Okapi(tokenized_corpus).get_scores(query) + the /max
  *      normalisation (rag/retrieval.py:324-347). Postings are term-major CSR, docs ascending per term.
  *      idf[V] is computed by the host exactly as rank-bm25 does (float64). */

@@ -60,6 +60,9 @@ _SIGS = {
     "rag_bm25_load_host": ([_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double], C.c_int),
     "rag_bm25_topk_host": ([_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
     "rag_bm25_scores_host": ([_P, _P, _P, C.c_int, _P], C.c_int),
+    "rag_rrf_fuse_dev": ([_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
+    "rag_bm25_topk_dev": ([_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P], C.c_int),
+    "rag_hybrid_rrf_dev": ([_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P], C.c_int),
     "rag_linear_fuse_topk_host": ([_P, _P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _P, _P], C.c_int),
     "rag_ce_load_host": ([_P, C.POINTER(CeConfig), C.POINTER(_P), C.c_int], C.c_int),
     "rag_ce_score_host": ([_P, _P, _P, _P, C.c_int, C.c_int, _P], C.c_int),
@@ -304,6 +307,29 @@ class RagEngine:
         self._check(self.lib.rag_bm25_topk_host(self.h, _ptr(term_ptr), _ptr(terms), Q, int(k), _ptr(ids), _ptr(rows),
                                                 _ptr(sc), _ptr(mx)), "rag_bm25_topk_host")
         return ids, rows, sc, mx
+
+    def hybrid_rrf_dev(self, q, term_ptr, terms, pool, k, rrf_k=60, tenant=-1, stream=None):
+        """All-device hybrid (torch CUDA tensors): dense top-pool + BM25 top-pool -> RRF -> (keys [Q,k] int64, rrf scores
+        [Q,k] float64, ranks [Q,k,2] int32). term_ptr / terms are int32 CUDA tensors."""
+        import torch
+        Q = q.shape[0]
+        dev = q.device
+        key = ("hyb", Q, pool, k)
+        if getattr(self, "_hyb_key", None) != key:
+            self._hyb = (torch.empty((2, Q, pool), dtype=torch.int64, device=dev),
+                         torch.empty((Q, pool), dtype=torch.float64, device=dev),
+                         torch.empty((Q, k), dtype=torch.int64, device=dev),
+                         torch.empty((Q, k), dtype=torch.float64, device=dev),
+                         torch.empty((Q, k, 2), dtype=torch.int32, device=dev))
+            self._hyb_key = key
+        lists, sc, keys, rrf, ranks = self._hyb
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        self._check(self.lib.rag_hybrid_rrf_dev(self.h, C.c_void_p(q.data_ptr()), C.c_void_p(term_ptr.data_ptr()),
+                                                C.c_void_p(terms.data_ptr()), Q, int(pool), int(k), int(rrf_k), int(tenant),
+                                                C.c_void_p(lists.data_ptr()), C.c_void_p(sc.data_ptr()),
+                                                C.c_void_p(keys.data_ptr()), C.c_void_p(rrf.data_ptr()),
+                                                C.c_void_p(ranks.data_ptr()), st), "rag_hybrid_rrf_dev")
+        return keys, rrf, ranks
 
     def bm25_scores(self, term_ptr, terms):
         term_ptr = _np(term_ptr, np.int32)

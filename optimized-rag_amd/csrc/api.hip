@@ -15,6 +15,10 @@ int bm25_load_host(rag_ctx* h, const int64_t* indptr, const int32_t* doc, const 
 int bm25_topk_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, int k, int64_t* ids_out,
                    int32_t* rows_out, double* scores_out, double* raw_max_out);
 int bm25_scores_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, double* out);
+int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int64_t* ids_dev,
+                  int32_t* rows_dev, double* scores_dev, double* raw_max_dev, hipStream_t st);
+int rrf_fuse_dev(rag_ctx* h, const int64_t* lists_dev, int Q, int L, int len, int64_t list_stride, int64_t query_stride, int rrf_k,
+                 int top_k, int64_t* keys_dev, double* scores_dev, int32_t* ranks_dev, hipStream_t st);
 void bm25_free(rag_ctx* h);
 int ce_load_host(rag_ctx* h, const rag_ce_config* cfg, const float* const* tensors, int n);
 int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L, float* out,
@@ -306,6 +310,40 @@ int rag_bm25_topk_host(rag_handle_t h, const int32_t* term_ptr, const int32_t* t
     if (!h) return RAG_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     return bm25_topk_host(h, term_ptr, terms, Q, k, ids_out, rows_out, scores_out, raw_max_out);
+}
+
+int rag_bm25_topk_dev(rag_handle_t h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int64_t* ids_dev,
+                      int32_t* rows_dev, double* scores_dev, double* raw_max_dev, void* stream) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, k, ids_dev, rows_dev, scores_dev, raw_max_dev,
+                         stream ? (hipStream_t)stream : h->stream);
+}
+
+int rag_rrf_fuse_dev(rag_handle_t h, const int64_t* lists_dev, int Q, int L, int len, int rrf_k, int top_k, int64_t* keys_dev,
+                     double* scores_dev, int32_t* ranks_dev, void* stream) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return rrf_fuse_dev(h, lists_dev, Q, L, len, len, (int64_t)L * len, rrf_k, top_k, keys_dev, scores_dev, ranks_dev,
+                        stream ? (hipStream_t)stream : h->stream);
+}
+
+// dense top-pool + BM25 top-pool + RRF -> top-k, all on the device, one call (BASELINE.json configs[2]).
+// lists_ws_dev: caller scratch [2][Q][pool] int64 (receives the dense, then the BM25 ranked id list);
+// scores_ws_dev: caller scratch [Q][pool] float64.
+int rag_hybrid_rrf_dev(rag_handle_t h, const float* q_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int pool,
+                       int k, int rrf_k, int tenant, int64_t* lists_ws_dev, double* scores_ws_dev, int64_t* keys_out_dev,
+                       double* rrf_out_dev, int32_t* ranks_out_dev, void* stream) {
+    if (!h) return RAG_ERR_ARG;
+    ARG_CHECK(h, q_dev && term_ptr_dev && lists_ws_dev && scores_ws_dev && keys_out_dev && rrf_out_dev, "hybrid: null pointer");
+    ARG_CHECK(h, pool > 0 && pool <= RAG_MAX_K && k > 0, "hybrid: 0 < pool <= 256");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    int rc = dense_search(h, q_dev, Q, pool, tenant, lists_ws_dev, nullptr, scores_ws_dev, st);
+    if (rc) return rc;
+    rc = bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, lists_ws_dev + (size_t)Q * pool, nullptr, scores_ws_dev, nullptr, st);
+    if (rc) return rc;
+    return rrf_fuse_dev(h, lists_ws_dev, Q, 2, pool, (int64_t)Q * pool, pool, rrf_k, k, keys_out_dev, rrf_out_dev, ranks_out_dev, st);
 }
 
 int rag_bm25_scores_host(rag_handle_t h, const int32_t* term_ptr, const int32_t* terms, int Q, double* out) {

@@ -32,6 +32,9 @@ struct rag_bm25_index {
     double* idf = nullptr;
     int32_t* range_off = nullptr;      // [n_terms][n_ranges+1]: first posting of term t with doc >= r*BM_RANGE (rel. to indptr[t])
     int n_ranges = 0;
+    uint64_t* ws_key = nullptr;        // per-range partial top-k workspace for the device entry point
+    uint32_t* ws_row = nullptr;
+    size_t ws_entries = 0;
     double avgdl = 0, k1 = 1.5, b = 0.75;
 };
 
@@ -263,7 +266,8 @@ __device__ __forceinline__ void bm_sort_pairs(uint64_t* k1, uint32_t* k2, int P,
 }
 
 __global__ __launch_bounds__(256) void bm25_merge_kernel(const uint64_t* __restrict__ part_key, const uint32_t* __restrict__ part_row,
-                                                          int n_ranges, int k, int64_t* __restrict__ ids_out,
+                                                          int n_ranges, int k, const int64_t* __restrict__ idmap,
+                                                          int64_t id_base, int64_t* __restrict__ ids_out,
                                                           int32_t* __restrict__ rows_out, double* __restrict__ scores_out,
                                                           double* __restrict__ raw_max_out) {
     __shared__ uint64_t sk[BM_MERGE];
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(const uint64_t* __restr
         uint64_t u = sk[i];
         u = (u & 0x8000000000000000ull) ? (u & 0x7fffffffffffffffull) : ~u;
         const double s = __builtin_bit_cast(double, u);
-        ids_out[(size_t)q * k + i] = ok ? (int64_t)sr[i] : -1;
+        ids_out[(size_t)q * k + i] = ok ? (idmap ? idmap[sr[i]] : id_base + (int64_t)sr[i]) : -1;
         if (rows_out) rows_out[(size_t)q * k + i] = ok ? (int32_t)sr[i] : -1;
         scores_out[(size_t)q * k + i] = ok ? s / mx : 0.0;
     }
@@ -310,6 +314,7 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(const uint64_t* __restr
 void bm25_free(rag_ctx* h) {
     if (!h->bm25) return;
     hipFree(h->bm25->indptr); hipFree(h->bm25->doc); hipFree(h->bm25->w); hipFree(h->bm25->idf); hipFree(h->bm25->range_off);
+    hipFree(h->bm25->ws_key); hipFree(h->bm25->ws_row);
     delete h->bm25;
     h->bm25 = nullptr;
 }
@@ -397,7 +402,9 @@ static int bm25_run(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, i
         hipLaunchKernelGGL(bm25_range_kernel, dim3(n_ranges, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc,
                            ix->w, ix->idf, ix->range_off, ix->n_ranges, tp, tm, ix->n_docs, ix->n_terms, k, mode, dd, pk, pr);
         if (mode == 0)
-            hipLaunchKernelGGL(bm25_merge_kernel, dim3(Q), dim3(256), 0, st, pk, pr, n_ranges, k, idd, rwd, scd, mxd);
+            hipLaunchKernelGGL(bm25_merge_kernel, dim3(Q), dim3(256), 0, st, pk, pr, n_ranges, k,
+                               h->n_rows == ix->n_docs ? h->ids : (const int64_t*)nullptr,
+                               h->n_rows == ix->n_docs ? h->id_base : (int64_t)0, idd, rwd, scd, mxd);
         e = hipGetLastError();
     }
     if (mode == 0) {
@@ -414,6 +421,39 @@ static int bm25_run(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, i
         h->err = std::string("bm25: ") + hipGetErrorString(e != hipSuccess ? e : e2);
         return RAG_ERR_HIP;
     }
+    return RAG_OK;
+}
+
+// device-pointer entry: everything stays in HBM, asynchronous on `st` (workspace grows on first use / larger Q)
+int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int64_t* ids_dev,
+                  int32_t* rows_dev, double* scores_dev, double* raw_max_dev, hipStream_t st) {
+    ARG_CHECK(h, h->bm25 != nullptr, "no BM25 index loaded");
+    ARG_CHECK(h, Q > 0 && Q <= 65535 && term_ptr_dev && ids_dev && scores_dev, "bm25_topk_dev: bad arguments");
+    ARG_CHECK(h, k > 0 && k <= BM_MERGE / 2 && k <= BM_RANGE, "bm25: 0 < k <= 1024");
+    rag_bm25_index* ix = h->bm25;
+    static bool attr = false;
+    if (!attr) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bm25_range_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, BM_LDS_BYTES));
+        attr = true;
+    }
+    const size_t need = (size_t)Q * ix->n_ranges * k;
+    if (need > ix->ws_entries) {
+        hipFree(ix->ws_key); hipFree(ix->ws_row);
+        ix->ws_key = nullptr; ix->ws_row = nullptr; ix->ws_entries = 0;
+        HIP_TRY(h, hipMalloc(&ix->ws_key, need * sizeof(uint64_t)));
+        HIP_TRY(h, hipMalloc(&ix->ws_row, need * sizeof(uint32_t)));
+        ix->ws_entries = need;
+    }
+    hipLaunchKernelGGL(bm25_range_kernel, dim3(ix->n_ranges, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc, ix->w,
+                       ix->idf, ix->range_off, ix->n_ranges, term_ptr_dev, terms_dev, ix->n_docs, ix->n_terms, k, 0,
+                       (double*)nullptr, ix->ws_key, ix->ws_row);
+    // doc ids follow the dense index's mapping when both indexes cover the same rows (hybrid fusion needs one id space)
+    const bool aligned = h->n_rows == ix->n_docs;
+    hipLaunchKernelGGL(bm25_merge_kernel, dim3(Q), dim3(256), 0, st, ix->ws_key, ix->ws_row, ix->n_ranges, k,
+                       aligned ? h->ids : (const int64_t*)nullptr, aligned ? h->id_base : (int64_t)0, ids_dev, rows_dev, scores_dev,
+                       raw_max_dev);
+    HIP_TRY(h, hipGetLastError());
     return RAG_OK;
 }
 

@@ -14,9 +14,9 @@ __device__ __forceinline__ unsigned hash64(uint64_t x) {
     return (unsigned)x;
 }
 
-// One workgroup per query. lists: [Q][L][len] int64 keys, -1 padding.
-__global__ __launch_bounds__(256) void rrf_fuse_kernel(const int64_t* __restrict__ lists, int L, int len, int rrf_k,
-                                                        int top_k, int64_t* __restrict__ keys_out,
+// One workgroup per query. List l of query q starts at lists + q*query_stride + l*list_stride (len keys, -1 padding).
+__global__ __launch_bounds__(256) void rrf_fuse_kernel(const int64_t* __restrict__ lists, int L, int len, int64_t list_stride,
+                                                        int64_t query_stride, int rrf_k, int top_k, int64_t* __restrict__ keys_out,
                                                         double* __restrict__ scores_out, int32_t* __restrict__ ranks_out) {
     __shared__ unsigned long long tkey[RRF_TABLE];     // hash table: key+1 (0 = empty)
     __shared__ int tfirst[RRF_TABLE];                  // first flat position of that key
@@ -26,9 +26,9 @@ __global__ __launch_bounds__(256) void rrf_fuse_kernel(const int64_t* __restrict
     __shared__ int n_owner;
     const int q = blockIdx.x, tid = threadIdx.x;
     const int T = L * len;
-    const int64_t* src = lists + (size_t)q * T;
+    const int64_t* src = lists + (size_t)q * query_stride;
     for (int i = tid; i < RRF_TABLE; i += 256) { tkey[i] = 0ull; tfirst[i] = 0x7fffffff; }
-    for (int i = tid; i < T; i += 256) item[i] = src[i];
+    for (int i = tid; i < T; i += 256) item[i] = src[(size_t)(i / len) * list_stride + (i % len)];
     if (tid == 0) n_owner = 0;
     for (int i = tid; i < top_k; i += 256) {
         keys_out[(size_t)q * top_k + i] = -1;
@@ -96,6 +96,18 @@ __global__ __launch_bounds__(256) void rrf_fuse_kernel(const int64_t* __restrict
     }
 }
 
+int rrf_fuse_dev(rag_ctx* h, const int64_t* lists_dev, int Q, int L, int len, int64_t list_stride, int64_t query_stride, int rrf_k,
+                 int top_k, int64_t* keys_dev, double* scores_dev, int32_t* ranks_dev, hipStream_t st) {
+    ARG_CHECK(h, Q > 0 && L > 0 && len >= 0 && top_k > 0, "rrf: sizes must be positive");
+    ARG_CHECK(h, (int64_t)L * len <= RRF_MAX_ITEMS, "rrf: n_lists*list_len must be <= 1024");
+    ARG_CHECK(h, lists_dev && keys_dev && scores_dev, "rrf: null pointer");
+    if (len == 0) len = 1, list_stride = 0;       // nothing to fuse: every item reads as padding below
+    hipLaunchKernelGGL(rrf_fuse_kernel, dim3(Q), dim3(256), 0, st, lists_dev, L, len, list_stride, query_stride, rrf_k, top_k,
+                       keys_dev, scores_dev, ranks_dev);
+    HIP_TRY(h, hipGetLastError());
+    return RAG_OK;
+}
+
 int rrf_fuse_host(rag_ctx* h, const int64_t* lists, int Q, int L, int len, int rrf_k, int top_k, int64_t* keys_out,
                   double* scores_out, int32_t* ranks_out) {
     ARG_CHECK(h, Q > 0 && L > 0 && len >= 0 && top_k > 0, "rrf: sizes must be positive");
@@ -112,7 +124,8 @@ int rrf_fuse_host(rag_ctx* h, const int64_t* lists, int Q, int L, int len, int r
     if (e == hipSuccess && ranks_out) e = hipMalloc(&rd, (size_t)Q * top_k * L * sizeof(int32_t));
     if (e == hipSuccess && T) e = hipMemcpyAsync(ld, lists, (size_t)Q * T * sizeof(int64_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(rrf_fuse_kernel, dim3(Q), dim3(256), 0, st, ld, L, len, rrf_k, top_k, kd, sd, rd);
+        hipLaunchKernelGGL(rrf_fuse_kernel, dim3(Q), dim3(256), 0, st, ld, L, std::max(len, 1), (int64_t)len, (int64_t)T, rrf_k, top_k,
+                           kd, sd, rd);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(keys_out, kd, (size_t)Q * top_k * sizeof(int64_t), hipMemcpyDeviceToHost, st);

@@ -354,3 +354,33 @@ def test_gpu_document_index_search(eng):
     hr = HybridRetriever(memory_manager=None, document_store=store, agent_id="agent-1", engine=eng)
     res = hr.retrieve("whatever", sources=["documents"], top_k=5)
     assert [d["metadata"]["i"] for d in res] == oid[0].tolist() and all(d["source"] == "documents" for d in res)
+
+
+# ---------------------------------------------------------------------------------------- fused device hybrid
+def test_hybrid_rrf_dev_matches_oracle_pipeline(eng):
+    """rag_hybrid_rrf_dev (dense top-pool + BM25 top-pool + RRF, all on device) == oracle dense + oracle BM25 + oracle RRF."""
+    import torch
+    from optimized_rag_amd.bm25 import Bm25Postings
+    rng = np.random.default_rng(51)
+    N, D, Q, pool, k = 20000, 1536, 12, 100, 20
+    docs = synthetic_postings(rng, N, 3000, 25)
+    corpus = [" ".join(f"t{t}" for t in d) for d in docs]
+    emb = rng.standard_normal((N, D)).astype(np.float32)
+    q = (emb[rng.integers(0, N, Q)] + 0.5 * rng.standard_normal((Q, D))).astype(np.float32)
+    queries = [" ".join(f"t{t}" for t in rng.choice(docs[int(rng.integers(0, N))] or [1], size=5)) for _ in range(Q)]
+    ids = (np.arange(N)[::-1] + 7_000_000).astype(np.int64)                      # non-trivial id mapping
+    eng.index_load(emb, ids=ids)
+    post = Bm25Postings.from_corpus(corpus).load(eng)
+    ptr, terms = post.encode_queries(queries)
+    keys, rrf, ranks = eng.hybrid_rrf_dev(torch.from_numpy(q).cuda(), torch.from_numpy(ptr).cuda(),
+                                          torch.from_numpy(terms).cuda(), pool, k)
+    torch.cuda.synchronize()
+    keys, rrf, ranks = keys.cpu().numpy(), rrf.cpu().numpy(), ranks.cpu().numpy()
+    d_rows, _ = O.dense_topk(emb, q, pool)
+    obm = O.BM25Okapi([O.tokenize(c) for c in corpus])
+    for qi in range(Q):
+        b_rows = O.stable_topk_desc(obm.get_scores(O.tokenize(queries[qi])), pool)
+        okeys, oscores, oranks = O.rrf_fuse([[int(ids[r]) for r in d_rows[qi]], [int(ids[r]) for r in b_rows]], k=60, top_k=k)
+        assert keys[qi].tolist() == okeys
+        assert rrf[qi].tolist() == oscores                                    # bit-exact float64
+        assert ranks[qi].tolist() == oranks
