@@ -16,7 +16,7 @@
 #include "common.h"
 
 #define BM_RANGE 16384
-#define BM_THREADS 512
+#define BM_THREADS 1024
 #define BM_SEG (BM_RANGE / BM_THREADS)      // 32 contiguous docs per thread
 // accumulator i lives at LDS double i + i/32: a thread's 32 contiguous docs then start one bank-pair further than its
 // neighbour's, so the per-thread segment reads are conflict-free (unpadded: every lane on the same bank, 32-way)
