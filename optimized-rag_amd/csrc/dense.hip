@@ -9,14 +9,14 @@
 //   dense_emit       S~ = C16 . Q16^T on MFMA (fp16 in, fp32 acc), 256x256 tiles through LDS; the
 //                    Q x N score matrix is never written: the epilogue emits only (score,row) keys
 //                    with S~ >= tau[q] into a per-query candidate buffer.  Run as a few stages over
-//                    growing row ranges; after each stage `select` sorts the buffer, keeps the best
-//                    K' and raises tau[q] to the K'-th best score seen so far.
-//   rescore          float64 cosine of the K' shortlisted rows against the fp32 master rows
-//   finalize         order by (float64 cosine desc, row asc), write top-k, and PROVE exactness:
-//                    every row outside the shortlist has S~ <= bound, |S~ - S| <= eps  =>  if the
-//                    k-th exact score > bound + eps the id set is the exact scan's.  Otherwise
-//   wide             rescore the whole candidate buffer (bound = last emission threshold), else
-//   scan             float64 exact scan of every row for that query.
+//                    growing row ranges; after each stage `select` finds the k-th best score so far,
+//                    sets tau[q] = that - 2*eps and drops every key below it.
+//   rescore          float64 cosine of the surviving rows (~1.5 k per query) against the fp32 master rows
+//   finalize         order by (float64 cosine desc, row asc), write top-k. EXACTNESS IS STRUCTURAL: with
+//                    |S~ - S| <= eps, a row below tau cannot be in the exact top-k (proof at select_kernel), so the
+//                    survivors always contain it. Only two escapes exist:
+//   wide             more than 256 survivors (tight clusters, duplicates): rank the whole buffer;
+//   scan             the 4096-entry buffer overflowed: float64 exact scan of every row for that query.
 #include "common.h"
 
 #define WAVE 64
@@ -333,22 +333,26 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
 
 // ------------------------------------------------------------------------------------------------
 // K2: per-query select as a PER-WAVEFRONT bitwise radix select (one wave per query, 4 queries per workgroup).
-// Keys are unique 64-bit values (orderable score << 32 | ~row), so "the keep-th largest key" is a total-order
-// pivot: build it MSB-first, one bit per step, counting keys >= candidate with ballot + popcount (no atomics, no
-// sort, no cross-lane reduction). Stops as soon as a candidate has exactly `keep` keys above it. Survivors are
-// compacted to the front of cand[] with ballot prefix sums; nothing downstream needs them sorted (rescore /
-// finalize rank by the exact float64 score).
-//   n_in   = dense0_rows (stage 0: slots 0..rows-1, empty slots are 0) or min(cnt, cap)
-//   keep   = K' : cand[0..m) = the m = min(valid, K') best keys, cnt = m, tau = score of the K'-th best
-//   final  : the other valid keys follow at cand[m..n_valid), n_sorted = n_valid,
-//            bound = max(tau_in, best score beyond the shortlist), +inf if the buffer ever overflowed
+// Keys are unique 64-bit values (orderable score << 32 | ~row), so "the k-th largest key" is a total-order pivot:
+// build it MSB-first, one bit per step, counting keys >= candidate with ballot + popcount (no atomics, no sort, no
+// cross-lane reduction); stop as soon as a candidate has exactly k keys above it.
+//
+// Threshold rule (this is what makes the result PROVABLY the exact scan's): let s~(k) be the k-th best fp16-pass score
+// among the rows seen so far and eps the bound |s~ - s| <= eps. The final exact k-th score satisfies
+// s_k >= s~(k) - eps (the k rows with the best s~ all have s >= s~(k) - eps), and a row with s~ < s~(k) - 2 eps has
+// s <= s~ + eps < s~(k) - eps <= s_k: it cannot be in the top-k. So tau = s~(k) - 2 eps is a safe emission threshold
+// (s~(k) only grows as more rows are seen) and every key below it can be dropped for good. What survives (typically
+// ~1.5 k keys) is rescored in float64 and ranked; no a-posteriori check is needed unless the buffer overflowed.
+//   n_in = dense0_rows (stage 0: slots 0..rows-1, empty slots are 0) or min(cnt, cap)
+//   out  : cand[0..m) = all keys with score >= tau (unordered), cnt = m, tau updated;
+//          final stage: n_sorted = m; bound = +inf if the buffer ever overflowed (candidates were lost), else -inf
 // ------------------------------------------------------------------------------------------------
 #define SEL_REG 32                      // keys held in registers per lane (covers 2048 candidates)
 #define SELECT_LDS_BYTES (4 * (RAG_CAND_CAP - SEL_REG * 64) * 8)
 __global__ __launch_bounds__(256) void select_kernel(uint64_t* __restrict__ cand, unsigned* __restrict__ cnt,
                                                       float* __restrict__ tau, float* __restrict__ bound,
                                                       int* __restrict__ n_sorted, int* __restrict__ stats, int n_queries,
-                                                      int dense0_rows, int keep, int final_stage) {
+                                                      int dense0_rows, int k, float two_eps, int final_stage) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wv;
@@ -367,86 +371,54 @@ __global__ __launch_bounds__(256) void select_kernel(uint64_t* __restrict__ cand
         kreg[e] = i < n_in ? c[i] : 0ull;
     }
     const int n_spill = max(0, n_in - SEL_REG * 64);
+    const int n_spill_pad = (n_spill + 63) & ~63;
     for (int i = lane; i < n_spill; i += 64) spill[i] = c[SEL_REG * 64 + i];
     int n_valid = 0;
 #pragma unroll
     for (int e = 0; e < SEL_REG; ++e) n_valid += __popcll(__ballot(kreg[e] != 0ull));
-    for (int i = lane; i < ((n_spill + 63) & ~63); i += 64) n_valid += __popcll(__ballot(i < n_spill && spill[i] != 0ull));
-    const int m = min(n_valid, keep);
-    uint64_t pivot = 1ull;                                   // every valid key is >= 1
-    if (n_valid > keep) {
-        pivot = 0ull;
+    for (int i = lane; i < n_spill_pad; i += 64) n_valid += __popcll(__ballot(i < n_spill && spill[i] != 0ull));
+    const float tau_in = tau[q];
+    float tau_new = tau_in;
+    if (n_valid >= k) {
+        uint64_t pivot = 0ull;                               // becomes (a lower bound of) the k-th largest key
         for (int bit = 63; bit >= 0; --bit) {
             const uint64_t trial = pivot | (1ull << bit);
             int ge = 0;
 #pragma unroll
             for (int e = 0; e < SEL_REG; ++e) ge += __popcll(__ballot(kreg[e] >= trial));
-            for (int i = lane; i < ((n_spill + 63) & ~63); i += 64) ge += __popcll(__ballot(i < n_spill && spill[i] >= trial));
-            if (ge >= keep) pivot = trial;
-            if (ge == keep) break;                           // exactly `keep` keys are >= pivot: done
+            for (int i = lane; i < n_spill_pad; i += 64) ge += __popcll(__ballot(i < n_spill && spill[i] >= trial));
+            if (ge >= k) pivot = trial;
+            if (ge == k) break;          // exactly k keys are >= pivot; its score bits are <= the k-th best score: safe
         }
+        tau_new = fmaxf(tau_in, key_score(pivot) - two_eps);
     }
-    // compaction: keys >= pivot first (exactly m of them), the others after (final stage only); track best dropped
-    uint64_t best_dropped = 0ull;
+    // compaction: every valid key with score >= tau_new moves to the front (all keys were loaded before any store)
+    const uint64_t cut = (uint64_t)f32_orderable(tau_new) << 32;
     int n_top = 0;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int e = 0; e < SEL_REG; ++e) {
-        const uint64_t k = kreg[e];
-        const bool top = k != 0ull && k >= pivot;
+        const uint64_t key = kreg[e];
+        const bool top = key != 0ull && key >= cut;
         const uint64_t bt = __ballot(top);
-        if (top) c[n_top + __popcll(bt & lt_mask)] = k;
-        if (k != 0ull && k < pivot) best_dropped = best_dropped > k ? best_dropped : k;
+        if (top) c[n_top + __popcll(bt & lt_mask)] = key;
         n_top += __popcll(bt);
     }
     for (int i0 = 0; i0 < n_spill; i0 += 64) {
         const int i = i0 + lane;
-        const uint64_t k = i < n_spill ? spill[i] : 0ull;
-        const bool top = k != 0ull && k >= pivot;
+        const uint64_t key = i < n_spill ? spill[i] : 0ull;
+        const bool top = key != 0ull && key >= cut;
         const uint64_t bt = __ballot(top);
-        if (top) c[n_top + __popcll(bt & lt_mask)] = k;
-        if (k != 0ull && k < pivot) best_dropped = best_dropped > k ? best_dropped : k;
+        if (top) c[n_top + __popcll(bt & lt_mask)] = key;
         n_top += __popcll(bt);
     }
-    if (final_stage) {                                       // second pass: append the non-shortlisted valid keys
-        int pos = m;
-#pragma unroll
-        for (int e = 0; e < SEL_REG; ++e) {
-            const uint64_t k = kreg[e];
-            const bool rest = k != 0ull && k < pivot;
-            const uint64_t br = __ballot(rest);
-            if (rest) c[pos + __popcll(br & lt_mask)] = k;
-            pos += __popcll(br);
-        }
-        for (int i0 = 0; i0 < n_spill; i0 += 64) {
-            const int i = i0 + lane;
-            const uint64_t k = i < n_spill ? spill[i] : 0ull;
-            const bool rest = k != 0ull && k < pivot;
-            const uint64_t br = __ballot(rest);
-            if (rest) c[pos + __popcll(br & lt_mask)] = k;
-            pos += __popcll(br);
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint64_t other = __shfl_xor(best_dropped, o);
-        best_dropped = best_dropped > other ? best_dropped : other;
-    }
     if (lane == 0) {
-        const float tau_in = tau[q];
-        // bound[] starts at -inf; an overflow at ANY stage lost candidates for good -> sticky +inf:
-        // nothing can be proven from the buffer, the query goes to the exact scan.
-        float bnd = bound[q];
-        if (overflow) bnd = INFINITY;
-        if (final_stage) {
-            bnd = fmaxf(bnd, tau_in);
-            if (n_valid > m) bnd = fmaxf(bnd, key_score(best_dropped));
-            n_sorted[q] = n_valid;
-        }
-        bound[q] = bnd;
-        cnt[q] = (unsigned)m;
-        // the K'-th best score seen so far is a lower bound of the final K'-th best: safe emission threshold
-        tau[q] = (m == keep) ? fmaxf(key_score(pivot), tau_in) : tau_in;
+        // bound[] starts at -inf; an overflow at ANY stage lost candidates for good -> sticky +inf: the query goes to the
+        // exact scan.
+        if (overflow) bound[q] = INFINITY;
+        if (final_stage) n_sorted[q] = n_top;
+        cnt[q] = (unsigned)n_top;
+        tau[q] = tau_new;
     }
 }
 
@@ -476,38 +448,42 @@ __device__ __forceinline__ double exact_cosine_wave(const float* __restrict__ qv
 
 __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ q32, const float* __restrict__ emb32,
                                                        const uint64_t* __restrict__ cand, const int* __restrict__ n_sorted,
-                                                       double* __restrict__ exact, int dim, int keep) {
+                                                       double* __restrict__ exact, int dim) {
     const int q = blockIdx.y;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int m = min(n_sorted[q], keep);
-    if (j >= m) return;
-    const uint32_t row = key_row(cand[(size_t)q * RAG_CAND_CAP + j]);
-    const double c = exact_cosine_wave(q32 + (size_t)q * dim, emb32 + (size_t)row * dim, dim, lane);
-    if (lane == 0) exact[(size_t)q * RAG_CAND_CAP + j] = c;
+    const int m = n_sorted[q];
+    for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < m; j += gridDim.x * 4) {
+        const uint32_t row = key_row(cand[(size_t)q * RAG_CAND_CAP + j]);
+        const double c = exact_cosine_wave(q32 + (size_t)q * dim, emb32 + (size_t)row * dim, dim, lane);
+        if (lane == 0) exact[(size_t)q * RAG_CAND_CAP + j] = c;
+    }
 }
 
-// order by (exact desc, row asc); write top-k; prove exactness against `bound`.
+// order the survivors by (exact desc, row asc) and write the top-k. Up to RAG_MAX_K survivors are ranked here; more
+// (tight clusters / many duplicates) go to wide_kernel, an overflowed buffer to the exact scan.
 __global__ __launch_bounds__(256) void finalize_kernel(const uint64_t* __restrict__ cand, const int* __restrict__ n_sorted,
                                                         const double* __restrict__ exact, const float* __restrict__ bound,
-                                                        const int64_t* __restrict__ ids, int64_t id_base, int keep, int k,
-                                                        double eps, int force_level, int64_t* __restrict__ ids_out,
+                                                        const int64_t* __restrict__ ids, int64_t id_base, int k,
+                                                        int force_level, int64_t* __restrict__ ids_out,
                                                         int32_t* __restrict__ rows_out, double* __restrict__ scores_out,
                                                         int* __restrict__ flag, int* __restrict__ stats) {
     __shared__ double sc[RAG_MAX_K];
     __shared__ uint32_t rw[RAG_MAX_K];
-    __shared__ double kth;
     const int q = blockIdx.x, tid = threadIdx.x;
-    const int m = min(n_sorted[q], keep);
-    if (tid < m) {
-        sc[tid] = exact[(size_t)q * RAG_CAND_CAP + tid];
-        rw[tid] = key_row(cand[(size_t)q * RAG_CAND_CAP + tid]);
-    }
-    if (tid == 0) kth = -INFINITY;
+    const int m = n_sorted[q];
     for (int i = tid; i < k; i += 256) {
         ids_out[(size_t)q * k + i] = -1;
         if (rows_out) rows_out[(size_t)q * k + i] = -1;
         scores_out[(size_t)q * k + i] = 0.0;
+    }
+    const bool overflowed = bound[q] == INFINITY;
+    if (overflowed || m > RAG_MAX_K || force_level > 0) {
+        if (tid == 0) flag[q] = (overflowed || force_level > 1) ? 2 : 1;
+        return;
+    }
+    if (tid < m) {
+        sc[tid] = exact[(size_t)q * RAG_CAND_CAP + tid];
+        rw[tid] = key_row(cand[(size_t)q * RAG_CAND_CAP + tid]);
     }
     __syncthreads();
     if (tid < m) {
@@ -520,51 +496,31 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint64_t* __restric
             if (rows_out) rows_out[(size_t)q * k + rank] = (int32_t)r;
             scores_out[(size_t)q * k + rank] = e;
         }
-        if (rank == k - 1) kth = e;
     }
-    __syncthreads();
     if (tid == 0) {
-        const float b = bound[q];
-        bool proven = (b == -INFINITY) || (m >= k && kth > (double)b + eps);
-        if (force_level > 0) proven = false;
-        flag[q] = proven ? 0 : 1;
-        if (proven) atomicAdd(&stats[0], 1);
+        flag[q] = 0;
+        atomicAdd(&stats[0], 1);
     }
 }
 
-// L2: rescore the WHOLE candidate buffer of an unproven query; bound = last emission threshold.
-__global__ __launch_bounds__(512) void wide_kernel(const float* __restrict__ q32, const float* __restrict__ emb32,
-                                                    const uint64_t* __restrict__ cand, const int* __restrict__ n_sorted,
-                                                    double* __restrict__ exact, const float* __restrict__ tau_last,
-                                                    const float* __restrict__ bound, const int64_t* __restrict__ ids,
-                                                    int64_t id_base, int dim, int keep, int k, double eps, int force_level,
-                                                    int64_t* __restrict__ ids_out, int32_t* __restrict__ rows_out,
-                                                    double* __restrict__ scores_out, int* __restrict__ flag,
-                                                    int* __restrict__ stats) {
+// Wide path: more than RAG_MAX_K survivors (already rescored): rank all of them (up to the buffer capacity).
+__global__ __launch_bounds__(512) void wide_kernel(const uint64_t* __restrict__ cand, const int* __restrict__ n_sorted,
+                                                    const double* __restrict__ exact, const int64_t* __restrict__ ids,
+                                                    int64_t id_base, int k, int64_t* __restrict__ ids_out,
+                                                    int32_t* __restrict__ rows_out, double* __restrict__ scores_out,
+                                                    int* __restrict__ flag, int* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sc = reinterpret_cast<double*>(smem);                       // [cap]
     uint32_t* rw = reinterpret_cast<uint32_t*>(smem + RAG_CAND_CAP * 8);   // [cap]
-    __shared__ double kth;
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int q = blockIdx.x, tid = threadIdx.x;
     if (flag[q] != 1) return;
     const int n = n_sorted[q];
-    const bool overflowed = bound[q] == INFINITY;
-    if (n <= keep || overflowed || force_level > 1) {      // nothing more to learn from the buffer
-        if (tid == 0) flag[q] = 2;
-        return;
-    }
     const uint64_t* c = cand + (size_t)q * RAG_CAND_CAP;
-    double* ex = exact + (size_t)q * RAG_CAND_CAP;
-    for (int j = keep + wv; j < n; j += 8) {
-        const double v = exact_cosine_wave(q32 + (size_t)q * dim, emb32 + (size_t)key_row(c[j]) * dim, dim, lane);
-        if (lane == 0) ex[j] = v;
-    }
-    __syncthreads();
+    const double* ex = exact + (size_t)q * RAG_CAND_CAP;
     for (int i = tid; i < n; i += 512) {
         sc[i] = ex[i];
         rw[i] = key_row(c[i]);
     }
-    if (tid == 0) kth = -INFINITY;
     __syncthreads();
     for (int i = tid; i < n; i += 512) {
         const double e = sc[i];
@@ -575,15 +531,12 @@ __global__ __launch_bounds__(512) void wide_kernel(const float* __restrict__ q32
             ids_out[(size_t)q * k + rank] = ids ? ids[r] : id_base + (int64_t)r;
             if (rows_out) rows_out[(size_t)q * k + rank] = (int32_t)r;
             scores_out[(size_t)q * k + rank] = e;
-            if (rank == k - 1) kth = e;
         }
     }
     __syncthreads();
     if (tid == 0) {
-        const float b = tau_last[q];
-        const bool proven = (b == -INFINITY) || (n >= k && kth > (double)b + eps);
-        flag[q] = proven ? 0 : 2;
-        if (proven) atomicAdd(&stats[1], 1);
+        flag[q] = 0;
+        atomicAdd(&stats[1], 1);
     }
 }
 
@@ -719,7 +672,7 @@ static int ensure_workspace(rag_ctx* h, int Q) {
     HIP_TRY(h, hipMalloc(&h->q16, (size_t)qpad * h->dim_pad * sizeof(half_t)));
     HIP_TRY(h, hipMalloc(&h->cand, (size_t)qpad * RAG_CAND_CAP * sizeof(uint64_t)));
     HIP_TRY(h, hipMalloc(&h->cnt, (size_t)qpad * sizeof(unsigned)));
-    HIP_TRY(h, hipMalloc(&h->tau, 2 * (size_t)qpad * sizeof(float)));      // [tau | tau_last]
+    HIP_TRY(h, hipMalloc(&h->tau, (size_t)qpad * sizeof(float)));
     HIP_TRY(h, hipMalloc(&h->bound, (size_t)qpad * sizeof(float)));
     HIP_TRY(h, hipMalloc(&h->n_sorted, (size_t)qpad * sizeof(int)));
     HIP_TRY(h, hipMalloc(&h->exact, (size_t)qpad * RAG_CAND_CAP * sizeof(double)));
@@ -769,7 +722,7 @@ static double fp16_pass_eps(int dim_pad) {
     return (2 * u16 + u16 * u16) * 1.01 + 2.0 * dim_pad * u32 + 8 * u32 + 2e-6;
 }
 
-static int shortlist_for(int k) {
+static int shortlist_for_unused(int k) {
     int kp = std::max(32, (int)round_up(2 * k + 8, 16));        // k=20 -> 48: gap to the 48th neighbour >> eps on typical data
     return std::min(kp, RAG_MAX_K);
 }
@@ -782,12 +735,11 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
     int rc = ensure_workspace(h, Q);
     if (rc) return rc;
     const int32_t* tenants = tenant >= 0 ? h->tenants : nullptr;
-    const int keep = shortlist_for(k);
     const double eps = fp16_pass_eps(h->dim_pad);
+    const float two_eps = (float)(2.0 * eps * 1.0001 + 1e-7);        // float subtraction in the select kernel: round up
     const int qpad = (int)round_up(Q, RAG_TILE);
     const int n_qtiles = qpad / RAG_TILE;
     float* tau = h->tau;
-    float* tau_last = h->tau + round_up(h->ws_q, RAG_TILE);
     const char* fl = getenv("RAG_FORCE_LEVEL");
     const int force_level = fl ? atoi(fl) : 0;
 
@@ -799,7 +751,6 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
     HIP_TRY(h, hipMemsetAsync(h->stats, 0, 8 * sizeof(int), st));
     HIP_TRY(h, hipMemsetAsync(h->cnt, 0, (size_t)qpad * sizeof(unsigned), st));
     hipLaunchKernelGGL(fill_f32_kernel, dim3((qpad + 255) / 256), dim3(256), 0, st, tau, -INFINITY, qpad);
-    hipLaunchKernelGGL(fill_f32_kernel, dim3((qpad + 255) / 256), dim3(256), 0, st, tau_last, -INFINITY, qpad);
     hipLaunchKernelGGL(fill_f32_kernel, dim3((qpad + 255) / 256), dim3(256), 0, st, h->bound, -INFINITY, qpad);
 
     static bool attr_set = false;
@@ -831,8 +782,6 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
             // dense slots: clear stage-0 slots so filtered / padded rows read as empty
             HIP_TRY(h, hipMemset2DAsync(h->cand, RAG_CAND_CAP * sizeof(uint64_t), 0,
                                         (size_t)stage0_tiles * RAG_TILE * sizeof(uint64_t), qpad, st));
-        } else {
-            HIP_TRY(h, hipMemcpyAsync(tau_last, tau, (size_t)qpad * sizeof(float), hipMemcpyDeviceToDevice, st));
         }
         if (h->profiling && stage > 0) {      // the thresholded kernel only (stage 0 is 0.2% of the rows)
             if ((int)h->gemm_events.size() <= h->gemm_events_used) {
@@ -856,23 +805,21 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
         }
         const bool last = end == total_tiles;
         hipLaunchKernelGGL(select_kernel, dim3((Q + 3) / 4), dim3(256), SELECT_LDS_BYTES, st, h->cand, h->cnt, tau, h->bound,
-                           h->n_sorted, h->stats, Q, stage == 0 ? stage0_tiles * RAG_TILE : 0, keep, last ? 1 : 0);
+                           h->n_sorted, h->stats, Q, stage == 0 ? stage0_tiles * RAG_TILE : 0, k, two_eps, last ? 1 : 0);
         HIP_TRY(h, hipGetLastError());
         begin = end;
         ++stage;
     }
     if (total_tiles == 0) {   // empty index: nothing found
         hipLaunchKernelGGL(select_kernel, dim3((Q + 3) / 4), dim3(256), SELECT_LDS_BYTES, st, h->cand, h->cnt, tau, h->bound,
-                           h->n_sorted, h->stats, Q, 0, keep, 1);
+                           h->n_sorted, h->stats, Q, 0, k, two_eps, 1);
     }
 
-    hipLaunchKernelGGL(rescore_kernel, dim3((keep + 3) / 4, Q), dim3(256), 0, st, q_dev, h->emb32, h->cand, h->n_sorted,
-                       h->exact, h->dim, keep);
-    hipLaunchKernelGGL(finalize_kernel, dim3(Q), dim3(256), 0, st, h->cand, h->n_sorted, h->exact, h->bound, h->ids,
-                       h->id_base, keep, k, eps, force_level, ids_dev, rows_dev, scores_dev, h->flag, h->stats);
-    hipLaunchKernelGGL(wide_kernel, dim3(Q), dim3(512), RAG_CAND_CAP * 12, st, q_dev, h->emb32, h->cand, h->n_sorted,
-                       h->exact, tau_last, h->bound, h->ids, h->id_base, h->dim, keep, k, eps, force_level, ids_dev,
-                       rows_dev, scores_dev, h->flag, h->stats);
+    hipLaunchKernelGGL(rescore_kernel, dim3(16, Q), dim3(256), 0, st, q_dev, h->emb32, h->cand, h->n_sorted, h->exact, h->dim);
+    hipLaunchKernelGGL(finalize_kernel, dim3(Q), dim3(256), 0, st, h->cand, h->n_sorted, h->exact, h->bound, h->ids, h->id_base, k,
+                       force_level, ids_dev, rows_dev, scores_dev, h->flag, h->stats);
+    hipLaunchKernelGGL(wide_kernel, dim3(Q), dim3(512), RAG_CAND_CAP * 12, st, h->cand, h->n_sorted, h->exact, h->ids, h->id_base, k,
+                       ids_dev, rows_dev, scores_dev, h->flag, h->stats);
     HIP_TRY(h, hipGetLastError());
     // exact scan for whatever is still unproven (device-side early exit when nothing is flagged)
     if (h->n_rows > 0) {
@@ -898,7 +845,7 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
     h->last_q = Q;
     h->last_k = k;
     h->last_stages = stage;
-    h->last_shortlist = keep;
+    h->last_shortlist = k;
     h->last_eps = eps;
     h->last_stats_valid = true;
     return RAG_OK;
