@@ -15,7 +15,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define RAG_CAND_CAP 4096        // per-query candidate buffer entries (u64 keys)
 #define RAG_STAGE0_ROWS 2048     // rows whose scores are stored densely (no threshold yet)
-#define RAG_STAGE_GROWTH 8       // each threshold stage covers ~8x the rows seen so far (32x measured slower: more emission)
+#define RAG_STAGE_GROWTH 8       // each threshold stage covers ~8x the rows seen so far (RAG_STAGE_GROWTH env overrides, for tuning)
 #define RAG_TILE 256             // GEMM tile edge (corpus rows x queries)
 #define RAG_BK 64                // K-slice per LDS stage (halfs)
 #define RAG_MAX_K 256            // largest k / shortlist supported by the select kernels

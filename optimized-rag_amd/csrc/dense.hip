@@ -266,9 +266,10 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    // every dense slot is written (0 = empty for padded / filtered rows): no memset needed beforehand
                     const int row = row0 + wm * 128 + i * 16 + fq * 4 + r;
-                    if (row < n_rows_valid && (tenants == nullptr || tenants[row] == tenant))
-                        cand[(size_t)q * RAG_CAND_CAP + row] = make_key(acc[i][j][r] * scale, (uint32_t)row);
+                    const bool ok = row < n_rows_valid && (tenants == nullptr || tenants[row] == tenant);
+                    cand[(size_t)q * RAG_CAND_CAP + row] = ok ? make_key(acc[i][j][r] * scale, (uint32_t)row) : 0ull;
                 }
         }
         return;
@@ -653,9 +654,16 @@ __global__ __launch_bounds__(256) void scan_merge_kernel(const uint64_t* __restr
     }
 }
 
-__global__ void fill_f32_kernel(float* p, float v, int n) {
+// per-search state in one launch: thresholds / proof bounds to -inf, candidate counters and statistics to 0
+__global__ void search_init_kernel(float* __restrict__ tau, float* __restrict__ bound, unsigned* __restrict__ cnt,
+                                   int* __restrict__ stats, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
+    if (i < n) {
+        tau[i] = -INFINITY;
+        bound[i] = -INFINITY;
+        cnt[i] = 0u;
+    }
+    if (i < 8) stats[i] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -748,10 +756,7 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
         HIP_TRY(h, hipMemsetAsync(h->q16 + (size_t)Q * h->dim_pad, 0, (size_t)(qpad - Q) * h->dim_pad * sizeof(half_t), st));
     hipLaunchKernelGGL(normalize_rows_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, q_dev, h->q16, (int64_t)Q, h->dim,
                        h->dim_pad, (int*)nullptr);
-    HIP_TRY(h, hipMemsetAsync(h->stats, 0, 8 * sizeof(int), st));
-    HIP_TRY(h, hipMemsetAsync(h->cnt, 0, (size_t)qpad * sizeof(unsigned), st));
-    hipLaunchKernelGGL(fill_f32_kernel, dim3((qpad + 255) / 256), dim3(256), 0, st, tau, -INFINITY, qpad);
-    hipLaunchKernelGGL(fill_f32_kernel, dim3((qpad + 255) / 256), dim3(256), 0, st, h->bound, -INFINITY, qpad);
+    hipLaunchKernelGGL(search_init_kernel, dim3((qpad + 255) / 256), dim3(256), 0, st, tau, h->bound, h->cnt, h->stats, qpad);
 
     static bool attr_set = false;
     if (!attr_set) {
@@ -769,20 +774,16 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
     // ---- stage schedule over row tiles: [0, 2048), then ~8x growth each -------------------------
     const int total_tiles = (int)(round_up(h->n_rows, RAG_TILE) / RAG_TILE);
     const int stage0_tiles = std::min(total_tiles, RAG_STAGE0_ROWS / RAG_TILE);
+    static const int growth = [] { const char* g = getenv("RAG_STAGE_GROWTH"); const int v = g ? atoi(g) : 0; return v >= 2 ? v : RAG_STAGE_GROWTH; }();
     int begin = 0, stage = 0;
     while (begin < total_tiles) {
         int end;
         if (stage == 0) end = stage0_tiles;
-        else end = (int)std::min<int64_t>(total_tiles, (int64_t)begin * RAG_STAGE_GROWTH);
+        else end = (int)std::min<int64_t>(total_tiles, (int64_t)begin * growth);
         // avoid a tiny trailing stage
         if (total_tiles - end < end / 4) end = total_tiles;
         const int n_rt = end - begin;
         const int grid = (int)round_up(n_rt, 8) * n_qtiles;
-        if (stage == 0) {
-            // dense slots: clear stage-0 slots so filtered / padded rows read as empty
-            HIP_TRY(h, hipMemset2DAsync(h->cand, RAG_CAND_CAP * sizeof(uint64_t), 0,
-                                        (size_t)stage0_tiles * RAG_TILE * sizeof(uint64_t), qpad, st));
-        }
         if (h->profiling && stage > 0) {      // the thresholded kernel only (stage 0 is 0.2% of the rows)
             if ((int)h->gemm_events.size() <= h->gemm_events_used) {
                 hipEvent_t a, b;
