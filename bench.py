@@ -86,20 +86,26 @@ def main():
 
     from optimized_rag_amd import RagEngine
     Q, k = args.queries, args.k
-    n_chunks = 8
-    chunk_rows = args.rows // n_chunks
-    assert args.rows % n_chunks == 0 and n_chunks % world == 0
+    # the corpus is generated in seeded 125,000-row chunks (identical for every N) and appended chunk by chunk, so a
+    # 12.5M-row shard (the per-GPU share of the 100M x 8 config) never exists twice in memory
+    chunk_rows = CHUNK_ROWS
+    assert args.rows % (chunk_rows * world) == 0, "rows must be a multiple of 125000 * n_gpus"
+    n_chunks = args.rows // chunk_rows
     my_chunks = list(range(rank * n_chunks // world, (rank + 1) * n_chunks // world))
-    shard = torch.cat([gen_chunk(c, chunk_rows, device) for c in my_chunks])
+    n_local = len(my_chunks) * chunk_rows
     id_base = my_chunks[0] * chunk_rows
     eng = RagEngine(dim=DIM, device=local_rank)
-    eng.index_load(shard, id_base=id_base)
-    n_local = shard.shape[0]
+    eng.index_reserve(n_local, id_base=id_base)
+    host_parts = [] if (rank == 0 and world == 1 and not args.no_cpu_baseline and args.rows <= 2_000_000) else None
+    for c in my_chunks:
+        blk = gen_chunk(c, chunk_rows, device)
+        eng.index_append(blk)
+        if host_parts is not None:
+            host_parts.append(blk.cpu())
+        del blk
     queries, planted = gen_queries(Q, args.rows, n_chunks, chunk_rows, device)
-    host_corpus = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        host_corpus = shard.cpu()
-    del shard
+    host_corpus = torch.cat(host_parts) if host_parts else None
+    del host_parts
     torch.cuda.empty_cache()
 
     from optimized_rag_amd.sharded import ShardedDenseIndex
@@ -169,6 +175,7 @@ def main():
 
     # ---- roofline of the dominant kernel: dense_emit_kernel<false> (the thresholded GEMM stages) -----------
     stage0_rows = min(n_local, 2048)
+    roof_bytes_note = None
     dim_pad = (DIM + 63) // 64 * 64
     qpad = (Q + 255) // 256 * 256
     flops_per_step = 2.0 * qpad * (n_local - stage0_rows) * dim_pad            # algorithmic, per step, this rank

@@ -10,8 +10,10 @@
  *   - every function returns 0 on success, <0 on error; rag_last_error(h) gives the message.
  *   - plain pointers and sizes only; the caller owns every buffer; nothing throws across the ABI.
  *   - "_host" pointers are host memory (copied over PCIe inside the call, call is synchronous);
- *     "_dev"  pointers are device memory on the handle's GPU; those calls are asynchronous on `stream`
- *     (a hipStream_t passed as void*, NULL = the handle's own stream).
+ *     "_dev"  pointers are device memory on the handle's GPU; those calls are asynchronous on `stream`, a
+ *     hipStream_t passed as void*. NULL means the DEFAULT (null) stream, exactly as in HIP itself — frameworks
+ *     whose current stream is the default stream (PyTorch) pass 0 and get correct ordering with their own work.
+ *     The handle's private stream is only used by the synchronous *_host entry points.
  *   - one handle = one GPU = one process rank. Concurrent calls on one handle must be serialised by
  *     the caller (the reference graph is single-threaded, agent/rag_graph.py:506).
  *   - doc ids are int64 (SQL BIGSERIAL ids, database/migrations/001_initial_schema.sql); scores are
@@ -53,6 +55,13 @@ int rag_index_load_host(rag_handle_t h, const float* emb_host, const int64_t* id
                         int64_t n_rows);
 int rag_index_load_dev(rag_handle_t h, const float* emb_dev, const int64_t* ids_dev, int64_t id_base,
                        int64_t n_rows, void* stream);
+/* Chunked bulk load for shards that should not exist twice in memory (12.5M rows = 115 GB resident): reserve once,
+ * append row blocks in order (host or device source), search at any time over the rows appended so far.
+ * The bulk export of `document_chunks(id, agent_id, content, embedding)` (rag/document_store.py:210-221) maps onto
+ * this directly. */
+int rag_index_reserve(rag_handle_t h, int64_t n_rows_total, int64_t id_base);
+int rag_index_append_host(rag_handle_t h, const float* emb_host, int64_t n_rows);
+int rag_index_append_dev(rag_handle_t h, const float* emb_dev, int64_t n_rows, void* stream);
 /* Optional multi-tenant filter: tenant_of_row[n_rows] (the `WHERE dc.agent_id = %s`,
  * rag/document_store.py:457). tenant < 0 in a search = no filter. */
 int rag_index_set_tenants_host(rag_handle_t h, const int32_t* tenant_of_row_host, int64_t n_rows);

@@ -47,6 +47,9 @@ _SIGS = {
     "rag_set_profiling": ([_P, C.c_int], C.c_int),
     "rag_index_load_host": ([_P, _P, _P, C.c_int64, C.c_int64], C.c_int),
     "rag_index_load_dev": ([_P, _P, _P, C.c_int64, C.c_int64, _P], C.c_int),
+    "rag_index_reserve": ([_P, C.c_int64, C.c_int64], C.c_int),
+    "rag_index_append_host": ([_P, _P, C.c_int64], C.c_int),
+    "rag_index_append_dev": ([_P, _P, C.c_int64, _P], C.c_int),
     "rag_index_set_tenants_host": ([_P, _P, C.c_int64], C.c_int),
     "rag_index_rows": ([_P, C.POINTER(C.c_int64)], C.c_int),
     "rag_index_fetch_rows_host": ([_P, _P, C.c_int, _P], C.c_int),
@@ -184,6 +187,23 @@ class RagEngine:
         self._check(self.lib.rag_index_load_host(self.h, _ptr(emb), _ptr(ida), int(id_base), emb.shape[0]),
                     "rag_index_load_host")
         self.n_rows = int(emb.shape[0])
+
+    def index_reserve(self, n_rows_total, id_base=0):
+        self._check(self.lib.rag_index_reserve(self.h, int(n_rows_total), int(id_base)), "rag_index_reserve")
+        self.n_rows = 0
+
+    def index_append(self, emb):
+        """Append a block of rows (numpy host array or torch CUDA tensor) to a reserved index."""
+        if _is_torch(emb):
+            import torch
+            assert emb.is_cuda and emb.dtype == torch.float32 and emb.is_contiguous() and emb.shape[1] == self.dim
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self._check(self.lib.rag_index_append_dev(self.h, C.c_void_p(emb.data_ptr()), emb.shape[0], st), "rag_index_append_dev")
+            torch.cuda.current_stream().synchronize()
+        else:
+            emb = _np(emb, np.float32)
+            self._check(self.lib.rag_index_append_host(self.h, _ptr(emb), emb.shape[0]), "rag_index_append_host")
+        self.n_rows += int(emb.shape[0])
 
     def set_tenants(self, tenant_of_row):
         t = None if tenant_of_row is None else _np(tenant_of_row, np.int32)

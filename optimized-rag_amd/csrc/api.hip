@@ -125,7 +125,51 @@ int rag_index_load_host(rag_handle_t h, const float* emb_host, const int64_t* id
 int rag_index_load_dev(rag_handle_t h, const float* emb_dev, const int64_t* ids_dev, int64_t id_base, int64_t n_rows,
                        void* stream) {
     if (!h) return RAG_ERR_ARG;
-    return index_load_common(h, emb_dev, ids_dev, id_base, n_rows, stream ? (hipStream_t)stream : h->stream, false);
+    return index_load_common(h, emb_dev, ids_dev, id_base, n_rows, (hipStream_t)stream, false);
+}
+
+// ---- chunked bulk load (export of document_chunks / archival_memory in pieces) -------------------
+int rag_index_reserve(rag_handle_t h, int64_t n_rows_total, int64_t id_base) {
+    if (!h) return RAG_ERR_ARG;
+    ARG_CHECK(h, n_rows_total > 0 && n_rows_total < (int64_t)0x7fffff00, "n_rows must fit int32 per GPU");
+    HIP_TRY(h, hipSetDevice(h->device));
+    dense_free(h);
+    h->id_base = id_base;
+    h->n_reserved = n_rows_total;
+    h->n_rows_pad = round_up(n_rows_total, (int64_t)RAG_TILE * 8);
+    HIP_TRY(h, hipMalloc(&h->emb32, (size_t)n_rows_total * h->dim * sizeof(float)));
+    HIP_TRY(h, hipMalloc(&h->emb16, (size_t)h->n_rows_pad * h->dim_pad * sizeof(half_t)));
+    HIP_TRY(h, hipMalloc(&h->bad_rows, sizeof(int)));
+    HIP_TRY(h, hipMemsetAsync(h->bad_rows, 0, sizeof(int), h->stream));
+    // rows not appended yet (and the tile padding) must read as zero vectors
+    HIP_TRY(h, hipMemsetAsync(h->emb16, 0, (size_t)h->n_rows_pad * h->dim_pad * sizeof(half_t), h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return RAG_OK;
+}
+
+static int index_append(rag_ctx* h, const float* emb, int64_t n, hipStream_t st, bool host) {
+    ARG_CHECK(h, h->n_reserved > 0, "rag_index_reserve first");
+    ARG_CHECK(h, n >= 0 && h->n_rows + n <= h->n_reserved, "append exceeds the reserved row count");
+    ARG_CHECK(h, n == 0 || emb != nullptr, "emb is null");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (n == 0) return RAG_OK;
+    HIP_TRY(h, hipMemcpyAsync(h->emb32 + (size_t)h->n_rows * h->dim, emb, (size_t)n * h->dim * sizeof(float),
+                              host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+    int rc = dense_index_normalize_range(h, h->n_rows, n, st);
+    if (rc) return rc;
+    h->n_rows += n;
+    if (host) HIP_TRY(h, hipStreamSynchronize(st));
+    return RAG_OK;
+}
+
+int rag_index_append_host(rag_handle_t h, const float* emb_host, int64_t n_rows) {
+    if (!h) return RAG_ERR_ARG;
+    return index_append(h, emb_host, n_rows, h->stream, true);
+}
+
+int rag_index_append_dev(rag_handle_t h, const float* emb_dev, int64_t n_rows, void* stream) {
+    if (!h) return RAG_ERR_ARG;
+    return index_append(h, emb_dev, n_rows, (hipStream_t)stream, false);
 }
 
 int rag_index_set_tenants_host(rag_handle_t h, const int32_t* t, int64_t n_rows) {
@@ -166,7 +210,7 @@ int rag_dense_topk_dev(rag_handle_t h, const float* q_dev, int Q, int k, int ten
     ARG_CHECK(h, q_dev && ids_dev && scores_dev, "null pointer");
     ARG_CHECK(h, Q > 0 && Q <= 65535, "1 <= n_queries <= 65535");
     HIP_TRY(h, hipSetDevice(h->device));
-    return dense_search(h, q_dev, Q, k, tenant, ids_dev, rows_dev, scores_dev, stream ? (hipStream_t)stream : h->stream);
+    return dense_search(h, q_dev, Q, k, tenant, ids_dev, rows_dev, scores_dev, (hipStream_t)stream);
 }
 
 int rag_dense_topk_host(rag_handle_t h, const float* q_host, int Q, int k, int tenant, int64_t* ids_out, int32_t* rows_out,
@@ -252,7 +296,7 @@ int rag_merge_topk_dev(rag_handle_t h, const int64_t* ids_dev, const double* sco
     ARG_CHECK(h, ids_dev && scores_dev && ids_out_dev && scores_out_dev, "null pointer");
     HIP_TRY(h, hipSetDevice(h->device));
     return merge_topk(h, ids_dev, scores_dev, n_lists, list_stride, Q, k, ids_out_dev, scores_out_dev,
-                      stream ? (hipStream_t)stream : h->stream);
+                      (hipStream_t)stream);
 }
 
 int rag_pairwise_cosine_host(rag_handle_t h, const float* a, int m, const float* b, int n, int dim, double* out) {
@@ -317,7 +361,7 @@ int rag_bm25_topk_dev(rag_handle_t h, const int32_t* term_ptr_dev, const int32_t
     if (!h) return RAG_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     return bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, k, ids_dev, rows_dev, scores_dev, raw_max_dev,
-                         stream ? (hipStream_t)stream : h->stream);
+                         (hipStream_t)stream);
 }
 
 int rag_rrf_fuse_dev(rag_handle_t h, const int64_t* lists_dev, int Q, int L, int len, int rrf_k, int top_k, int64_t* keys_dev,
@@ -325,7 +369,7 @@ int rag_rrf_fuse_dev(rag_handle_t h, const int64_t* lists_dev, int Q, int L, int
     if (!h) return RAG_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     return rrf_fuse_dev(h, lists_dev, Q, L, len, len, (int64_t)L * len, rrf_k, top_k, keys_dev, scores_dev, ranks_dev,
-                        stream ? (hipStream_t)stream : h->stream);
+                        (hipStream_t)stream);
 }
 
 // dense top-pool + BM25 top-pool + RRF -> top-k, all on the device, one call (BASELINE.json configs[2]).
@@ -338,7 +382,7 @@ int rag_hybrid_rrf_dev(rag_handle_t h, const float* q_dev, const int32_t* term_p
     ARG_CHECK(h, q_dev && term_ptr_dev && lists_ws_dev && scores_ws_dev && keys_out_dev && rrf_out_dev, "hybrid: null pointer");
     ARG_CHECK(h, pool > 0 && pool <= RAG_MAX_K && k > 0, "hybrid: 0 < pool <= 256");
     HIP_TRY(h, hipSetDevice(h->device));
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t st = (hipStream_t)stream;
     int rc = dense_search(h, q_dev, Q, pool, tenant, lists_ws_dev, nullptr, scores_ws_dev, st);
     if (rc) return rc;
     rc = bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, lists_ws_dev + (size_t)Q * pool, nullptr, scores_ws_dev, nullptr, st);
@@ -368,7 +412,7 @@ int rag_ce_score_dev(rag_handle_t h, const int32_t* ids, const int32_t* tt, cons
                      void* stream) {
     if (!h) return RAG_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
-    return ce_score(h, ids, tt, lens, P, L, out, stream ? (hipStream_t)stream : h->stream, false);
+    return ce_score(h, ids, tt, lens, P, L, out, (hipStream_t)stream, false);
 }
 
 }  // extern "C"

@@ -34,6 +34,7 @@ struct rag_ctx {
 
     // dense index
     int64_t n_rows = 0, n_rows_pad = 0, id_base = 0;
+    int64_t n_reserved = 0;      // rows allocated by rag_index_reserve (chunked bulk load), 0 otherwise
     float* emb32 = nullptr;      // [n_rows][dim]        fp32 master rows
     half_t* emb16 = nullptr;     // [n_rows_pad][dim_pad] fp16 (2^7 * unit rows), zero padded
     int64_t* ids = nullptr;      // [n_rows] or null
@@ -113,6 +114,7 @@ __host__ __device__ static inline uint64_t f64_orderable(double s) {
 
 // entry points implemented per file
 int dense_index_build(rag_ctx* h, const float* emb_dev, int64_t n_rows, hipStream_t st);
+int dense_index_normalize_range(rag_ctx* h, int64_t first_row, int64_t n_rows, hipStream_t st);
 int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev,
                  double* scores_dev, hipStream_t st);
 int dense_free(rag_ctx* h);

@@ -699,6 +699,7 @@ int dense_free(rag_ctx* h) {
     h->emb32 = nullptr; h->emb16 = nullptr; h->ids = nullptr; h->tenants = nullptr; h->bad_rows = nullptr;
     hipFree(h->scan_scores); h->scan_scores = nullptr; h->scan_rows = 0;
     h->n_rows = h->n_rows_pad = 0;
+    h->n_reserved = 0;
     return RAG_OK;
 }
 
@@ -718,6 +719,16 @@ int dense_index_build(rag_ctx* h, const float* emb_dev, int64_t n_rows, hipStrea
                            h->dim_pad, h->bad_rows);
         HIP_TRY(h, hipGetLastError());
     }
+    return RAG_OK;
+}
+
+// chunked bulk load: fp16 operand rows for master rows [first_row, first_row + n_rows) (already copied into emb32)
+int dense_index_normalize_range(rag_ctx* h, int64_t first_row, int64_t n_rows, hipStream_t st) {
+    if (n_rows <= 0) return RAG_OK;
+    const int grid = (int)std::min<int64_t>((n_rows + 3) / 4, 256 * 16);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3(grid), dim3(256), 0, st, h->emb32 + (size_t)first_row * h->dim,
+                       h->emb16 + (size_t)first_row * h->dim_pad, n_rows, h->dim, h->dim_pad, h->bad_rows);
+    HIP_TRY(h, hipGetLastError());
     return RAG_OK;
 }
 

@@ -176,3 +176,56 @@ def test_merge_topk_equals_unsharded_search(eng_factory):
     oid, osc = O.dense_topk(corpus, queries, k)
     np.testing.assert_array_equal(oi.cpu().numpy(), oid)
     np.testing.assert_allclose(os_.cpu().numpy(), osc, atol=SCORE_TOL)
+
+
+def test_chunked_reserve_append_equals_one_shot_load(eng_factory):
+    """rag_index_reserve + rag_index_append_* (host and device blocks) == rag_index_load; searchable while filling."""
+    import torch
+    rng = np.random.default_rng(12)
+    N, D = 9000, 384
+    corpus = rng.standard_normal((N, D)).astype(np.float32)
+    queries = planted_queries(rng, corpus, 10)
+    eng = eng_factory(D)
+    eng.index_reserve(N, id_base=500)
+    eng.index_append(corpus[:2500])                                       # host block
+    ids, rows, sc = eng.dense_topk(queries, 20)                           # search over the rows appended so far
+    oid, osc = O.dense_topk(corpus[:2500], queries, 20)
+    np.testing.assert_array_equal(rows, oid.astype(np.int32))
+    eng.index_append(torch.from_numpy(corpus[2500:7000]).cuda())          # device block
+    eng.index_append(corpus[7000:])
+    ids, rows, sc = eng.dense_topk(queries, 20)
+    oid, osc = O.dense_topk(corpus, queries, 20)
+    np.testing.assert_array_equal(rows, oid.astype(np.int32))
+    np.testing.assert_array_equal(ids, oid + 500)
+    np.testing.assert_allclose(sc, osc, atol=SCORE_TOL)
+    with pytest.raises(Exception):
+        eng.index_append(corpus[:1])                                      # beyond the reservation: loud error
+
+
+def test_device_entry_points_are_ordered_with_the_callers_stream(eng_factory):
+    """Regression: *_dev calls run on the stream handed in (torch's current stream, which may be the default stream 0).
+    A source buffer that is overwritten right after rag_index_append_dev, and outputs consumed right after
+    rag_dense_topk_dev without any explicit synchronisation, must still see correctly ordered data."""
+    import torch
+    D, blk_rows, n_blk = 256, 20000, 12
+    eng = eng_factory(D)
+    eng.index_reserve(blk_rows * n_blk)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    buf = torch.empty((blk_rows, D), device="cuda")
+    firsts = []
+    for b in range(n_blk):
+        buf.normal_(generator=g)
+        firsts.append(buf[:3].clone())
+        eng.lib.rag_index_append_dev(eng.h, buf.data_ptr(), blk_rows, torch.cuda.current_stream().cuda_stream)
+        eng.n_rows += blk_rows
+        buf.fill_(float(b))                                          # clobber the source immediately
+    want = torch.cat(firsts).cpu().numpy()
+    rows = np.concatenate([np.arange(b * blk_rows, b * blk_rows + 3) for b in range(n_blk)])
+    np.testing.assert_array_equal(eng.fetch_rows(rows), want)
+    q = torch.from_numpy(want[::3].copy()).cuda()                    # one exact copy per block
+    ids = torch.empty((n_blk, 4), dtype=torch.int64, device="cuda")
+    sc = torch.empty((n_blk, 4), dtype=torch.float64, device="cuda")
+    eng.dense_topk_dev(q, 4, ids, None, sc)
+    got = ids[:, 0].clone()                                          # consumer on the same stream, no sync in between
+    assert got.cpu().tolist() == [b * blk_rows for b in range(n_blk)]
