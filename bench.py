@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--mode", default="dense", choices=["dense", "hybrid", "rerank"],
                     help="dense = the headline metric (default); hybrid / rerank = BASELINE configs[2] / [3], single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-query-latency", action="store_true",
+                    help="also time Q=1 searches (off by default so that every launch of the run has the bench shape and "
+                         "rocprofv3's per-kernel averages match the reported ones)")
     ap.add_argument("--cpu-sample-queries", type=int, default=128)
     args = ap.parse_args()
 
@@ -148,7 +151,7 @@ def main():
 
     # single-query latency (what one agent turn sees): Q = 1 through the same entry point, synchronised
     lat1 = None
-    if world == 1:
+    if world == 1 and args.single_query_latency:
         q1 = queries[:1].contiguous()
         i1 = torch.empty((1, k), dtype=torch.int64, device=device)
         s1 = torch.empty((1, k), dtype=torch.float64, device=device)
