@@ -72,8 +72,9 @@ int rag_index_fetch_rows_host(rag_handle_t h, const int64_t* rows_host, int n, f
 /* Exact cosine top-k over the resident index, Q queries at once.
  * Result = what an un-indexed `ORDER BY embedding <=> q LIMIT k` returns: cosine descending, ties by
  * lower row first; ids_out[Q*k] (-1 padded), rows_out[Q*k] local row numbers (may be NULL),
- * scores_out[Q*k] = 1 - distance as float64. Identical id sets to the float64 oracle are PROVEN per
- * query (fp16 MFMA pass + float64 rescore + error-bound check, falling back to an exact scan). */
+ * scores_out[Q*k] = 1 - distance as float64. Identical id sets to the float64 exact scan hold BY CONSTRUCTION:
+ * the fp16 MFMA pass only discards rows whose score is more than 2*eps below the k-th best (eps = proven bound on
+ * the fp16 error), survivors are rescored in float64; a float64 scan of every row is the overflow fallback. */
 int rag_dense_topk_host(rag_handle_t h, const float* q_host, int n_queries, int k, int tenant,
                         int64_t* ids_out_host, int32_t* rows_out_host, double* scores_out_host);
 int rag_dense_topk_dev(rag_handle_t h, const float* q_dev, int n_queries, int k, int tenant,
@@ -82,11 +83,11 @@ int rag_dense_topk_dev(rag_handle_t h, const float* q_dev, int n_queries, int k,
 /* Counters of the last dense search (device counters are read back: synchronises). */
 typedef struct rag_dense_stats {
     int32_t n_queries;
-    int32_t proven_fast;      /* proven exact from the top-K' shortlist */
-    int32_t proven_wide;      /* needed the whole candidate buffer      */
-    int32_t exact_scan;       /* fell back to the float64 full scan     */
-    int32_t overflowed;       /* candidate buffer overflowed            */
-    int32_t shortlist;        /* K'                                     */
+    int32_t proven_fast;      /* <= 256 survivors above tau: ranked in the fast path (exact by construction) */
+    int32_t proven_wide;      /* more survivors (clusters, duplicates): ranked by the wide kernel            */
+    int32_t exact_scan;       /* candidate buffer overflowed: float64 scan of every row                      */
+    int32_t overflowed;       /* overflow events (any stage)                                                 */
+    int32_t shortlist;        /* k (the threshold is the k-th best score so far minus 2*eps)                 */
     int32_t stages;           /* threshold stages used                  */
     int32_t reserved;
     double eps;               /* rigorous |fp16 score - exact| bound    */

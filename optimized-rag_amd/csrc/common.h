@@ -47,16 +47,16 @@ struct rag_ctx {
     half_t* q16 = nullptr;           // [ws_qpad][dim_pad]
     uint64_t* cand = nullptr;        // [ws_qpad][RAG_CAND_CAP]
     unsigned* cnt = nullptr;         // [ws_qpad]   emitted candidates (may exceed cap = overflow)
-    float* tau = nullptr;            // [ws_qpad]   emission threshold (fp16-pass score)
-    float* bound = nullptr;          // [ws_qpad]   proof bound after the final select
-    int* n_sorted = nullptr;         // [ws_qpad]   candidates kept sorted in cand[] after final select
+    float* tau = nullptr;            // [ws_qpad]   emission threshold = k-th best fp16-pass score so far - 2 eps
+    float* bound = nullptr;          // [ws_qpad]   -inf, or +inf once the candidate buffer overflowed (sticky)
+    int* n_sorted = nullptr;         // [ws_qpad]   survivors left in cand[] after the final select
     double* exact = nullptr;         // [ws_qpad][RAG_CAND_CAP] float64 rescored cosines
-    int* flag = nullptr;             // [ws_qpad]   0 proven fast, 1 needs wide, 2 needs exact scan
+    int* flag = nullptr;             // [ws_qpad]   0 done, 1 needs wide ranking, 2 needs exact scan, 3 scanned
     int* stats = nullptr;            // [8] device counters
     // exact-scan fallback workspace
     double* scan_scores = nullptr;   // [n_rows] (allocated on first use)
     int64_t scan_rows = 0;
-    int64_t* out_ids = nullptr;      // [ws_q][RAG_MAX_K] staging for host calls
+    int64_t* out_ids = nullptr;      // (unused staging, kept for ABI-stable struct layout inside the library)
     int32_t* out_rows = nullptr;
     double* out_scores = nullptr;
     int out_k = 0;

@@ -741,11 +741,6 @@ static double fp16_pass_eps(int dim_pad) {
     return (2 * u16 + u16 * u16) * 1.01 + 2.0 * dim_pad * u32 + 8 * u32 + 2e-6;
 }
 
-static int shortlist_for_unused(int k) {
-    int kp = std::max(32, (int)round_up(2 * k + 8, 16));        // k=20 -> 48: gap to the 48th neighbour >> eps on typical data
-    return std::min(kp, RAG_MAX_K);
-}
-
 int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev,
                  double* scores_dev, hipStream_t st) {
     ARG_CHECK(h, h->emb16 != nullptr, "no index loaded");
