@@ -180,13 +180,16 @@ def main():
     stage0_rows = min(n_local, 2048)
     roof_bytes_note = None
     dim_pad = (DIM + 63) // 64 * 64
-    qpad = (Q + 255) // 256 * 256
-    flops_per_step = 2.0 * qpad * (n_local - stage0_rows) * dim_pad            # algorithmic, per step, this rank
+    # algorithmic work of the thresholded GEMM stages per step on this rank: every (query, row) dot product once, every
+    # fp16 corpus row read once (+ the query tile once per launch). No padding counted.
+    flops_per_step = 2.0 * Q * (n_local - stage0_rows) * DIM
     launches_per_step = gemm_launches / args.steps
     avg_launch_ms = gemm_ms / gemm_launches
     achieved_tflops = flops_per_step * args.steps / (gemm_ms * 1e-3) / 1e12
-    bytes_per_step = (n_local - stage0_rows) * dim_pad * 2.0 + launches_per_step * qpad * dim_pad * 2.0
+    bytes_per_step = (n_local - stage0_rows) * dim_pad * 2.0 + launches_per_step * Q * dim_pad * 2.0
     achieved_gbs = bytes_per_step * args.steps / (gemm_ms * 1e-3) / 1e9
+    # which roof binds this shape: time at MFMA peak vs time at HBM peak (crossover at ~300 queries per batch)
+    mfma_bound = flops_per_step / (PEAK_MFMA_TFLOPS * 1e12) >= bytes_per_step / (PEAK_HBM_GBS * 1e9)
     # HBM traffic per launch: from the committed rocprofv3 --pmc passes of this same command (profiles/), which
     # cannot be collected from inside the timed run. FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950).
     traffic = None
@@ -194,15 +197,19 @@ def main():
     if world == 1 and args.rows == 1_000_000 and Q == 1024 and os.path.exists(pmc_path):
         with open(pmc_path) as f:
             traffic = json.load(f)["kernels"]["dense_emit_kernel<false>"]["hbm_traffic_bytes_per_launch"]["total"]
+    mfma_view = {"achieved": round(achieved_tflops, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(achieved_tflops / PEAK_MFMA_TFLOPS, 4)}
+    hbm_view = {"achieved": round(achieved_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(achieved_gbs / PEAK_HBM_GBS, 4)}
     roofline = {
-        "bound": "mfma", "kernel": "dense_emit_kernel<false>", "achieved": round(achieved_tflops, 2),
-        "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_MFMA_TFLOPS, 4),
+        "bound": "mfma" if mfma_bound else "hbm", "kernel": "dense_emit_kernel<false>",
+        **(mfma_view if mfma_bound else hbm_view),
         "traffic": traffic, "traffic_source": "profiles/r01_c_dense_pmc.json (bytes per launch; algorithmic: "
         f"{bytes_per_step / launches_per_step:.4g})" if traffic else None,
         "launches_per_step": launches_per_step, "avg_launch_ms": round(avg_launch_ms, 4),
         "algorithmic_flops_per_launch": flops_per_step / launches_per_step,
-        "hbm_view": {"algorithmic_bytes_per_step": bytes_per_step, "achieved_GBs": round(achieved_gbs, 1),
-                     "frac_of_8TBs": round(achieved_gbs / PEAK_HBM_GBS, 4)},
+        "algorithmic_bytes_per_launch": bytes_per_step / launches_per_step,
+        "other_roof": hbm_view if mfma_bound else mfma_view,
     }
 
     cpu_baseline = None

@@ -43,7 +43,7 @@ struct rag_ce_model {
     int64_t ws_tokens = 0;
     int ws_pairs = 0, ws_L = 0;
     float *x32 = nullptr, *y32 = nullptr;
-    half_t *x16 = nullptr, *qk16 = nullptr, *vt16 = nullptr, *ctx16 = nullptr, *h16 = nullptr;
+    half_t *x16 = nullptr, *q16 = nullptr, *kf16 = nullptr, *vf16 = nullptr, *ctx16 = nullptr, *h16 = nullptr;
     int32_t *ids = nullptr, *tt = nullptr, *lens = nullptr;
     float* logits = nullptr;
 };
@@ -55,6 +55,8 @@ struct rag_ce_model {
 #define CE_X_BYTES (CE_BN * CE_BK * 2)                    // one plane of the token tile: 16 KiB
 #define CE_STAGE_BYTES (2 * CE_W_BYTES + 2 * CE_X_BYTES)  // W_hi | W_lo | X_hi | X_lo = 48 KiB
 #define CE_GEMM_LDS (3 * CE_STAGE_BYTES)                  // three stages = 144 KiB
+#define CE_EPI_BYTES (CE_GEMM_LDS / 8)                    // per-wave epilogue transpose region: 18 KiB
+#define CE_EPI_PLANE (64 * 144)                           // one fp16 plane of a 64 x 64 tile, rows padded to 144 B
 
 enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2 };
 
@@ -85,8 +87,9 @@ template <int EPI>
 __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__ W, size_t w_plane, const half_t* __restrict__ X,
                                                        size_t x_plane, int N, int K, const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ out32,
-                                                       half_t* __restrict__ out16, size_t out_plane, half_t* __restrict__ vt16,
-                                                       size_t vt_plane, int L, int hidden, int heads, int64_t m_valid) {
+                                                       half_t* __restrict__ out16, size_t out_plane, half_t* __restrict__ kf16,
+                                                       half_t* __restrict__ vf16, size_t kv_plane, int L, int hidden, int heads,
+                                                       int64_t m_valid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -161,43 +164,118 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
     }
     if (!lag) { CE_BAR }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // epilogue: acc[i][j][r] = C^T[n = n0 + wm*64 + i*16 + fq*4 + r][m = m0 + wn*64 + j*16 + fr]
+    // epilogue: acc[i][j][r] = C^T[n = nb + i*16 + fq*4 + r][m = mb + j*16 + fr]. Each wave transposes its 64 x 64
+    // tile through a private 18 KiB LDS region (the pipeline stages are dead by now) so that every global store /
+    // residual load instruction covers whole 128 B lines of the row-major outputs instead of 32 B row fragments.
+    CE_BAR
+    char* wl = smem + wid * CE_EPI_BYTES;
+    const int nb = n0 + wm * 64, mb = m0 + wn * 64;
+    if (EPI == EPI_RESID) {
+        // fp32 tile [token][feature], row stride 272 B
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wm * 64 + i * 16 + fq * 4;
-        const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+        for (int i = 0; i < 4; ++i) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + nb + i * 16 + fq * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wn * 64 + j * 16 + fr;
-            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
-            if (EPI == EPI_RESID) {
-                const float4 rv = *reinterpret_cast<const float4*>(resid + (size_t)m * N + n);
-                *reinterpret_cast<float4*>(out32 + (size_t)m * N + n) = make_float4(v0 + rv.x, v1 + rv.y, v2 + rv.z, v3 + rv.w);
-            } else if (EPI == EPI_GELU) {
-                const float c = 0.70710678118654752440f;
-                v0 = 0.5f * v0 * (1.0f + erff(v0 * c));
-                v1 = 0.5f * v1 * (1.0f + erff(v1 * c));
-                v2 = 0.5f * v2 * (1.0f + erff(v2 * c));
-                v3 = 0.5f * v3 * (1.0f + erff(v3 * c));
-                store_split4(out16 + (size_t)m * N + n, out_plane, v0, v1, v2, v3);
-            } else {   // EPI_QKV: features [0,2*hidden) -> qk16[m][2*hidden]; [2*hidden,3*hidden) -> vt16[pair][head][d][L]
-                if (n < 2 * hidden) {
-                    store_split4(out16 + (size_t)m * (2 * hidden) + n, out_plane, v0, v1, v2, v3);
-                } else if (m < m_valid) {                         // padded token rows have no (pair, token) slot
-                    const int f = n - 2 * hidden;                 // 4 consecutive d of one head (32 % 4 == 0)
-                    const int dh = hidden / heads;
-                    const int head = f / dh, d = f % dh;
-                    const int pair = m / L, tok = m % L;
-                    half_t* o = vt16 + (((size_t)pair * heads + head) * dh + d) * L + tok;
-                    const float vv[4] = {v0, v1, v2, v3};
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4*>(wl + (j * 16 + fr) * 272 + (i * 16 + fq * 4) * 4) =
+                    make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int rr = lane >> 4, cc = lane & 15;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 4 + rr;
+            const float4 v = *reinterpret_cast<const float4*>(wl + row * 272 + cc * 16);
+            const size_t g = (size_t)(mb + row) * N + nb + cc * 4;
+            const float4 rv = *reinterpret_cast<const float4*>(resid + g);
+            *reinterpret_cast<float4*>(out32 + g) = make_float4(v.x + rv.x, v.y + rv.y, v.z + rv.z, v.w + rv.w);
+        }
+    } else if (EPI == EPI_GELU || nb < 2 * hidden) {
+        // split-fp16 tile [token][feature]: hi plane then lo plane, row stride 144 B
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const half_t hi = (half_t)vv[r];
-                        o[(size_t)r * L] = hi;
-                        o[vt_plane + (size_t)r * L] = (half_t)(vv[r] - (float)hi);
-                    }
+        for (int i = 0; i < 4; ++i) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + nb + i * 16 + fq * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+                if (EPI == EPI_GELU) {
+                    const float c = 0.70710678118654752440f;
+                    v0 = 0.5f * v0 * (1.0f + erff(v0 * c));
+                    v1 = 0.5f * v1 * (1.0f + erff(v1 * c));
+                    v2 = 0.5f * v2 * (1.0f + erff(v2 * c));
+                    v3 = 0.5f * v3 * (1.0f + erff(v3 * c));
                 }
+                store_split4(reinterpret_cast<half_t*>(wl + (j * 16 + fr) * 144 + (i * 16 + fq * 4) * 2), CE_EPI_PLANE / 2, v0, v1,
+                             v2, v3);
             }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (EPI == EPI_GELU || nb < hidden) {
+            // FFN activations [token][ffn], or Q rows [token][hidden]: 8 lanes cover one 128 B line of a row
+            const int ldo = EPI == EPI_GELU ? N : hidden;
+            const int rr = lane >> 3, cc = lane & 7;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 8 + rr;
+                const half8 hi = *reinterpret_cast<const half8*>(wl + row * 144 + cc * 16);
+                const half8 lo = *reinterpret_cast<const half8*>(wl + CE_EPI_PLANE + row * 144 + cc * 16);
+                half_t* o = out16 + (size_t)(mb + row) * ldo + nb + cc * 8;
+                *reinterpret_cast<half8*>(o) = hi;
+                *reinterpret_cast<half8*>(o + out_plane) = lo;
+            }
+        } else {
+            // K features -> kf16[pair][head][key tile][lane = fq*16 + key%16][8 dims fq*8..]: the MFMA A-fragment order the
+            // attention kernel DMAs straight into LDS. One store instruction = one whole 1 KiB fragment tile.
+            const int head0 = (nb - hidden) >> 5;                  // this wave's 64 features = heads head0, head0+1
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int hl = it >> 2, tl = it & 3;               // head, 16-token tile inside the wave's 64 tokens
+                const int64_t m = mb + tl * 16;
+                if (m >= m_valid) continue;                        // padded token rows have no (pair, token) slot
+                const int pair = (int)(m / L), t = (int)(m % L) >> 4;
+                const half8 hi = *reinterpret_cast<const half8*>(wl + (tl * 16 + fr) * 144 + (hl * 4 + fq) * 16);
+                const half8 lo = *reinterpret_cast<const half8*>(wl + CE_EPI_PLANE + (tl * 16 + fr) * 144 + (hl * 4 + fq) * 16);
+                half_t* o = kf16 + ((((size_t)pair * heads + head0 + hl) * (L >> 4) + t) * 64 + lane) * 8;
+                *reinterpret_cast<half8*>(o) = hi;
+                *reinterpret_cast<half8*>(o + kv_plane) = lo;
+            }
+        }
+    } else {
+        // EPI_QKV, V features: split-fp16 tile [feature][token] in LDS, then vf16[pair][head][32-key block][d half]
+        // [lane = fq*16 + d%16][8 key slots]: slot e < 4 is key fq*4 + e of the block, slot e >= 4 is key 16 + fq*4 + e - 4
+        // (the order in which the S^T accumulators of two adjacent key tiles sit in a lane's registers, so P never
+        // leaves registers in the attention kernel).
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + nb + i * 16 + fq * 4);
+            const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[i][j][r] + bb[r];
+                    const half_t hi = (half_t)v;
+                    half_t* q = reinterpret_cast<half_t*>(wl + (i * 16 + fq * 4 + r) * 144 + (j * 16 + fr) * 2);
+                    q[0] = hi;
+                    q[CE_EPI_PLANE / 2] = (half_t)(v - (float)hi);
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int head0 = (nb - 2 * hidden) >> 5;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int hl = it >> 2, kl = (it >> 1) & 1, dh = it & 1;    // head, 32-key block, d half
+            const int64_t m = mb + kl * 32;
+            if (m >= m_valid) continue;
+            const int pair = (int)(m / L), kb = (int)(m % L) >> 5;
+            const char* rowp = wl + (hl * 32 + dh * 16 + fr) * 144 + (kl * 32 + fq * 4) * 2;
+            const half4 h0 = *reinterpret_cast<const half4*>(rowp), h1 = *reinterpret_cast<const half4*>(rowp + 32);
+            const half4 l0 = *reinterpret_cast<const half4*>(rowp + CE_EPI_PLANE), l1 = *reinterpret_cast<const half4*>(rowp + CE_EPI_PLANE + 32);
+            const half8 hi = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            const half8 lo = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            half_t* o = vf16 + (((((size_t)pair * heads + head0 + hl) * (L >> 5) + kb) * 2 + dh) * 64 + lane) * 8;
+            *reinterpret_cast<half8*>(o) = hi;
+            *reinterpret_cast<half8*>(o + kv_plane) = lo;
         }
     }
 }
@@ -265,126 +343,141 @@ __global__ __launch_bounds__(256) void ce_layernorm_kernel(const float* __restri
     wave_layernorm<PER>(v, g, b, hidden, eps, lane, x32 + tok * hidden, x16 + tok * hidden, plane);
 }
 
-// ---- attention: d_head must be 32. NT = L/16 key tiles; one wave owns QB consecutive 16-query blocks so every K / V
-// fragment it loads from L2 is used QB times. All operands are split fp16 (hi plane + lo plane): S and P.V are 3 MFMAs
-// each. S is computed TRANSPOSED (A = K rows, B = Q rows): the accumulator then has the query on the lane column and
-// 4 consecutive KEYS in a lane's registers, so P goes to LDS as packed 8-byte writes (not 2-byte scatters) and the
-// softmax row reduction is registers + two xor-shuffles.
-template <int NT, int QB>
-__global__ __launch_bounds__(256) void ce_attention_kernel(const half_t* __restrict__ qk16, size_t qk_plane,
-                                                            const half_t* __restrict__ vt16, size_t vt_plane,
-                                                            const int32_t* __restrict__ lens, int L, int hidden, int heads,
-                                                            half_t* __restrict__ ctx16, size_t ctx_plane) {
+// ---- attention: d_head must be 32. One block per (head, pair); every wave owns QB consecutive 16-query blocks.
+// K and V of the (pair, head) arrive in LDS by LDS-DMA, already in MFMA fragment order (written that way by the QKV
+// epilogue), so a fragment read is one conflict-free ds_read_b128 at lane*16 and is shared by all waves of the block.
+// All operands are split fp16 (hi + lo plane): S and P.V are 3 MFMAs each. S is computed TRANSPOSED (A = K rows,
+// B = Q rows): the accumulator lane (fr, fq) then holds query fr x keys fq*4..+4, which IS the B-operand layout of the
+// next MFMA if the 32 k-slots of a key block are numbered (fq, e) -> key fq*4 + e (e < 4) | 16 + fq*4 + e - 4: V is
+// stored in that slot order, so P goes registers -> MFMA without touching LDS. Online (flash-style) softmax over
+// 32-key blocks in the exp2 domain; key blocks past the pair's length are skipped, the boundary block is masked.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t ce_pk(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+__device__ __forceinline__ float ce_trunc10(float e) {     // e with the mantissa cut to 10 bits: exactly a fp16 value
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, e) & 0xFFFFE000u);
+}
+__device__ __forceinline__ void ce_dma_at(const half_t* __restrict__ g, char* lds_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_uniform, 16, 0, 0);
+}
+
+template <int QB>
+__global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __restrict__ q16, size_t q_plane,
+                                                             const half_t* __restrict__ kf16, const half_t* __restrict__ vf16,
+                                                             size_t kv_plane, const int32_t* __restrict__ lens, int L, int hidden,
+                                                             int heads, half_t* __restrict__ ctx16, size_t ctx_plane) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int PLD = NT * 16 + 8;                                            // P tile row pitch (halfs)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // per wave: QB x (P hi [16 q][L keys] | P lo)
-    half_t (*pbase)[PLD] = reinterpret_cast<half_t (*)[PLD]>(smem + (size_t)wv * QB * 2 * 16 * PLD * 2);
-    const int pair = blockIdx.z, head = blockIdx.y;
-    const int qb0 = (blockIdx.x * 4 + wv) * QB;          // first 16-query block of this wave
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+    const int head = blockIdx.x, pair = blockIdx.y;
     const int len = max(1, min(lens[pair], L));
-    if (qb0 * 16 >= L) return;
+    const int nkb = (len + 31) >> 5;                                  // 32-key blocks that hold at least one real key
     const int fr = lane & 15, fq = lane >> 4;
+    const size_t plane_b = (size_t)L * 64;                            // bytes of one K (or V) plane of this (pair, head)
+    char* const k_hi = smem;
+    char* const k_lo = smem + plane_b;
+    char* const v_hi = smem + 2 * plane_b;
+    char* const v_lo = smem + 3 * plane_b;
+    {
+        const half_t* kg = kf16 + ((size_t)pair * heads + head) * L * 32 + lane * 8;
+        const half_t* vg = vf16 + ((size_t)pair * heads + head) * L * 32 + lane * 8;
+        for (int c = wv; c < 2 * nkb; c += nwaves) {                  // 1 KiB fragment tiles: 2 per key block and plane
+            ce_dma_at(kg + (size_t)c * 512, k_hi + c * 1024);
+            ce_dma_at(kg + kv_plane + (size_t)c * 512, k_lo + c * 1024);
+            ce_dma_at(vg + (size_t)c * 512, v_hi + c * 1024);
+            ce_dma_at(vg + kv_plane + (size_t)c * 512, v_lo + c * 1024);
+        }
+    }
     const size_t row0 = (size_t)pair * L;
-    const int ld = 2 * hidden;
-    const float scale = 0.17677669529663687f;            // 32^-0.5
-    // B operand = Q rows (query fr of block b, k = 8*fq..+8); rows past L are clamped (results discarded)
+    const int qb0 = wv * QB;
+    // B operand = Q rows (query fr of block b, dims 8*fq..+8)
     half8 qh[QB], ql[QB];
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        const int qrow = min((qb0 + b) * 16 + fr, L - 1);
-        const half_t* qp = qk16 + (row0 + qrow) * ld + head * 32 + fq * 8;
+        const half_t* qp = q16 + (row0 + (qb0 + b) * 16 + fr) * hidden + head * 32 + fq * 8;
         qh[b] = *reinterpret_cast<const half8*>(qp);
-        ql[b] = *reinterpret_cast<const half8*>(qp + qk_plane);
+        ql[b] = *reinterpret_cast<const half8*>(qp + q_plane);
     }
-    f32x4 s[QB][NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        // A operand = K rows (key fr of tile t)
-        const half_t* kp = qk16 + (row0 + t * 16 + fr) * ld + hidden + head * 32 + fq * 8;
-        const half8 kh = *reinterpret_cast<const half8*>(kp);
-        const half8 kl = *reinterpret_cast<const half8*>(kp + qk_plane);
-#pragma unroll
-        for (int b = 0; b < QB; ++b) {
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            z = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[b], z, 0, 0, 0);
-            z = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[b], z, 0, 0, 0);
-            z = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[b], z, 0, 0, 0);
-            // C layout: col = fr = query, row = fq*4 + r = key within the tile
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[b][t][r] = (t * 16 + fq * 4 + r) < len ? z[r] * scale : -INFINITY;
-        }
-    }
-    float inv_sum[QB];
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        // softmax over keys of query fr: this lane's NT*4 values, then the 4 lanes sharing fr (xor 16, 32)
-        float m = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) m = fmaxf(m, fmaxf(fmaxf(s[b][t][0], s[b][t][1]), fmaxf(s[b][t][2], s[b][t][3])));
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
-        float a = 0.f;
-        half_t (*ph)[PLD] = pbase + (size_t)(2 * b) * 16;
-        half_t (*pl)[PLD] = pbase + (size_t)(2 * b + 1) * 16;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            float e[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { e[r] = expf(s[b][t][r] - m); a += e[r]; }
-            const half4 hi = {(half_t)e[0], (half_t)e[1], (half_t)e[2], (half_t)e[3]};
-            const half4 lo = {(half_t)(e[0] - (float)hi[0]), (half_t)(e[1] - (float)hi[1]), (half_t)(e[2] - (float)hi[2]),
-                              (half_t)(e[3] - (float)hi[3])};
-            *reinterpret_cast<half4*>(&ph[fr][t * 16 + fq * 4]) = hi;      // P[query fr][4 consecutive keys]
-            *reinterpret_cast<half4*>(&pl[fr][t * 16 + fq * 4]) = lo;
-        }
-        a += __shfl_xor(a, 16);
-        a += __shfl_xor(a, 32);
-        inv_sum[b] = 1.0f / a;
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's LDS writes done (wave-private tiles)
-    __builtin_amdgcn_wave_barrier();
-    // ctx[q][d] = sum_key P[q][key] * V[key][d]:  A = P (row q = fr, keys 8*fq..), B = V^T rows (d = fr)
     f32x4 c0[QB], c1[QB];
-#pragma unroll
-    for (int b = 0; b < QB; ++b) { c0[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; c1[b] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    const half_t* vbase = vt16 + ((size_t)pair * heads + head) * 32 * L;
-#pragma unroll
-    for (int kb = 0; kb < NT / 2; ++kb) {          // 32 keys per MFMA
-        const half_t* v0p = vbase + (size_t)fr * L + kb * 32 + fq * 8;
-        const half_t* v1p = vbase + (size_t)(16 + fr) * L + kb * 32 + fq * 8;
-        const half8 v0h = *reinterpret_cast<const half8*>(v0p), v0l = *reinterpret_cast<const half8*>(v0p + vt_plane);
-        const half8 v1h = *reinterpret_cast<const half8*>(v1p), v1l = *reinterpret_cast<const half8*>(v1p + vt_plane);
-#pragma unroll
-        for (int b = 0; b < QB; ++b) {
-            half_t (*ph)[PLD] = pbase + (size_t)(2 * b) * 16;
-            half_t (*pl)[PLD] = pbase + (size_t)(2 * b + 1) * 16;
-            const half8 pfh = *reinterpret_cast<const half8*>(&ph[fr][kb * 32 + fq * 8]);
-            const half8 pfl = *reinterpret_cast<const half8*>(&pl[fr][kb * 32 + fq * 8]);
-            c0[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfl, v0h, c0[b], 0, 0, 0);
-            c0[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh, v0l, c0[b], 0, 0, 0);
-            c0[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh, v0h, c0[b], 0, 0, 0);
-            c1[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfl, v1h, c1[b], 0, 0, 0);
-            c1[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh, v1l, c1[b], 0, 0, 0);
-            c1[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfh, v1h, c1[b], 0, 0, 0);
-        }
-    }
-    // C layout: col = fr = d (c0: d, c1: 16+d), row = fq*4 + r = query; 1/sum of that query lives in lane (fq*4+r)
+    float mrun[QB], lsum[QB];
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
+        c0[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        c1[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mrun[b] = -INFINITY;
+        lsum[b] = 0.f;
+    }
+    const float cs = (float)(0.17677669529663687 * 1.4426950408889634);    // 32^-0.5 * log2(e)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int fo = kb * 2048 + lane * 16;
+        const half8 k0h = *reinterpret_cast<const half8*>(k_hi + fo), k1h = *reinterpret_cast<const half8*>(k_hi + fo + 1024);
+        const half8 k0l = *reinterpret_cast<const half8*>(k_lo + fo), k1l = *reinterpret_cast<const half8*>(k_lo + fo + 1024);
+        const half8 v0h = *reinterpret_cast<const half8*>(v_hi + fo), v1h = *reinterpret_cast<const half8*>(v_hi + fo + 1024);
+        const half8 v0l = *reinterpret_cast<const half8*>(v_lo + fo), v1l = *reinterpret_cast<const half8*>(v_lo + fo + 1024);
+        const bool edge = (kb + 1) * 32 > len;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qrow = (qb0 + b) * 16 + fq * 4 + r;
-            const float inv = __shfl(inv_sum[b], fq * 4 + r);
-            if (qrow >= L) continue;
-            half_t* o = ctx16 + (row0 + qrow) * hidden + head * 32;
-            const float a0 = c0[b][r] * inv, a1 = c1[b][r] * inv;
-            const half_t h0 = (half_t)a0, h1 = (half_t)a1;
-            o[fr] = h0;
-            o[16 + fr] = h1;
-            o[ctx_plane + fr] = (half_t)(a0 - (float)h0);
-            o[ctx_plane + 16 + fr] = (half_t)(a1 - (float)h1);
+        for (int b = 0; b < QB; ++b) {
+            f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
+            z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0l, qh[b], z0, 0, 0, 0);
+            z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1l, qh[b], z1, 0, 0, 0);
+            z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, ql[b], z0, 0, 0, 0);
+            z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, ql[b], z1, 0, 0, 0);
+            z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, qh[b], z0, 0, 0, 0);
+            z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, qh[b], z1, 0, 0, 0);
+            // lane (fr, fq): z0[r] = S[query fr][key kb*32 + fq*4 + r], z1[r] = same + 16
+            if (edge) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (kb * 32 + fq * 4 + r >= len) z0[r] = -INFINITY;
+                    if (kb * 32 + 16 + fq * 4 + r >= len) z1[r] = -INFINITY;
+                }
+            }
+            float mx = fmaxf(fmaxf(fmaxf(z0[0], z0[1]), fmaxf(z0[2], z0[3])), fmaxf(fmaxf(z1[0], z1[1]), fmaxf(z1[2], z1[3])));
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun[b], mx);                  // finite: key 0 is always real
+            const float alpha = __builtin_amdgcn_exp2f((mrun[b] - mnew) * cs);
+            mrun[b] = mnew;
+            const float off = -mnew * cs;
+            float e[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e[r] = __builtin_amdgcn_exp2f(fmaf(z0[r], cs, off));
+                e[4 + r] = __builtin_amdgcn_exp2f(fmaf(z1[r], cs, off));
+            }
+            lsum[b] = lsum[b] * alpha + (((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7])));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { c0[b][r] *= alpha; c1[b][r] *= alpha; }
+            float eh[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) eh[r] = ce_trunc10(e[r]);
+            const u32x4 ph_u = {ce_pk(eh[0], eh[1]), ce_pk(eh[2], eh[3]), ce_pk(eh[4], eh[5]), ce_pk(eh[6], eh[7])};
+            const u32x4 pl_u = {ce_pk(e[0] - eh[0], e[1] - eh[1]), ce_pk(e[2] - eh[2], e[3] - eh[3]),
+                                ce_pk(e[4] - eh[4], e[5] - eh[5]), ce_pk(e[6] - eh[6], e[7] - eh[7])};
+            const half8 ph = __builtin_bit_cast(half8, ph_u), pl = __builtin_bit_cast(half8, pl_u);
+            // ctx^T[d][q] += V^T[d][key] P[q][key]: A = V fragment (row d), B = P (col q = fr)
+            c0[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0l, ph, c0[b], 0, 0, 0);
+            c1[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1l, ph, c1[b], 0, 0, 0);
+            c0[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0h, pl, c0[b], 0, 0, 0);
+            c1[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1h, pl, c1[b], 0, 0, 0);
+            c0[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0h, ph, c0[b], 0, 0, 0);
+            c1[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1h, ph, c1[b], 0, 0, 0);
         }
+    }
+    // lane (fr, fq): c0[r] = ctx[query fr][d = fq*4 + r], c1[r] = d + 16; the row sum is spread over the 4 fq lanes
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        float l = lsum[b];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        half_t* o = ctx16 + (row0 + (qb0 + b) * 16 + fr) * hidden + head * 32 + fq * 4;
+        store_split4(o, ctx_plane, c0[b][0] * inv, c0[b][1] * inv, c0[b][2] * inv, c0[b][3] * inv);
+        store_split4(o + 16, ctx_plane, c1[b][0] * inv, c1[b][1] * inv, c1[b][2] * inv, c1[b][3] * inv);
     }
 }
 
@@ -423,9 +516,9 @@ __global__ void ce_f32_split_kernel(const float* __restrict__ in, half_t* __rest
 
 // ------------------------------------------------------------------------------------------------
 static void ce_free_ws(rag_ce_model* m) {
-    hipFree(m->x32); hipFree(m->y32); hipFree(m->x16); hipFree(m->qk16); hipFree(m->vt16); hipFree(m->ctx16);
+    hipFree(m->x32); hipFree(m->y32); hipFree(m->x16); hipFree(m->q16); hipFree(m->kf16); hipFree(m->vf16); hipFree(m->ctx16);
     hipFree(m->h16); hipFree(m->ids); hipFree(m->tt); hipFree(m->lens); hipFree(m->logits);
-    m->x32 = m->y32 = nullptr; m->x16 = m->qk16 = m->vt16 = m->ctx16 = m->h16 = nullptr;
+    m->x32 = m->y32 = nullptr; m->x16 = m->q16 = m->kf16 = m->vf16 = m->ctx16 = m->h16 = nullptr;
     m->ids = m->tt = m->lens = nullptr; m->logits = nullptr;
     m->ws_tokens = 0; m->ws_pairs = 0; m->ws_L = 0;
 }
@@ -511,25 +604,25 @@ int ce_load_host(rag_ctx* h, const rag_ce_config* cfg, const float* const* T, in
 
 static const int kAttnL[] = {32, 64, 96, 128, 192, 256, 384, 512};
 
-struct ce_planes { size_t x, qk, vt, ctx, h; };
+struct ce_planes { size_t x, q, kv, ctx, h; };
 static ce_planes planes_for(const rag_ce_model* m, int64_t Mp) {
     const size_t H = m->cfg.hidden, F = m->cfg.ffn;
-    return {(size_t)Mp * H, (size_t)Mp * 2 * H, (size_t)Mp * H + 2048, (size_t)Mp * H, (size_t)Mp * F};
+    return {(size_t)Mp * H, (size_t)Mp * H, (size_t)Mp * H + 2048, (size_t)Mp * H, (size_t)Mp * F};
 }
 
-template <int NT>
-static void launch_attention(rag_ce_model* m, int P, int L, const ce_planes& pp, hipStream_t st) {
-    constexpr int QB = NT <= 16 ? 2 : 1;                               // 16-query blocks per wave (register budget)
-    const size_t lds = (size_t)4 * QB * 2 * 16 * (NT * 16 + 8) * 2;    // 4 waves x QB x (P hi + P lo)
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ce_attention_kernel<NT, QB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
+template <int QB>
+static int launch_attention(rag_ctx* h, rag_ce_model* m, int P, int L, const ce_planes& pp, hipStream_t st) {
+    const int lds = L * 256;                                           // K hi | K lo | V hi | V lo fragment planes
+    static int attr_lds = 0;
+    if (lds > attr_lds) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_attention_kernel<QB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_lds = lds;
     }
-    const int qblocks = L / 16;
-    hipLaunchKernelGGL((ce_attention_kernel<NT, QB>), dim3((qblocks + 4 * QB - 1) / (4 * QB), m->cfg.heads, P), dim3(256), lds, st,
-                       m->qk16, pp.qk, m->vt16, pp.vt, m->lens, L, m->cfg.hidden, m->cfg.heads, m->ctx16, pp.ctx);
+    const int waves = L / (16 * QB);
+    hipLaunchKernelGGL((ce_attention_kernel<QB>), dim3(m->cfg.heads, P), dim3(64 * waves), lds, st, m->q16, pp.q, m->kf16, m->vf16,
+                       pp.kv, m->lens, L, m->cfg.hidden, m->cfg.heads, m->ctx16, pp.ctx);
+    return RAG_OK;
 }
 
 template <int PER>
@@ -569,28 +662,21 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     for (int l = 0; l < m->cfg.layers; ++l) {
         auto& ly = m->layers[l];
         hipLaunchKernelGGL(ce_gemm_kernel<EPI_QKV>, dim3(3 * H / CE_BM, mt), blk, lds, st, ly.wqkv, (size_t)3 * H * H, m->x16, pp.x,
-                           3 * H, H, ly.bqkv, (const float*)nullptr, (float*)nullptr, m->qk16, pp.qk, m->vt16, pp.vt, L, H,
+                           3 * H, H, ly.bqkv, (const float*)nullptr, (float*)nullptr, m->q16, pp.q, m->kf16, m->vf16, pp.kv, L, H,
                            m->cfg.heads, M);
-        switch (L / 16) {
-            case 2: launch_attention<2>(m, P, L, pp, st); break;
-            case 4: launch_attention<4>(m, P, L, pp, st); break;
-            case 6: launch_attention<6>(m, P, L, pp, st); break;
-            case 8: launch_attention<8>(m, P, L, pp, st); break;
-            case 12: launch_attention<12>(m, P, L, pp, st); break;
-            case 16: launch_attention<16>(m, P, L, pp, st); break;
-            case 24: launch_attention<24>(m, P, L, pp, st); break;
-            case 32: launch_attention<32>(m, P, L, pp, st); break;
-            default: h->err = "ce: unsupported padded sequence length"; return RAG_ERR_ARG;
+        {
+            const int rc = L == 32 ? launch_attention<1>(h, m, P, L, pp, st) : launch_attention<2>(h, m, P, L, pp, st);
+            if (rc != RAG_OK) return rc;
         }
         hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(H / CE_BM, mt), blk, lds, st, ly.wo, (size_t)H * H, m->ctx16, pp.ctx, H, H,
-                           ly.bo, m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (size_t)0, L, H, m->cfg.heads, M);
+                           ly.bo, m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, L, H, m->cfg.heads, M);
 #define LN1(PER) launch_ln<PER>(m, m->y32, ly.ln1_g, ly.ln1_b, M, pp.x, st)
         CE_PER_DISPATCH(LN1)
         hipLaunchKernelGGL(ce_gemm_kernel<EPI_GELU>, dim3(F / CE_BM, mt), blk, lds, st, ly.w1, (size_t)F * H, m->x16, pp.x, F, H,
-                           ly.b1, (const float*)nullptr, (float*)nullptr, m->h16, pp.h, (half_t*)nullptr, (size_t)0, L, H,
-                           m->cfg.heads, M);
+                           ly.b1, (const float*)nullptr, (float*)nullptr, m->h16, pp.h, (half_t*)nullptr, (half_t*)nullptr, (size_t)0,
+                           L, H, m->cfg.heads, M);
         hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(H / CE_BM, mt), blk, lds, st, ly.w2, (size_t)H * F, m->h16, pp.h, H, F,
-                           ly.b2, m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (size_t)0, L, H, m->cfg.heads, M);
+                           ly.b2, m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, L, H, m->cfg.heads, M);
 #define LN2(PER) launch_ln<PER>(m, m->y32, ly.ln2_g, ly.ln2_b, M, pp.x, st)
         CE_PER_DISPATCH(LN2)
     }
@@ -610,8 +696,9 @@ static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L) {
     m->ws_pairs = P;                                     // planes_for() uses the allocated pair count
     const ce_planes pp = planes_for(m, Mp);
     HIP_TRY(h, hipMalloc(&m->x16, 2 * pp.x * 2));
-    HIP_TRY(h, hipMalloc(&m->qk16, 2 * pp.qk * 2));
-    HIP_TRY(h, hipMalloc(&m->vt16, 2 * pp.vt * 2));
+    HIP_TRY(h, hipMalloc(&m->q16, 2 * pp.q * 2));
+    HIP_TRY(h, hipMalloc(&m->kf16, 2 * pp.kv * 2));
+    HIP_TRY(h, hipMalloc(&m->vf16, 2 * pp.kv * 2));
     HIP_TRY(h, hipMalloc(&m->ctx16, 2 * pp.ctx * 2));
     HIP_TRY(h, hipMalloc(&m->h16, 2 * pp.h * 2));
     HIP_TRY(h, hipMalloc(&m->ids, (size_t)Mp * 4));
@@ -622,8 +709,9 @@ static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L) {
     HIP_TRY(h, hipMemset(m->x16, 0, 2 * pp.x * 2));
     HIP_TRY(h, hipMemset(m->ctx16, 0, 2 * pp.ctx * 2));
     HIP_TRY(h, hipMemset(m->h16, 0, 2 * pp.h * 2));
-    HIP_TRY(h, hipMemset(m->qk16, 0, 2 * pp.qk * 2));
-    HIP_TRY(h, hipMemset(m->vt16, 0, 2 * pp.vt * 2));
+    HIP_TRY(h, hipMemset(m->q16, 0, 2 * pp.q * 2));
+    HIP_TRY(h, hipMemset(m->kf16, 0, 2 * pp.kv * 2));
+    HIP_TRY(h, hipMemset(m->vf16, 0, 2 * pp.kv * 2));
     HIP_TRY(h, hipMemset(m->x32, 0, (size_t)Mp * H * 4));
     m->ws_pairs = P;
     m->ws_L = L;

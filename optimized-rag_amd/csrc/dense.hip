@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 #define HALF_BYTES (128 * RAG_BK * 2)         // one half-tile: 128 rows x 64 halfs = 16 KiB
 #define TILE_BYTES (4 * HALF_BYTES)           // one K-step stage: A0 | A1 | B0 | B1
 #define DENSE_LDS_BYTES (2 * TILE_BYTES)      // two stages = 128 KiB
+#define DENSE_LDS_BYTES_SMALLQ (9 * HALF_BYTES)   // small-batch variant: 3 corpus stages (2 halves each) + 3 query half-tiles = 144 KiB
 
 // One half-tile (128 rows x 128 B = 1024 chunks of 16 B) by LDS-DMA: 512 threads -> 2 pieces per thread; piece j of
 // this wave lands at linear chunk j*512 + wid*64 (+lane): wave-uniform base + lane*16, as LDS-DMA requires.
@@ -101,7 +102,7 @@ __device__ __forceinline__ void load_fragB(FragB& f, const char* base, const int
 // sub-blocks of the wave's OWN corpus half, B0/B1 = 32-query sub-blocks of its own query half), done as TWO phases
 // of 32 MFMAs: pA = (A0,B0),(A1,B0)   pB = (A1,B1),(A0,B1). Every phase is an I-part (LDS fragment reads + two
 // half-tile LDS-DMA issues, then lgkmcnt(0)) and an M-part (32 MFMAs), each closed by s_barrier. The two waves that
-// share a SIMD (wave w and w+4, i.e. wm = 0 / 1) run HALF A PHASE APART (waves 4-7 take one extra barrier up front,
+// share a SIMD (wave w and w+4) run HALF A PHASE APART (waves 4-7 take one extra barrier up front,
 // waves 0-3 one at the end): while one wave's MFMAs own the matrix pipe its partner reads fragments and issues DMA.
 // (History, measured with tools/gemm_probe.hip: lock-step 4x16-MFMA phases 1131 TFLOP/s, staggered 4x16 1196;
 // a barrier interval costs ~150 cycles beyond its 16 MFMAs = 256 cycles, hence 32-MFMA parts.)
@@ -142,7 +143,9 @@ __device__ __forceinline__ void load_fragB(FragB& f, const char* base, const int
 #ifdef PROBE_NOWAIT      // timing experiment only (tools/gemm_probe.hip): results are wrong without the wait
 #define DMA_WAIT asm volatile("s_waitcnt vmcnt(12)" ::: "memory")
 #else
-#define DMA_WAIT asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
+#define DMA_WAIT                                                                                            \
+    if (SMALLQ) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                           \
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #endif
 #define BARRIER                                                                                             \
     __builtin_amdgcn_s_barrier();                                                                           \
@@ -151,22 +154,29 @@ __device__ __forceinline__ void load_fragB(FragB& f, const char* base, const int
 #define I_END(WAIT)                                                                                         \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
     STAMP(0)                                                                                                \
-    if ((WAIT) && lag) DMA_WAIT;                                                                            \
+    if ((WAIT) && lag) { DMA_WAIT }                                                                         \
     STAMP(1)                                                                                                \
     BARRIER                                                                                                 \
     STAMP(2)
 #define M_PART(FA0, FB0, SA0, SB0, FA1, FB1, SA1, SB1, WAIT)                                               \
-    __builtin_amdgcn_s_setprio(1);                                                                          \
-    MFMA_QUAD(FA0, FB0, SA0, SB0)                                                                           \
-    MFMA_QUAD(FA1, FB1, SA1, SB1)                                                                           \
-    __builtin_amdgcn_s_setprio(0);                                                                          \
+    if (active) {                                                                                           \
+        __builtin_amdgcn_s_setprio(1);                                                                      \
+        MFMA_QUAD(FA0, FB0, SA0, SB0)                                                                       \
+        MFMA_QUAD(FA1, FB1, SA1, SB1)                                                                       \
+        __builtin_amdgcn_s_setprio(0);                                                                      \
+    }                                                                                                       \
     STAMP(3)                                                                                                \
-    if ((WAIT) && !lag) DMA_WAIT;                                                                           \
+    if ((WAIT) && !lag) { DMA_WAIT }                                                                        \
     STAMP(1)                                                                                                \
     BARRIER                                                                                                 \
     STAMP(2)
 
-template <bool DENSE0>
+// SMALLQ (batches of <= 128 queries, one query tile): the pass is HBM-bound, so the LDS that the unused query half-tile
+// would take buys a THIRD corpus stage instead and the corpus DMA runs three K-steps ahead (queries two, in three
+// half-tile slots): A(t+3) issued in IB(t), B(t+2) in IA(t); the per-step wait is vmcnt(10) = {A(t+2), B(t+2), A(t+3)}
+// may still be in flight, A(t+1) and B(t+1) (both older in issue order) have landed. 64-96 KiB of corpus per CU in
+// flight instead of 32-64 KiB.
+template <bool DENSE0, bool SMALLQ>
 __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restrict__ corpus16, const half_t* __restrict__ q16,
                                                           int Dp, int rtile_begin, int n_rtiles, int n_qtiles,
                                                           int n_rows_valid, int q_valid, const float* __restrict__ tau,
@@ -180,7 +190,12 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;
+    // waves w and w+4 share a SIMD. Group g = wid>>2 (0 = leading, 1 = lagging half a phase); inside a group the wave on
+    // SIMD s owns corpus half wm = s&1 and the 64-query column block wn = (s>>1) + 2g. So a batch that fills only the
+    // first 64 / 128 columns of the tile leaves every SIMD with at most ONE wave that has real work: the others skip
+    // their fragment reads and MFMAs (they still issue DMA and meet every barrier), the MFMA time per K-step halves and
+    // the small-batch case becomes purely HBM-bound.
+    const int wm = wid & 1, wn = ((wid >> 1) & 1) + 2 * (wid >> 2);
 #ifdef DENSE_STAMP
     unsigned long long stamp_acc[4] = {0ull, 0ull, 0ull, 0ull}, stamp_prev = 0ull;
 #endif
@@ -209,7 +224,7 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
     for (int kk = 0; kk < 2; ++kk) off_k[kk] = fr * 128 + (((kk * 4 + fq) ^ sw) << 4);
     // this wave reads A from half wm (rows s*64 + i*16 + fr) and B from half wn>>1 (rows (wn&1)*64 + s*32 + j*16 + fr)
     const int a_off = wm * HALF_BYTES;
-    const int b_off = 2 * HALF_BYTES + (wn >> 1) * HALF_BYTES + (wn & 1) * 64 * 128;
+    const int b_off = (SMALLQ ? 0 : (wn >> 1) * HALF_BYTES) + (wn & 1) * 64 * 128;
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -220,16 +235,27 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
     const int nt = Dp / RAG_BK;            // even (dim_pad is a multiple of 128)
     const int last = nt - 1;
 #define SRC_STEP(u) (((u) < last ? (u) : last) * RAG_BK)
-#define STAGE_A(h, u) stage_half(a_src + (h) * half_rows + SRC_STEP(u), Dp, smem + ((u) & 1) * TILE_BYTES + (h) * HALF_BYTES, wid)
-#define STAGE_B(h, u) stage_half(b_src + (h) * half_rows + SRC_STEP(u), Dp, smem + ((u) & 1) * TILE_BYTES + (2 + (h)) * HALF_BYTES, wid)
-#define LDS_A(s, u) (smem + ((u) & 1) * TILE_BYTES + a_off + (s) * 64 * 128)
-#define LDS_B(s, u) (smem + ((u) & 1) * TILE_BYTES + b_off + (s) * 32 * 128)
+#define A_SLOT(u) (SMALLQ ? smem + ((u) % 3) * 2 * HALF_BYTES : smem + ((u) & 1) * TILE_BYTES)
+#define B_SLOT(u) (SMALLQ ? smem + 6 * HALF_BYTES + ((u) % 3) * HALF_BYTES : smem + ((u) & 1) * TILE_BYTES + 2 * HALF_BYTES)
+#define STAGE_A(h, u) stage_half(a_src + (h) * half_rows + SRC_STEP(u), Dp, A_SLOT(u) + (h) * HALF_BYTES, wid)
+#define STAGE_B(h, u) stage_half(b_src + (h) * half_rows + SRC_STEP(u), Dp, B_SLOT(u) + (h) * HALF_BYTES, wid)
+#define LDS_A(s, u) (A_SLOT(u) + a_off + (s) * 64 * 128)
+#define LDS_B(s, u) (B_SLOT(u) + b_off + (s) * 32 * 128)
 
     // prologue: step 0 complete, corpus halves of step 1 in flight
-    const bool lag = wm != 0;               // waves 4-7 run half a phase behind waves 0-3 (wave-uniform: from readfirstlane)
-    STAGE_B(0, 0); STAGE_B(1, 0); STAGE_A(0, 0); STAGE_A(1, 0);
-    STAGE_A(0, 1); STAGE_A(1, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    const bool lag = (wid >> 2) != 0;       // waves 4-7 run half a phase behind waves 0-3 (wave-uniform: from readfirstlane)
+    // wave-uniform: this wave's 64 query columns hold at least one query (compile-time true in the full-batch variant)
+    const bool active = !SMALLQ || (q0 + wn * 64 < q_valid);
+    if (SMALLQ) {
+        STAGE_B(0, 0); STAGE_A(0, 0); STAGE_A(1, 0);
+        STAGE_B(0, 1); STAGE_A(0, 1); STAGE_A(1, 1);
+        STAGE_A(0, 2); STAGE_A(1, 2);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    } else {
+        STAGE_B(0, 0); STAGE_B(1, 0); STAGE_A(0, 0); STAGE_A(1, 0);
+        STAGE_A(0, 1); STAGE_A(1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
     BARRIER
     FragA ax, ay;
     FragB bx, by;
@@ -239,12 +265,12 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
     if (lag) { BARRIER }
 
     for (int t = 0; t < nt; ++t) {
-        load_fragA(ax, LDS_A(0, t), off_k);  load_fragA(ay, LDS_A(1, t), off_k);  load_fragB(bx, LDS_B(0, t), off_k);
-        STAGE_B(0, t + 1);  STAGE_B(1, t + 1);
+        if (active) { load_fragA(ax, LDS_A(0, t), off_k);  load_fragA(ay, LDS_A(1, t), off_k);  load_fragB(bx, LDS_B(0, t), off_k); }
+        if (SMALLQ) { STAGE_B(0, t + 2); } else { STAGE_B(0, t + 1);  STAGE_B(1, t + 1); }
         I_END(0)
         M_PART(ax, bx, 0, 0, ay, bx, 1, 0, 0)
-        load_fragB(by, LDS_B(1, t), off_k);
-        STAGE_A(0, t + 2);  STAGE_A(1, t + 2);
+        if (active) { load_fragB(by, LDS_B(1, t), off_k); }
+        if (SMALLQ) { STAGE_A(0, t + 3);  STAGE_A(1, t + 3); } else { STAGE_A(0, t + 2);  STAGE_A(1, t + 2); }
         I_END(1)
         M_PART(ay, by, 1, 1, ax, by, 0, 1, 1)
     }
@@ -766,10 +792,12 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
 
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<true>),
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<true, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES));
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<false>),
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<false, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES_SMALLQ));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wide_kernel),
@@ -800,10 +828,13 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
             HIP_TRY(h, hipEventRecord(h->gemm_events[h->gemm_events_used].first, st));
         }
         if (stage == 0)
-            hipLaunchKernelGGL(dense_emit_kernel<true>, dim3(grid), dim3(512), DENSE_LDS_BYTES, st, h->emb16, h->q16,
+            hipLaunchKernelGGL((dense_emit_kernel<true, false>), dim3(grid), dim3(512), DENSE_LDS_BYTES, st, h->emb16, h->q16,
+                               h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant STAMP_ARG);
+        else if (Q <= 128 && !getenv("RAG_NO_SMALLQ"))
+            hipLaunchKernelGGL((dense_emit_kernel<false, true>), dim3(grid), dim3(512), DENSE_LDS_BYTES_SMALLQ, st, h->emb16, h->q16,
                                h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant STAMP_ARG);
         else
-            hipLaunchKernelGGL(dense_emit_kernel<false>, dim3(grid), dim3(512), DENSE_LDS_BYTES, st, h->emb16, h->q16,
+            hipLaunchKernelGGL((dense_emit_kernel<false, false>), dim3(grid), dim3(512), DENSE_LDS_BYTES, st, h->emb16, h->q16,
                                h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant STAMP_ARG);
         HIP_TRY(h, hipGetLastError());
         if (h->profiling && stage > 0) {

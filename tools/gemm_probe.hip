@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
     std::vector<float> ht(Q, tau_v);
     CK(hipMemcpy(tau, ht.data(), Q * 4, hipMemcpyHostToDevice));
     CK(hipMemset(cnt, 0, Q * 4));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                            DENSE_LDS_BYTES));
     const int grid = (int)round_up(n_rt, 8) * n_qt;
 #ifdef DENSE_STAMP
@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
     for (int it = 0; it < iters; ++it) {
         CK(hipMemset(cnt, 0, Q * 4));
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(dense_emit_kernel<false>, dim3(grid), dim3(512), DENSE_LDS_BYTES, 0, c, q, D, 0, n_rt, n_qt, N, Q, tau, cnt,
+        hipLaunchKernelGGL((dense_emit_kernel<false, false>), dim3(grid), dim3(512), DENSE_LDS_BYTES, 0, c, q, D, 0, n_rt, n_qt, N, Q, tau, cnt,
                            cand, (const int32_t*)nullptr, 0 EXTRA);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
@@ -61,10 +61,10 @@ int main(int argc, char** argv) {
         best = std::min(best, ms);
     }
     {   // correctness of the GEMM itself: dense stage-0 instance writes every score of rows [0,2048) as keys
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                DENSE_LDS_BYTES));
         CK(hipMemset(cand, 0, (size_t)Q * RAG_CAND_CAP * 8));
-        hipLaunchKernelGGL(dense_emit_kernel<true>, dim3(8 * n_qt), dim3(512), DENSE_LDS_BYTES, 0, c, q, D, 0, 8, n_qt, 2048, Q, tau, cnt,
+        hipLaunchKernelGGL((dense_emit_kernel<true, false>), dim3(8 * n_qt), dim3(512), DENSE_LDS_BYTES, 0, c, q, D, 0, 8, n_qt, 2048, Q, tau, cnt,
                            cand, (const int32_t*)nullptr, 0 EXTRA);
         CK(hipDeviceSynchronize());
         std::vector<uint64_t> hk((size_t)Q * RAG_CAND_CAP);
