@@ -41,29 +41,63 @@ def timed(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
+def timed_all_ranks(fn, steps, warmup, world):
+    """bench.py contract: barrier + synchronize on both sides, MAX over ranks."""
+    import torch.distributed as dist
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    return float(dt.item()) / steps
+
+
 def run_mode(args):
+    import os
+    import torch.distributed as dist
     from optimized_rag_amd import RagEngine
     from optimized_rag_amd.bm25 import Bm25Postings
-    device = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
-    eng = RagEngine(dim=DIM, device=0)
-    out = {"mode": args.mode, "n_gpus": 1, "data": "synthetic"}
+    from optimized_rag_amd.sharded import ShardedHybridIndex, ShardedReranker, shard_bounds
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    eng = RagEngine(dim=DIM, device=local)
+    out = {"mode": args.mode, "n_gpus": world, "data": "synthetic", "scaling": "strong",
+           "steps": args.steps, "warmup": args.warmup}
     if args.mode == "hybrid":
         N, Q, k, pool = args.rows, args.queries, args.k, 100
         g = torch.Generator(device=device)
         g.manual_seed(1234)
-        corpus = torch.randn((N, DIM), generator=g, device=device)
+        corpus = torch.randn((N, DIM), generator=g, device=device)        # same seed on every rank: replicated, then sliced
         corpus /= corpus.norm(dim=1, keepdim=True)
-        eng.index_load(corpus)
         rows = torch.randint(0, N, (Q,), generator=torch.Generator().manual_seed(4321))
         q = corpus[rows.to(device)] + torch.randn((Q, DIM), generator=g, device=device) * (0.5 / DIM ** 0.5)
         q = (q / q.norm(dim=1, keepdim=True)).contiguous()
-        del corpus
         t0 = time.perf_counter()
         indptr, d, tf, dl, tok, doc_ptr = synthetic_csr(N, 100_000, 120)
         post = Bm25Postings(indptr, d, tf, dl, Bm25Postings.idf_table(np.diff(indptr).clip(min=0), N), float(dl.sum()) / N)
         post.idf[np.diff(indptr) == 0] = 0.0
-        post.load(eng)
+        sharded = None
+        if world > 1:                  # SURVEY section 8e: rows, postings (global idf / avgdl) split contiguously
+            b0, e0 = shard_bounds(N, world)[rank]
+            sharded = ShardedHybridIndex(eng, rank=rank, world=world)
+            sharded.load_shard(corpus[b0:e0].contiguous(), b0, post.shard(b0, e0))
+        else:
+            eng.index_load(corpus)
+            post.load(eng)
+        del corpus
         build_s = time.perf_counter() - t0
         rng = np.random.default_rng(7)
         ptr, terms = [0], []
@@ -77,22 +111,21 @@ def run_mode(args):
         ptr_d, terms_d = torch.from_numpy(ptr).to(device), torch.from_numpy(terms).to(device)
         ids_d = torch.empty((Q, pool), dtype=torch.int64, device=device)
         sc_d = torch.empty((Q, pool), dtype=torch.float64, device=device)
-        import ctypes as C
 
         def dense():
             eng.dense_topk_dev(q, pool, ids_d, None, sc_d)
 
         def bm25():
-            eng._check(eng.lib.rag_bm25_topk_dev(eng.h, C.c_void_p(ptr_d.data_ptr()), C.c_void_p(terms_d.data_ptr()), Q, pool,
-                                                 C.c_void_p(ids_d.data_ptr()), None, C.c_void_p(sc_d.data_ptr()), None,
-                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rag_bm25_topk_dev")
+            eng.bm25_topk_dev(ptr_d, terms_d, pool, ids_d, None, sc_d)
 
         def hybrid():
+            if sharded is not None:
+                return sharded.search_hybrid(q, ptr_d, terms_d, pool, k)
             return eng.hybrid_rrf_dev(q, ptr_d, terms_d, pool, k)
 
         t_dense = timed(dense, args.steps, args.warmup)
         t_bm25 = timed(bm25, args.steps, 1)
-        total = timed(hybrid, args.steps, 1)
+        total = timed_all_ranks(hybrid, args.steps, 1, world)
         t_fuse = max(total - t_dense - t_bm25, 0.0)
         nnz_touched = float(sum(int(indptr[t + 1] - indptr[t]) for t in terms if t >= 0))
         out.update({
@@ -104,7 +137,8 @@ def run_mode(args):
                           "rrf_fuse_dev (by difference)": round(t_fuse * 1e3, 3)},
             "bm25": {"postings_touched_per_batch": nnz_touched,
                      "algorithmic_GBs": round(nnz_touched * 12 / t_bm25 / 1e9, 1), "index_build_s": round(build_s, 1)},
-            "note": "value = one rag_hybrid_rrf_dev call per batch, inputs and outputs resident in HBM",
+            "note": "value = one rag_hybrid_rrf_dev call per batch, inputs and outputs resident in HBM" if sharded is None else
+                    "value = local dense + BM25 lists, ONE all-gather (RCCL), two merges, RRF; max over ranks",
         })
     else:
         from oracle import bert_oracle as B          # weights only (seeded); the forward measured here is the HIP one
@@ -120,15 +154,13 @@ def run_mode(args):
         ids_d = torch.from_numpy(ids).to(device)
         tt_d = torch.from_numpy(tt).to(device)
         lens_d = torch.from_numpy(lens).to(device)
-        out_d = torch.empty((P,), dtype=torch.float32, device=device)
-        import ctypes as C
+        rer = ShardedReranker(eng, rank=rank, world=world)      # world == 1: a plain rag_ce_score_dev call
 
         def fwd():
-            eng._check(eng.lib.rag_ce_score_dev(eng.h, C.c_void_p(ids_d.data_ptr()), C.c_void_p(tt_d.data_ptr()),
-                                                C.c_void_p(lens_d.data_ptr()), P, L, C.c_void_p(out_d.data_ptr()),
-                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rag_ce_score_dev")
+            return rer.score(ids_d, tt_d, lens_d)
 
-        t = timed(fwd, max(1, args.steps // 10), 1)
+        out["steps"] = max(1, args.steps // 10)
+        t = timed_all_ranks(fwd, out["steps"], 1, world)
         flops = P * 6.0 * L * (3.539e6 + 1536.0 * L)            # SURVEY §8d per-pair formula
         out.update({
             "metric": "queries/sec (cross-encoder rerank of 100 candidates, L=256)", "value": round(Q / t, 2),
@@ -140,4 +172,7 @@ def run_mode(args):
                          "frac": round(flops / t / 1e12 / 2500.0, 4),
                          "note": "algorithmic fp16 FLOPs; the split-fp16 path issues 3 MFMAs per product"},
         })
-    print(json.dumps(out))
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()

@@ -148,6 +148,10 @@ int rag_bm25_load_host(rag_handle_t h, const int64_t* indptr_host /*V+1*/, const
 int rag_bm25_topk_host(rag_handle_t h, const int32_t* term_ptr_host, const int32_t* terms_host, int n_queries,
                        int k, int64_t* ids_out_host, int32_t* rows_out_host, double* scores_out_host,
                        double* raw_max_out_host);
+/* on = 1 (default): top-k scores are divided by the per-query max as rag/retrieval.py:343-345 does. on = 0: top-k
+ * scores stay raw; a row-sharded index merges the shards' raw lists first and divides by the
+ * GLOBAL max afterwards. raw_max_out is written either way. */
+int rag_bm25_set_normalize(rag_handle_t h, int on);
 /* dense scores for a (small) corpus: out[Q][N] raw (un-normalised) BM25, for hybrid_search semantics */
 int rag_bm25_scores_host(rag_handle_t h, const int32_t* term_ptr_host, const int32_t* terms_host, int n_queries,
                          double* out_host);

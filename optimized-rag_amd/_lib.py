@@ -63,6 +63,7 @@ _SIGS = {
     "rag_bm25_load_host": ([_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double], C.c_int),
     "rag_bm25_topk_host": ([_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
     "rag_bm25_scores_host": ([_P, _P, _P, C.c_int, _P], C.c_int),
+    "rag_bm25_set_normalize": ([_P, C.c_int], C.c_int),
     "rag_rrf_fuse_dev": ([_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
     "rag_bm25_topk_dev": ([_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P], C.c_int),
     "rag_hybrid_rrf_dev": ([_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P], C.c_int),
@@ -328,6 +329,32 @@ class RagEngine:
                                                 _ptr(sc), _ptr(mx)), "rag_bm25_topk_host")
         return ids, rows, sc, mx
 
+    def bm25_set_normalize(self, on):
+        """on=False: bm25_topk* return RAW scores (a row-sharded index divides by the global max after its merge)."""
+        self._check(self.lib.rag_bm25_set_normalize(self.h, 1 if on else 0), "rag_bm25_set_normalize")
+
+    def bm25_topk_dev(self, term_ptr, terms, k, ids_out, rows_out, scores_out, raw_max_out=None, stream=None):
+        """Device tensors in / out (int32 term arrays; int64 ids, float64 scores [Q, k]); asynchronous on `stream`."""
+        import torch
+        Q = term_ptr.shape[0] - 1
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        self._check(self.lib.rag_bm25_topk_dev(self.h, C.c_void_p(term_ptr.data_ptr()), C.c_void_p(terms.data_ptr()), Q, int(k),
+                                               C.c_void_p(ids_out.data_ptr()),
+                                               C.c_void_p(rows_out.data_ptr() if rows_out is not None else 0),
+                                               C.c_void_p(scores_out.data_ptr()),
+                                               C.c_void_p(raw_max_out.data_ptr() if raw_max_out is not None else 0), st),
+                    "rag_bm25_topk_dev")
+
+    def rrf_fuse_dev(self, lists, keys_out, scores_out, ranks_out, rrf_k=60, stream=None):
+        """lists: [Q, n_lists, list_len] int64 doc ids (-1 padded) on the device -> keys/scores [Q, top_k], ranks [Q, top_k, n_lists]."""
+        import torch
+        Q, n_lists, list_len = lists.shape
+        top_k = keys_out.shape[1]
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        self._check(self.lib.rag_rrf_fuse_dev(self.h, C.c_void_p(lists.data_ptr()), Q, n_lists, list_len, int(rrf_k), int(top_k),
+                                              C.c_void_p(keys_out.data_ptr()), C.c_void_p(scores_out.data_ptr()),
+                                              C.c_void_p(ranks_out.data_ptr()), st), "rag_rrf_fuse_dev")
+
     def hybrid_rrf_dev(self, q, term_ptr, terms, pool, k, rrf_k=60, tenant=-1, stream=None):
         """All-device hybrid (torch CUDA tensors): dense top-pool + BM25 top-pool -> RRF -> (keys [Q,k] int64, rrf scores
         [Q,k] float64, ranks [Q,k,2] int32). term_ptr / terms are int32 CUDA tensors."""
@@ -366,6 +393,15 @@ class RagEngine:
         arrs = [_np(t, np.float32) for t in tensors]
         ptrs = (_P * len(arrs))(*[a.ctypes.data for a in arrs])
         self._check(self.lib.rag_ce_load_host(self.h, C.byref(c), ptrs, len(arrs)), "rag_ce_load_host")
+
+    def ce_score_dev(self, input_ids, token_type_ids, lens, logits_out, stream=None):
+        """int32 CUDA tensors [P, L], [P, L], [P] -> float32 logits_out [P]; asynchronous on `stream`."""
+        import torch
+        P, L = input_ids.shape
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        self._check(self.lib.rag_ce_score_dev(self.h, C.c_void_p(input_ids.data_ptr()), C.c_void_p(token_type_ids.data_ptr()),
+                                              C.c_void_p(lens.data_ptr()), P, L, C.c_void_p(logits_out.data_ptr()), st),
+                    "rag_ce_score_dev")
 
     def ce_score(self, input_ids, token_type_ids, lens):
         ids = _np(input_ids, np.int32)

@@ -70,6 +70,17 @@ class Bm25Postings:
         idf = cls.idf_table(np.diff(indptr), n, epsilon) if V else np.zeros(0)
         return cls(indptr, doc, tf, doc_len, idf, avgdl, vocab, k1, b)
 
+    def shard(self, begin, end):
+        """Doc-partitioned slice [begin, end) for row-sharded search: postings of the shard's docs
+        with LOCAL doc numbers, the GLOBAL idf table / avgdl / vocabulary replicated (BM25 statistics are corpus-wide)."""
+        counts = np.diff(self.indptr)
+        term_of = np.repeat(np.arange(counts.shape[0], dtype=np.int64), counts)
+        keep = (self.doc >= begin) & (self.doc < end)
+        indptr = np.zeros(counts.shape[0] + 1, dtype=np.int64)
+        np.cumsum(np.bincount(term_of[keep], minlength=counts.shape[0]), out=indptr[1:])
+        return Bm25Postings(indptr, (self.doc[keep] - begin).astype(np.int32), self.tf[keep].copy(),
+                            self.doc_len[begin:end].copy(), self.idf, self.avgdl, self.vocab, self.k1, self.b)
+
     def encode_queries(self, queries):
         """List[str] -> (term_ptr int32 [Q+1], terms int32) with repeats kept and -1 for unknown tokens."""
         ptr, terms = [0], []

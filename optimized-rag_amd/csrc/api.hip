@@ -20,6 +20,7 @@ int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_
 int rrf_fuse_dev(rag_ctx* h, const int64_t* lists_dev, int Q, int L, int len, int64_t list_stride, int64_t query_stride, int rrf_k,
                  int top_k, int64_t* keys_dev, double* scores_dev, int32_t* ranks_dev, hipStream_t st);
 void bm25_free(rag_ctx* h);
+int bm25_set_normalize(rag_ctx* h, int on);
 int ce_load_host(rag_ctx* h, const rag_ce_config* cfg, const float* const* tensors, int n);
 int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L, float* out,
              hipStream_t st, bool host_ptrs);
@@ -388,6 +389,11 @@ int rag_hybrid_rrf_dev(rag_handle_t h, const float* q_dev, const int32_t* term_p
     rc = bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, lists_ws_dev + (size_t)Q * pool, nullptr, scores_ws_dev, nullptr, st);
     if (rc) return rc;
     return rrf_fuse_dev(h, lists_ws_dev, Q, 2, pool, (int64_t)Q * pool, pool, rrf_k, k, keys_out_dev, rrf_out_dev, ranks_out_dev, st);
+}
+
+int rag_bm25_set_normalize(rag_handle_t h, int on) {
+    if (!h) return RAG_ERR_ARG;
+    return bm25_set_normalize(h, on);
 }
 
 int rag_bm25_scores_host(rag_handle_t h, const int32_t* term_ptr, const int32_t* terms, int Q, double* out) {

@@ -36,6 +36,7 @@ struct rag_bm25_index {
     uint32_t* ws_row = nullptr;
     size_t ws_entries = 0;
     double avgdl = 0, k1 = 1.5, b = 0.75;
+    int normalize = 1;                 // 0: top-k scores stay raw (row-sharded search divides by the GLOBAL max after the merge)
 };
 
 __global__ void bm25_weights_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ doc,
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(const uint64_t* __restr
                                                           int n_ranges, int k, const int64_t* __restrict__ idmap,
                                                           int64_t id_base, int64_t* __restrict__ ids_out,
                                                           int32_t* __restrict__ rows_out, double* __restrict__ scores_out,
-                                                          double* __restrict__ raw_max_out) {
+                                                          double* __restrict__ raw_max_out, int normalize) {
     __shared__ uint64_t sk[BM_MERGE];
     __shared__ uint32_t sr[BM_MERGE];
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(const uint64_t* __restr
         const double s = __builtin_bit_cast(double, u);
         ids_out[(size_t)q * k + i] = ok ? (idmap ? idmap[sr[i]] : id_base + (int64_t)sr[i]) : -1;
         if (rows_out) rows_out[(size_t)q * k + i] = ok ? (int32_t)sr[i] : -1;
-        scores_out[(size_t)q * k + i] = ok ? s / mx : 0.0;
+        scores_out[(size_t)q * k + i] = ok ? (normalize ? s / mx : s) : 0.0;
     }
 }
 
@@ -404,7 +405,7 @@ static int bm25_run(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, i
         if (mode == 0)
             hipLaunchKernelGGL(bm25_merge_kernel, dim3(Q), dim3(256), 0, st, pk, pr, n_ranges, k,
                                h->n_rows == ix->n_docs ? h->ids : (const int64_t*)nullptr,
-                               h->n_rows == ix->n_docs ? h->id_base : (int64_t)0, idd, rwd, scd, mxd);
+                               h->n_rows == ix->n_docs ? h->id_base : (int64_t)0, idd, rwd, scd, mxd, ix->normalize);
         e = hipGetLastError();
     }
     if (mode == 0) {
@@ -452,8 +453,14 @@ int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_
     const bool aligned = h->n_rows == ix->n_docs;
     hipLaunchKernelGGL(bm25_merge_kernel, dim3(Q), dim3(256), 0, st, ix->ws_key, ix->ws_row, ix->n_ranges, k,
                        aligned ? h->ids : (const int64_t*)nullptr, aligned ? h->id_base : (int64_t)0, ids_dev, rows_dev, scores_dev,
-                       raw_max_dev);
+                       raw_max_dev, ix->normalize);
     HIP_TRY(h, hipGetLastError());
+    return RAG_OK;
+}
+
+int bm25_set_normalize(rag_ctx* h, int on) {
+    ARG_CHECK(h, h->bm25 != nullptr, "no BM25 index loaded");
+    h->bm25->normalize = on ? 1 : 0;
     return RAG_OK;
 }
 

@@ -1,7 +1,12 @@
-"""Row-sharded dense search across the GPUs of one node: one process per GPU, corpus rows
-partitioned contiguously, ONE small collective per batch.
+"""Row-sharded search across the GPUs of one node: one process per GPU, corpus rows (embeddings, BM25
+postings, token ids) partitioned contiguously, ONE small collective per stage.
 
-    local top-k (rag_dense_topk_dev)  ->  all_gather of [ids | float64 score bits]  ->  rag_merge_topk_dev
+    dense :  local top-k (rag_dense_topk_dev)  ->  all_gather of [ids | float64 score bits]  ->  rag_merge_topk_dev
+    hybrid:  local dense top-pool + local RAW BM25 top-pool (global idf / avgdl replicated)  ->  ONE all_gather of both
+             lists  ->  two merges  ->  BM25 / global max  ->  rag_rrf_fuse_dev on the merged lists (RRF needs GLOBAL
+             ranks, so the lists are merged before fusing)
+    rerank:  the Q x pool pairs are independent: each rank scores a contiguous slice (rag_ce_score_dev), one all_gather
+             of the logits
 
 The reference is single-process (no collective to mirror). torch.distributed (backend "nccl" = RCCL over xGMI on
 the GPU box, "gloo" in CPU tests) is plumbing only; the merge is the HIP kernel. The payload is Q*k*16 B per rank
@@ -52,10 +57,107 @@ class ShardedDenseIndex:
         self.engine.dense_topk_dev(queries, k, send[0], None, send[1].view(torch.float64), tenant=tenant)
         if self.world == 1:
             return send[0], send[1].view(torch.float64)
-        if dist.get_backend(self.group) == "nccl":          # RCCL: one flat gather straight into the merge buffer
-            dist.all_gather_into_tensor(recv, send, group=self.group)
-        else:
-            dist.all_gather(list(recv.unbind(0)), send, group=self.group)
+        _gather(recv, send, self.group)
         self.engine.merge_topk_dev(recv, recv.view(torch.float64)[:, 1], out_ids, out_scores, n_lists=self.world,
                                    list_stride=2 * Q * k)
         return out_ids, out_scores
+
+
+def _gather(recv, send, group):
+    if dist.get_backend(group) == "nccl":                   # RCCL: one flat gather straight into the merge buffer
+        dist.all_gather_into_tensor(recv, send, group=group)
+    else:
+        dist.all_gather(list(recv.unbind(0)), send, group=group)
+
+
+class ShardedHybridIndex(ShardedDenseIndex):
+    """Dense + BM25 + RRF over row shards. Every rank ends up with the same global result.
+
+    The engine of each rank holds its rows of the embedding matrix (ids = first_global_row + local row) and the
+    doc-partitioned slice of the postings built by Bm25Postings.shard (global statistics), loaded row-aligned so both
+    searches speak the same doc-id space."""
+
+    def load_shard(self, emb_shard, first_global_row, postings_shard=None):
+        super().load_shard(emb_shard, first_global_row)
+        if postings_shard is not None:
+            postings_shard.load(self.engine)
+        self.engine.bm25_set_normalize(False)
+
+    def _hyb_buffers(self, Q, pool, k, device):
+        key = ("hyb", Q, pool, k, str(device))
+        if key not in self._bufs:
+            i64, f64 = torch.int64, torch.float64
+            self._bufs[key] = dict(
+                send=torch.empty((4, Q, pool), dtype=i64, device=device),          # dense ids | dense score bits | bm25 ids | bm25 raw bits
+                recv=torch.empty((self.world, 4, Q, pool), dtype=i64, device=device),
+                lists=torch.empty((Q, 2, pool), dtype=i64, device=device),
+                dense_sc=torch.empty((Q, pool), dtype=f64, device=device),
+                bm_ids=torch.empty((Q, pool), dtype=i64, device=device),
+                dense_ids=torch.empty((Q, pool), dtype=i64, device=device),
+                bm_sc=torch.empty((Q, pool), dtype=f64, device=device),
+                keys=torch.empty((Q, k), dtype=i64, device=device),
+                rrf=torch.empty((Q, k), dtype=f64, device=device),
+                ranks=torch.empty((Q, k, 2), dtype=torch.int32, device=device))
+        return self._bufs[key]
+
+    def local_lists(self, queries, term_ptr, terms, pool, k, tenant=-1):
+        """This rank's half of the exchange: [4, Q, pool] int64 = dense ids | dense score bits | BM25 ids | raw BM25 bits."""
+        send = self._hyb_buffers(queries.shape[0], pool, k, queries.device)["send"]
+        f64 = torch.float64
+        self.engine.dense_topk_dev(queries, pool, send[0], None, send[1].view(f64), tenant=tenant)
+        self.engine.bm25_topk_dev(term_ptr, terms, pool, send[2], None, send[3].view(f64))
+        return send
+
+    def fuse_gathered(self, recv, k, rrf_k=60):
+        """recv: [world, 4, Q, pool] int64, every rank's local_lists() -> the global result (see search_hybrid)."""
+        world, _, Q, pool = recv.shape
+        b = self._hyb_buffers(Q, pool, k, recv.device)
+        stride = 4 * Q * pool
+        rf = recv.view(torch.float64)
+        self.engine.merge_topk_dev(recv, rf[:, 1], b["dense_ids"], b["dense_sc"], n_lists=world, list_stride=stride)
+        self.engine.merge_topk_dev(recv[:, 2], rf[:, 3], b["bm_ids"], b["bm_sc"], n_lists=world, list_stride=stride)
+        # rag/retrieval.py:343-345 with the global maximum: the merged list is sorted, so its head is the max
+        top = b["bm_sc"][:, :1]
+        b["bm_sc"] /= torch.where(top > 0, top, torch.ones_like(top))
+        b["lists"][:, 0] = b["dense_ids"]
+        b["lists"][:, 1] = b["bm_ids"]
+        self.engine.rrf_fuse_dev(b["lists"], b["keys"], b["rrf"], b["ranks"], rrf_k=rrf_k)
+        return dict(keys=b["keys"], rrf=b["rrf"], ranks=b["ranks"], dense_ids=b["dense_ids"], dense_scores=b["dense_sc"],
+                    bm25_ids=b["bm_ids"], bm25_scores=b["bm_sc"])
+
+    def search_hybrid(self, queries, term_ptr, terms, pool, k, rrf_k=60, tenant=-1):
+        """queries [Q, dim] float32, term_ptr [Q+1] / terms int32 (global term ids, -1 = unknown), all replicated.
+        Returns dict(keys [Q,k], rrf [Q,k], ranks [Q,k,2] (1-based rank in the dense / BM25 list, 0 = absent),
+        dense_ids/dense_scores [Q,pool], bm25_ids/bm25_scores [Q,pool] (scores max-normalised with the GLOBAL max))."""
+        send = self.local_lists(queries, term_ptr, terms, pool, k, tenant)
+        if self.world == 1:
+            return self.fuse_gathered(send.unsqueeze(0), k, rrf_k)
+        recv = self._hyb_buffers(queries.shape[0], pool, k, queries.device)["recv"]
+        _gather(recv, send, self.group)
+        return self.fuse_gathered(recv, k, rrf_k)
+
+
+class ShardedReranker:
+    """Cross-encoder scoring of P independent (query, passage) pairs split evenly over the ranks; every rank has the
+    model loaded (rag_ce_load_host) and receives all P logits. One all_gather of P/world float32 per rank."""
+
+    def __init__(self, engine, rank=None, world=None, group=None):
+        self.engine = engine
+        self.group = group
+        self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
+
+    def score(self, input_ids, token_type_ids, lens):
+        """int32 tensors [P, L], [P, L], [P] replicated on every rank -> float32 logits [P] on every rank."""
+        P = input_ids.shape[0]
+        per = (P + self.world - 1) // self.world                    # equal slices (the last one may be short)
+        lo, hi = min(P, self.rank * per), min(P, (self.rank + 1) * per)
+        mine = torch.zeros((per,), dtype=torch.float32, device=input_ids.device)
+        if hi > lo:
+            self.engine.ce_score_dev(input_ids[lo:hi].contiguous(), token_type_ids[lo:hi].contiguous(),
+                                     lens[lo:hi].contiguous(), mine[: hi - lo])
+        if self.world == 1:
+            return mine[:P]
+        out = torch.empty((self.world, per), dtype=torch.float32, device=input_ids.device)
+        _gather(out, mine, self.group)
+        return out.reshape(-1)[:P]

@@ -384,3 +384,47 @@ def test_hybrid_rrf_dev_matches_oracle_pipeline(eng):
         assert keys[qi].tolist() == okeys
         assert rrf[qi].tolist() == oscores                                    # bit-exact float64
         assert ranks[qi].tolist() == oranks
+
+
+def test_row_sharded_hybrid_equals_unsharded(eng):
+    """SURVEY §8e on one GPU: three engines hold three row shards (embeddings + doc-partitioned postings with the GLOBAL
+    idf / avgdl), their local_lists() are stacked as the all-gather would, and fuse_gathered() must reproduce the
+    unsharded rag_hybrid_rrf_dev result bit for bit (keys, ranks, float64 RRF scores) and the globally normalised BM25."""
+    import torch
+    from optimized_rag_amd import RagEngine
+    from optimized_rag_amd.bm25 import Bm25Postings
+    from optimized_rag_amd.sharded import ShardedHybridIndex, shard_bounds
+    rng = np.random.default_rng(77)
+    N, D, Q, pool, k, W = 5001, 1536, 14, 50, 20, 3
+    docs = synthetic_postings(rng, N, 800, 12)
+    corpus = [" ".join(f"t{t}" for t in d) for d in docs]
+    emb = rng.standard_normal((N, D)).astype(np.float32)
+    emb[4000] = emb[100]                                                          # cross-shard exact dense tie
+    q = (emb[rng.integers(0, N, Q)] + 0.5 * rng.standard_normal((Q, D))).astype(np.float32)
+    q[0] = emb[100]
+    queries = [" ".join(f"t{t}" for t in rng.choice(docs[int(rng.integers(0, N))] or [1], size=4)) for _ in range(Q)]
+    queries[1] = "zzz-unknown-token"                                              # all-zero BM25 list: divisor stays 1.0
+    post = Bm25Postings.from_corpus(corpus)
+    ptr, terms = post.encode_queries(queries)
+    qd, pd, td = torch.from_numpy(q).cuda(), torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda()
+
+    eng.index_load(emb)
+    post.load(eng)
+    keys, rrf, ranks = [t.cpu().numpy().copy() for t in eng.hybrid_rrf_dev(qd, pd, td, pool, k)]
+    _, _, bsc, _ = eng.bm25_topk(ptr, terms, pool)
+
+    shards, sends = [], []
+    for r, (b, e) in enumerate(shard_bounds(N, W)):
+        se = RagEngine(dim=D, device=0)
+        sh = ShardedHybridIndex(se, rank=r, world=W)
+        sh.load_shard(emb[b:e], b, post.shard(b, e))
+        sends.append(sh.local_lists(qd, pd, td, pool, k).clone())
+        shards.append((se, sh))
+    out = shards[0][1].fuse_gathered(torch.stack(sends), k)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out["keys"].cpu().numpy(), keys)
+    np.testing.assert_array_equal(out["ranks"].cpu().numpy(), ranks)
+    np.testing.assert_array_equal(out["rrf"].cpu().numpy(), rrf)                  # bit-exact float64
+    np.testing.assert_array_equal(out["bm25_scores"].cpu().numpy(), bsc)          # same raw / same global max -> same quotient
+    for se, _ in shards:
+        se.close()

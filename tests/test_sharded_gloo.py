@@ -30,22 +30,63 @@ class OracleEngine:
 
     def merge_topk_dev(self, ids, scores, ids_out, scores_out, n_lists=None, list_stride=None, stream=None):
         Q, k = ids_out.shape
-        fi = ids.reshape(-1)
-        fs = scores.reshape(-1) if scores.is_contiguous() else None
-        base_s = (scores.data_ptr() - ids.data_ptr()) // 8
-        flat = ids.reshape(-1)
-        flat_s = flat.view(torch.float64)
+        # raw-pointer semantics of the C-ABI: list l starts l*list_stride elements after the first element handed in
+        span = (n_lists - 1) * list_stride + Q * k
+        flat = torch.as_strided(ids, (span,), (1,))
+        flat_s = torch.as_strided(scores, (span,), (1,))
         for q in range(Q):
             cand = []
             for l in range(n_lists):
                 for j in range(k):
                     i = int(flat[l * list_stride + q * k + j])
                     if i >= 0:
-                        cand.append((-float(flat_s[base_s + l * list_stride + q * k + j]), i))
+                        cand.append((-float(flat_s[l * list_stride + q * k + j]), i))
             cand.sort()
             for j in range(k):
                 ids_out[q, j] = cand[j][1] if j < len(cand) else -1
                 scores_out[q, j] = -cand[j][0] if j < len(cand) else 0.0
+
+
+    # ---- BM25 / RRF / cross-encoder doubles for ShardedHybridIndex and ShardedReranker --------------------------
+    def bm25_load(self, indptr, doc, tf, doc_len, idf, avgdl, k1=1.5, b=0.75):
+        self.bm = (np.asarray(indptr), np.asarray(doc), np.asarray(tf), np.asarray(doc_len), np.asarray(idf), avgdl, k1, b)
+
+    def bm25_set_normalize(self, on):
+        self.bm_norm = bool(on)
+
+    def bm25_topk_dev(self, term_ptr, terms, k, ids_out, rows_out, scores_out, raw_max_out=None, stream=None):
+        assert not self.bm_norm, "a row shard must hand out RAW scores"
+        indptr, doc, tf, dl, idf, avgdl, k1, b = self.bm
+        tp, tm = term_ptr.numpy(), terms.numpy()
+        for q in range(tp.shape[0] - 1):
+            sc = np.zeros(dl.shape[0])
+            for t in tm[tp[q]:tp[q + 1]]:
+                if t < 0:
+                    continue
+                a, e = int(indptr[t]), int(indptr[t + 1])
+                d, f = doc[a:e], tf[a:e].astype(np.float64)
+                sc[d] += idf[t] * (f * (k1 + 1) / (f + k1 * (1 - b + b * dl[d] / avgdl)))
+            rows = O.stable_topk_desc(sc, k)
+            for j in range(k):
+                ids_out[q, j] = self.id_base + rows[j] if j < len(rows) else -1
+                scores_out[q, j] = sc[rows[j]] if j < len(rows) else 0.0
+
+    def rrf_fuse_dev(self, lists, keys_out, scores_out, ranks_out, rrf_k=60, stream=None):
+        Q, top_k = keys_out.shape
+        for q in range(Q):
+            keys, sc, rk = O.rrf_fuse([[int(x) for x in l if x >= 0] for l in lists[q].tolist()], k=rrf_k, top_k=top_k)
+            for j in range(top_k):
+                keys_out[q, j] = keys[j] if j < len(keys) else -1
+                scores_out[q, j] = sc[j] if j < len(keys) else 0.0
+                ranks_out[q, j] = torch.tensor(rk[j] if j < len(keys) else [0] * lists.shape[1], dtype=torch.int32)
+
+    def ce_score_dev(self, input_ids, token_type_ids, lens, logits_out, stream=None):
+        logits_out.copy_(fake_logits(input_ids, token_type_ids, lens))
+
+
+def fake_logits(ids, tt, lens):
+    """Any deterministic per-pair function: the reranker test checks the pair split / gather, not BERT."""
+    return ((ids * (1 + tt)).sum(1) % 1000).to(torch.float32) / 100.0 - lens.to(torch.float32)
 
 
 def _free_port():
@@ -77,6 +118,59 @@ def _worker(rank, world, port, n_rows, ret):
         ret[rank] = ok
     finally:
         dist.destroy_process_group()
+
+
+def _hybrid_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from optimized_rag_amd.bm25 import Bm25Postings
+        from optimized_rag_amd.sharded import ShardedHybridIndex, ShardedReranker, shard_bounds
+        rng = np.random.default_rng(11)
+        N, D, Q, pool, k = 157, 32, 6, 12, 5
+        words = [f"w{i}" for i in range(40)]
+        corpus = [" ".join(rng.choice(words, size=int(rng.integers(3, 12)))) for _ in range(N)]
+        emb = rng.standard_normal((N, D)).astype(np.float32)
+        q = (emb[rng.integers(0, N, Q)] + 0.4 * rng.standard_normal((Q, D))).astype(np.float32)
+        queries = [" ".join(rng.choice(words, size=3)) for _ in range(Q)]
+        queries[2] = "not-in-vocabulary"
+        post = Bm25Postings.from_corpus(corpus)
+        ptr, terms = post.encode_queries(queries)
+        b, e = shard_bounds(N, world)[rank]
+        idx = ShardedHybridIndex(OracleEngine(), rank=rank, world=world)
+        idx.load_shard(emb[b:e], b, post.shard(b, e))
+        out = idx.search_hybrid(torch.from_numpy(q), torch.from_numpy(ptr), torch.from_numpy(terms), pool, k)
+        # expectation: the unsharded oracle pipeline (dense top-pool, BM25 top-pool, RRF)
+        d_rows, _ = O.dense_topk(emb, q, pool)
+        obm = O.BM25Okapi([O.tokenize(c) for c in corpus])
+        ok = True
+        for qi in range(Q):
+            raw = obm.get_scores(O.tokenize(queries[qi]))
+            b_rows = O.stable_topk_desc(raw, pool)
+            keys, sc, rk = O.rrf_fuse([[int(r) for r in d_rows[qi]], [int(r) for r in b_rows]], k=60, top_k=k)
+            mx = raw.max() if raw.max() > 0 else 1.0
+            ok &= out["keys"][qi].tolist() == keys and out["rrf"][qi].tolist() == sc and out["ranks"][qi].tolist() == rk
+            ok &= out["bm25_ids"][qi].tolist() == [int(r) for r in b_rows]
+            ok &= out["bm25_scores"][qi].tolist() == [float(raw[r] / mx) for r in b_rows]
+        # rerank split: P pairs not divisible by the world size
+        P, L = 11, 16
+        ids = torch.from_numpy(rng.integers(1000, 30000, (P, L)).astype(np.int32))
+        tt = torch.from_numpy((np.arange(L)[None, :] >= 5).astype(np.int32).repeat(P, 0))
+        lens = torch.from_numpy(rng.integers(6, L + 1, P).astype(np.int32))
+        got = ShardedReranker(OracleEngine(), rank=rank, world=world).score(ids, tt, lens)
+        ok &= bool(torch.equal(got, fake_logits(ids, tt, lens)))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_hybrid_and_rerank_equal_global():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_hybrid_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
 
 
 @pytest.mark.parametrize("n_rows", [101, 40])
