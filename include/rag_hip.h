@@ -136,6 +136,18 @@ int rag_hybrid_rrf_dev(rag_handle_t h, const float* q_dev, const int32_t* term_p
                        double* scores_ws_dev, int64_t* keys_out_dev, double* rrf_out_dev, int32_t* ranks_out_dev,
                        void* stream);
 
+/* ---- greedy MMR selection on the device: replaces the Python loops of
+ *      MMRDiversifier.diversify (rag/reranker.py:116-195; variant 0: lambda*rel + (1-lambda)*(1-max_sim), first pick has
+ *      diversity 1.0) and apply_mmr (rag/nodes/helpers.py:183-260; variant 1: lambda*rel - (1-lambda)*max_sim).
+ *      First maximal candidate wins ties, float64 throughout. n (pool) <= 256. sel_out = positions into the candidate
+ *      list (-1 padded when fewer than top_k candidates), score_out = the MMR score each pick won with.
+ *      _host: explicit candidate embeddings emb[n][dim]. _dev: candidates are rows of the resident index
+ *      (rows_dev[Q][pool], -1 = empty), queries q_dev[Q][dim]; embeddings never leave HBM. */
+int rag_mmr_select_host(rag_handle_t h, const float* query_host /*dim*/, const float* emb_host /*n x dim*/, int n, int dim,
+                        int top_k, double lambda, int variant, int32_t* sel_out_host, double* score_out_host);
+int rag_mmr_select_dev(rag_handle_t h, const float* q_dev, const int32_t* rows_dev, int n_queries, int pool, int top_k,
+                       double lambda, int variant, int32_t* sel_out_dev, double* score_out_dev, void* stream);
+
 /* ---- BM25 over CSR postings: replaces BM25Okapi(tokenized_corpus).get_scores(query) + the /max
  *      normalisation (rag/retrieval.py:324-347). Postings are term-major CSR, docs ascending per term.
  *      idf[V] is computed by the host exactly as rank-bm25 does (float64). */

@@ -64,6 +64,8 @@ _SIGS = {
     "rag_bm25_topk_host": ([_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
     "rag_bm25_scores_host": ([_P, _P, _P, C.c_int, _P], C.c_int),
     "rag_bm25_set_normalize": ([_P, C.c_int], C.c_int),
+    "rag_mmr_select_host": ([_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _P, _P], C.c_int),
+    "rag_mmr_select_dev": ([_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _P, _P, _P], C.c_int),
     "rag_rrf_fuse_dev": ([_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
     "rag_bm25_topk_dev": ([_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P], C.c_int),
     "rag_hybrid_rrf_dev": ([_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P], C.c_int),
@@ -279,6 +281,31 @@ class RagEngine:
             self._check(self.lib.rag_pairwise_cosine_host(self.h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1],
                                                           _ptr(out)), "rag_pairwise_cosine_host")
         return out
+
+    MMR_MAX_CANDIDATES = 256
+
+    def mmr_select(self, query, embs, top_k, lam, variant):
+        """Greedy MMR over explicit candidates: query [dim], embs [n, dim] float32 -> (positions [<=top_k], scores).
+        variant 0 = MMRDiversifier.diversify, 1 = apply_mmr (see include/rag_hip.h)."""
+        query = _np(query, np.float32).reshape(-1)
+        embs = _np(embs, np.float32)
+        n, dim = embs.shape
+        kk = int(min(top_k, n))
+        sel = np.empty((kk,), dtype=np.int32)
+        sc = np.empty((kk,), dtype=np.float64)
+        self._check(self.lib.rag_mmr_select_host(self.h, _ptr(query), _ptr(embs), n, dim, kk, float(lam), int(variant),
+                                                 _ptr(sel), _ptr(sc)), "rag_mmr_select_host")
+        keep = sel >= 0
+        return sel[keep], sc[keep]
+
+    def mmr_select_dev(self, q, rows, top_k, lam, variant, sel_out, score_out, stream=None):
+        """Batched MMR over rows of the resident index: q [Q, dim] float32, rows [Q, pool] int32 (CUDA tensors)."""
+        import torch
+        Q, pool = rows.shape
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        self._check(self.lib.rag_mmr_select_dev(self.h, C.c_void_p(q.data_ptr()), C.c_void_p(rows.data_ptr()), Q, pool,
+                                                int(top_k), float(lam), int(variant), C.c_void_p(sel_out.data_ptr()),
+                                                C.c_void_p(score_out.data_ptr()), st), "rag_mmr_select_dev")
 
     def rrf_fuse(self, lists, rrf_k=60, top_k=10):
         """lists: int64 [Q, L, len] (-1 padded at tails). Returns (keys [Q,top_k], scores, ranks [Q,top_k,L])."""

@@ -21,6 +21,10 @@ int rrf_fuse_dev(rag_ctx* h, const int64_t* lists_dev, int Q, int L, int len, in
                  int top_k, int64_t* keys_dev, double* scores_dev, int32_t* ranks_dev, hipStream_t st);
 void bm25_free(rag_ctx* h);
 int bm25_set_normalize(rag_ctx* h, int on);
+int mmr_select_dev(rag_ctx* h, const float* queries_dev, const float* emb_dev, const int32_t* rows_dev, int Q, int n, int dim,
+                   int top_k, double lam, int variant, int32_t* sel_dev, double* score_dev, hipStream_t st);
+int mmr_select_host(rag_ctx* h, const float* query, const float* emb, int n, int dim, int top_k, double lam, int variant,
+                    int32_t* sel_out, double* score_out);
 int ce_load_host(rag_ctx* h, const rag_ce_config* cfg, const float* const* tensors, int n);
 int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L, float* out,
              hipStream_t st, bool host_ptrs);
@@ -419,6 +423,23 @@ int rag_ce_score_dev(rag_handle_t h, const int32_t* ids, const int32_t* tt, cons
     if (!h) return RAG_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     return ce_score(h, ids, tt, lens, P, L, out, (hipStream_t)stream, false);
+}
+
+int rag_mmr_select_host(rag_handle_t h, const float* query, const float* emb, int n, int dim, int top_k, double lambda,
+                        int variant, int32_t* sel_out, double* score_out) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return mmr_select_host(h, query, emb, n, dim, top_k, lambda, variant, sel_out, score_out);
+}
+
+// candidates = rows of the resident index (fp32 master rows): rows_dev[Q][pool], -1 = empty slot
+int rag_mmr_select_dev(rag_handle_t h, const float* q_dev, const int32_t* rows_dev, int Q, int pool, int top_k, double lambda,
+                       int variant, int32_t* sel_dev, double* score_dev, void* stream) {
+    if (!h) return RAG_ERR_ARG;
+    ARG_CHECK(h, h->emb32 != nullptr && rows_dev, "mmr_select_dev: no index loaded / null rows");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return mmr_select_dev(h, q_dev, h->emb32, rows_dev, Q, pool, h->dim, top_k, lambda, variant, sel_dev, score_dev,
+                          (hipStream_t)stream);
 }
 
 }  // extern "C"

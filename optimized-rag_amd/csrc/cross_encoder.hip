@@ -698,7 +698,7 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
 static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L) {
     if (P <= m->ws_pairs && L == m->ws_L) return RAG_OK;
     ce_free_ws(m);
-    const int H = m->cfg.hidden, F = m->cfg.ffn;
+    const int H = m->cfg.hidden;
     const int64_t Mp = round_up((int64_t)P * L, CE_BN);
     HIP_TRY(h, hipMalloc(&m->x32, (size_t)Mp * H * 4));
     HIP_TRY(h, hipMalloc(&m->y32, (size_t)Mp * H * 4));

@@ -25,6 +25,9 @@ def apply_mmr(query: str, documents: List[Dict[str, Any]], lambda_: float, k: in
                 doc["embedding"] = emb
                 embs.append(emb)
         m = as_matrix([q_emb] + embs)
+        if len(documents) <= eng.MMR_MAX_CANDIDATES:           # greedy loop on the device (rag_mmr_select_host, variant 1)
+            selected, _ = eng.mmr_select(m[0], m[1:], k, lambda_, 1)
+            return [documents[int(i)] for i in selected]
         S = eng.pairwise_cosine(m, m[1:])
         rel, sim = S[0], S[1:]
         selected, remaining = [], list(range(len(documents)))

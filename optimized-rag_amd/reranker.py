@@ -76,11 +76,17 @@ class MMRDiversifier(_EngineMixin):
         if not valid:
             logger.warning("MMR: No valid embeddings found, returning original results")
             return results[:top_k]
-        # one cosine matrix [query | docs] x [docs] replaces the O(k*n*|selected|) Python cosine calls
         m = as_matrix([query_embedding if query_embedding else []] + [r['embedding'] for r in valid])
+        lam = self.lambda_param
+        if len(valid) <= self.engine.MMR_MAX_CANDIDATES:
+            # the whole greedy loop runs on the device (rag_mmr_select_host, variant 0)
+            selected, scores = self.engine.mmr_select(m[0], m[1:], top_k, lam, 0)
+            for i, sc in zip(selected, scores):
+                valid[int(i)]['mmr_score'] = float(sc)
+            return [valid[int(i)] for i in selected]
+        # larger pools: one cosine matrix [query | docs] x [docs] on the device, greedy loop on the host
         S = self.engine.pairwise_cosine(m, m[1:])
         rel, sim = S[0], S[1:]
-        lam = self.lambda_param
         selected, remaining = [], list(range(len(valid)))
         while len(selected) < top_k and remaining:
             best, best_s = None, None

@@ -428,3 +428,44 @@ def test_row_sharded_hybrid_equals_unsharded(eng):
     np.testing.assert_array_equal(out["bm25_scores"].cpu().numpy(), bsc)          # same raw / same global max -> same quotient
     for se, _ in shards:
         se.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_mmr_device_selection_matches_oracle(eng, variant):
+    """rag_mmr_select_host on explicit candidates and rag_mmr_select_dev on index rows == the oracle's greedy loops
+    (positions identical; the scores each pick won with within 1e-12), incl. duplicates, a zero row and -1 padding."""
+    import torch
+    rng = np.random.default_rng(90 + variant)
+    N, D, Q, pool, k, lam = 4000, 1536, 6, 100, 20, 0.7
+    centers = rng.standard_normal((12, D))
+    emb = (centers[rng.integers(0, 12, N)] + 0.6 * rng.standard_normal((N, D))).astype(np.float32)   # clustered: diversity matters
+    emb[17] = emb[5]                                                        # exact duplicate rows
+    emb[23] = 0.0                                                           # zero-norm row: cosine 0.0
+    q = (centers[:Q] + 0.5 * rng.standard_normal((Q, D))).astype(np.float32)
+    eng.index_load(emb)
+    rows = np.stack([rng.choice(N, pool, replace=False) for _ in range(Q)]).astype(np.int32)
+    rows[0, :4] = [5, 17, 23, 40]
+    rows[1, 60:] = -1                                                       # short pool
+    rows[2, 3:] = -1                                                        # fewer candidates than k
+    sel = torch.empty((Q, k), dtype=torch.int32, device="cuda")
+    sc = torch.empty((Q, k), dtype=torch.float64, device="cuda")
+    eng.mmr_select_dev(torch.from_numpy(q).cuda(), torch.from_numpy(rows).cuda(), k, lam, variant, sel, sc)
+    torch.cuda.synchronize()
+    sel, sc = sel.cpu().numpy(), sc.cpu().numpy()
+    for qi in range(Q):
+        live = [j for j in range(pool) if rows[qi, j] >= 0]
+        cand = [emb[rows[qi, j]].astype(np.float64).tolist() for j in live]
+        if variant == 0:
+            pos, osc = O.mmr_class(q[qi].astype(np.float64).tolist(), cand, k, lam)
+        else:
+            pos = O.mmr_helper(q[qi].astype(np.float64).tolist(), cand, k, lam) if len(cand) > k else None
+            osc = None
+        if pos is None:                                   # apply_mmr returns its input unchanged when len <= k (host-side rule)
+            continue
+        want = [live[p] for p in pos] + [-1] * (k - len(pos))
+        assert sel[qi].tolist() == want
+        if osc is not None:
+            np.testing.assert_allclose(sc[qi, :len(osc)], osc, atol=1e-12)
+        # explicit-candidate host entry gives the same picks
+        hs, hsc = eng.mmr_select(q[qi], np.asarray([emb[rows[qi, j]] for j in live]), k, lam, variant)
+        assert hs.tolist() == pos
