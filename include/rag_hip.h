@@ -65,6 +65,9 @@ int rag_index_append_dev(rag_handle_t h, const float* emb_dev, int64_t n_rows, v
 /* Optional multi-tenant filter: tenant_of_row[n_rows] (the `WHERE dc.agent_id = %s`,
  * rag/document_store.py:457). tenant < 0 in a search = no filter. */
 int rag_index_set_tenants_host(rag_handle_t h, const int32_t* tenant_of_row_host, int64_t n_rows);
+/* Explicit doc ids (e.g. the table's primary keys) for an index filled through rag_index_reserve/append: ids[n_rows],
+ * n_rows == rows appended so far; NULL restores id = id_base + row. */
+int rag_index_set_ids_host(rag_handle_t h, const int64_t* ids_host, int64_t n_rows);
 int rag_index_rows(rag_handle_t h, int64_t* n_rows_out);
 /* copy rows' fp32 embeddings back (kills apply_mmr's per-doc re-embedding, rag/nodes/helpers.py:215-223) */
 int rag_index_fetch_rows_host(rag_handle_t h, const int64_t* rows_host, int n, float* out_host);

@@ -51,6 +51,7 @@ _SIGS = {
     "rag_index_append_host": ([_P, _P, C.c_int64], C.c_int),
     "rag_index_append_dev": ([_P, _P, C.c_int64, _P], C.c_int),
     "rag_index_set_tenants_host": ([_P, _P, C.c_int64], C.c_int),
+    "rag_index_set_ids_host": ([_P, _P, C.c_int64], C.c_int),
     "rag_index_rows": ([_P, C.POINTER(C.c_int64)], C.c_int),
     "rag_index_fetch_rows_host": ([_P, _P, C.c_int, _P], C.c_int),
     "rag_dense_topk_host": ([_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P], C.c_int),
@@ -212,6 +213,10 @@ class RagEngine:
         t = None if tenant_of_row is None else _np(tenant_of_row, np.int32)
         self._check(self.lib.rag_index_set_tenants_host(self.h, _ptr(t), 0 if t is None else t.shape[0]),
                     "rag_index_set_tenants_host")
+
+    def set_ids(self, ids):
+        ids = _np(ids, np.int64)
+        self._check(self.lib.rag_index_set_ids_host(self.h, _ptr(ids), ids.shape[0]), "rag_index_set_ids_host")
 
     def fetch_rows(self, rows):
         rows = _np(rows, np.int64)

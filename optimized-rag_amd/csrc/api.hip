@@ -189,6 +189,18 @@ int rag_index_set_tenants_host(rag_handle_t h, const int32_t* t, int64_t n_rows)
     return RAG_OK;
 }
 
+int rag_index_set_ids_host(rag_handle_t h, const int64_t* ids, int64_t n_rows) {
+    if (!h) return RAG_ERR_ARG;
+    ARG_CHECK(h, n_rows == h->n_rows, "id array length must equal the index row count");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipFree(h->ids);
+    h->ids = nullptr;
+    if (ids == nullptr || n_rows == 0) return RAG_OK;
+    HIP_TRY(h, hipMalloc(&h->ids, (size_t)n_rows * sizeof(int64_t)));
+    HIP_TRY(h, hipMemcpy(h->ids, ids, (size_t)n_rows * sizeof(int64_t), hipMemcpyHostToDevice));
+    return RAG_OK;
+}
+
 int rag_index_rows(rag_handle_t h, int64_t* n_rows_out) {
     if (!h || !n_rows_out) return RAG_ERR_ARG;
     *n_rows_out = h->n_rows;

@@ -14,6 +14,24 @@ from .engine import get_engine
 logger = logging.getLogger(__name__)
 
 
+class _ShardRows:
+    """List-like view of a shard's payload rows [begin, end): `rows[i]` reads one JSON line from disk."""
+
+    def __init__(self, shard, begin, end):
+        self.shard, self.begin, self.end = shard, begin, end
+
+    def __len__(self):
+        return self.end - self.begin
+
+    def __getitem__(self, i):
+        g = self.begin + int(i)
+        r = self.shard.row(g)
+        r["id"] = int(self.shard.ids[g])
+        ts = float(self.shard.created_at[g])
+        r["created_at"] = None if ts != ts else ts
+        return r
+
+
 class GpuDocumentIndex:
     def __init__(self, embedding_service, dim: int = 1536, *, engine=None):
         self.embeddings = embedding_service            # same attribute name the reference's DocumentStore uses
@@ -39,6 +57,17 @@ class GpuDocumentIndex:
             tenants[i] = self._tenant_id.setdefault(str(r.get("agent_id", "")), len(self._tenant_id))
         self.engine.index_load(emb)
         self.engine.set_tenants(tenants)
+
+    def load_shard(self, shard, begin: int = 0, end: Optional[int] = None, chunk_rows: int = 131072) -> None:
+        """Stream an exported shard directory (shard_format.py; path or open Shard) into the index: rows [begin, end),
+        payloads stay on disk and are read lazily per hit, doc ids are the table's primary keys."""
+        from . import shard_format as SF
+        sh = SF.open_shard(shard) if isinstance(shard, str) else shard
+        end = sh.n_rows if end is None else end
+        assert sh.dim == self.dim
+        SF.load_shard_into(self.engine, sh, begin, end, chunk_rows)
+        self._tenant_id = dict(sh.tenant_table)
+        self.rows = _ShardRows(sh, begin, end)
 
     def _search_rows(self, agent_id, query_embeddings, top_k):
         if agent_id is not None and str(agent_id) not in self._tenant_id:

@@ -229,3 +229,30 @@ def test_device_entry_points_are_ordered_with_the_callers_stream(eng_factory):
     eng.dense_topk_dev(q, 4, ids, None, sc)
     got = ids[:, 0].clone()                                          # consumer on the same stream, no sync in between
     assert got.cpu().tolist() == [b * blk_rows for b in range(n_blk)]
+
+
+def test_shard_directory_streams_into_the_index(eng_factory, tmp_path):
+    """export rows shaped like document_chunks -> shard directory -> chunked load (whole shard and a
+    [begin, end) row range as one rank of a multi-GPU run would) -> search returns the table's primary keys, honours
+    the agent_id filter and matches the oracle."""
+    from optimized_rag_amd import shard_format as SF
+    rng = np.random.default_rng(21)
+    N, D = 3000, 384
+    emb = rng.standard_normal((N, D)).astype(np.float32)
+    pk = (rng.permutation(N) + 50_000).astype(np.int64)
+    agents = rng.integers(0, 3, N)
+    rows = [(int(pk[i]), f"agent-{agents[i]}", f"doc {i} w{i % 17}", SF.format_pgvector_text(emb[i]) if i % 5 == 0 else emb[i],
+             None, None) for i in range(N)]
+    sh = SF.open_shard(SF.export_table(rows, str(tmp_path / "s"), dim=D))
+    queries = planted_queries(rng, emb, 9)
+    eng = eng_factory(D)
+    post = SF.load_shard_into(eng, sh, chunk_rows=700)
+    assert post is not None and eng.n_rows == N
+    check(eng, emb, queries, 20, ids=pk)
+    t = sh.tenant_table["agent-1"]
+    check(eng, emb, queries, 20, tenant_of_row=np.asarray(sh.tenants), tenant=t, ids=pk)
+    b, e = 1000, 2200                                          # one rank's row range
+    eng2 = eng_factory(D)
+    SF.load_shard_into(eng2, sh, begin=b, end=e, chunk_rows=512)
+    check(eng2, emb[b:e], queries, 20, ids=pk[b:e])
+    sh.close()
