@@ -151,6 +151,14 @@ int rag_mmr_select_host(rag_handle_t h, const float* query_host /*dim*/, const f
 int rag_mmr_select_dev(rag_handle_t h, const float* q_dev, const int32_t* rows_dev, int n_queries, int pool, int top_k,
                        double lambda, int variant, int32_t* sel_out_dev, double* score_out_dev, void* stream);
 
+/* ---- semantic chunker chain: replaces the sentence loop of SemanticChunker.chunk
+ *      (rag/chunking.py:153-199): sentence i joins the running chunk when cos(running pairwise average, e_i) >= threshold
+ *      and the chunk stays <= max_chunk characters, else the chunk closes if it has >= min_chunk characters (otherwise
+ *      the sentence is absorbed). emb[n][dim] sentence embeddings, sent_len[n] = len(sentence);
+ *      group_out[n] = chunk number of each sentence. */
+int rag_chunk_chain_host(rag_handle_t h, const float* emb_host, const int32_t* sent_len_host, int n, int dim,
+                         double threshold, int max_chunk, int min_chunk, int32_t* group_out_host);
+
 /* ---- BM25 over CSR postings: replaces BM25Okapi(tokenized_corpus).get_scores(query) + the /max
  *      normalisation (rag/retrieval.py:324-347). Postings are term-major CSR, docs ascending per term.
  *      idf[V] is computed by the host exactly as rank-bm25 does (float64). */

@@ -65,6 +65,7 @@ _SIGS = {
     "rag_bm25_topk_host": ([_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
     "rag_bm25_scores_host": ([_P, _P, _P, C.c_int, _P], C.c_int),
     "rag_bm25_set_normalize": ([_P, C.c_int], C.c_int),
+    "rag_chunk_chain_host": ([_P, _P, _P, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _P], C.c_int),
     "rag_mmr_select_host": ([_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _P, _P], C.c_int),
     "rag_mmr_select_dev": ([_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _P, _P, _P], C.c_int),
     "rag_rrf_fuse_dev": ([_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
@@ -285,6 +286,16 @@ class RagEngine:
         if out.size:
             self._check(self.lib.rag_pairwise_cosine_host(self.h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1],
                                                           _ptr(out)), "rag_pairwise_cosine_host")
+        return out
+
+    def chunk_chain(self, embs, sent_len, threshold, max_chunk, min_chunk):
+        """SemanticChunker's sentence loop on the device: embs [n, dim] float32, sent_len [n] -> chunk number per sentence."""
+        embs = _np(embs, np.float32)
+        sent_len = _np(sent_len, np.int32)
+        n, dim = embs.shape
+        out = np.empty((n,), dtype=np.int32)
+        self._check(self.lib.rag_chunk_chain_host(self.h, _ptr(embs), _ptr(sent_len), n, dim, float(threshold), int(max_chunk),
+                                                  int(min_chunk), _ptr(out)), "rag_chunk_chain_host")
         return out
 
     MMR_MAX_CANDIDATES = 256

@@ -21,6 +21,8 @@ int rrf_fuse_dev(rag_ctx* h, const int64_t* lists_dev, int Q, int L, int len, in
                  int top_k, int64_t* keys_dev, double* scores_dev, int32_t* ranks_dev, hipStream_t st);
 void bm25_free(rag_ctx* h);
 int bm25_set_normalize(rag_ctx* h, int on);
+int chunk_chain_host(rag_ctx* h, const float* emb, const int32_t* sent_len, int n, int dim, double threshold, int max_chunk,
+                     int min_chunk, int32_t* group_out);
 int mmr_select_dev(rag_ctx* h, const float* queries_dev, const float* emb_dev, const int32_t* rows_dev, int Q, int n, int dim,
                    int top_k, double lam, int variant, int32_t* sel_dev, double* score_dev, hipStream_t st);
 int mmr_select_host(rag_ctx* h, const float* query, const float* emb, int n, int dim, int top_k, double lam, int variant,
@@ -452,6 +454,13 @@ int rag_mmr_select_dev(rag_handle_t h, const float* q_dev, const int32_t* rows_d
     HIP_TRY(h, hipSetDevice(h->device));
     return mmr_select_dev(h, q_dev, h->emb32, rows_dev, Q, pool, h->dim, top_k, lambda, variant, sel_dev, score_dev,
                           (hipStream_t)stream);
+}
+
+int rag_chunk_chain_host(rag_handle_t h, const float* emb, const int32_t* sent_len, int n, int dim, double threshold,
+                         int max_chunk, int min_chunk, int32_t* group_out) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return chunk_chain_host(h, emb, sent_len, n, dim, threshold, max_chunk, min_chunk, group_out);
 }
 
 }  // extern "C"
