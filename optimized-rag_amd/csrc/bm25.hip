@@ -17,7 +17,7 @@
 
 #define BM_RANGE 16384
 #define BM_THREADS 1024
-#define BM_SEG (BM_RANGE / BM_THREADS)      // 32 contiguous docs per thread
+#define BM_SEG (BM_RANGE / BM_THREADS)      // 16 contiguous docs per thread
 // accumulator i lives at LDS double i + i/32: a thread's 32 contiguous docs then start one bank-pair further than its
 // neighbour's, so the per-thread segment reads are conflict-free (unpadded: every lane on the same bank, 32-way)
 #define SC_IDX(i) ((i) + ((i) >> 5))
@@ -35,6 +35,8 @@ struct rag_bm25_index {
     uint64_t* ws_key = nullptr;        // per-range partial top-k workspace for the device entry point
     uint32_t* ws_row = nullptr;
     size_t ws_entries = 0;
+    uint64_t* ws_tau = nullptr;        // [ws_tau_q] first-stage threshold per query
+    int ws_tau_q = 0;
     double avgdl = 0, k1 = 1.5, b = 0.75;
     int normalize = 1;                 // 0: top-k scores stay raw (row-sharded search divides by the GLOBAL max after the merge)
 };
@@ -81,12 +83,13 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
                                                                  const int32_t* __restrict__ term_ptr, const int32_t* __restrict__ terms,
                                                                  int64_t n_docs, int64_t n_terms, int k, int mode,
                                                                  double* __restrict__ dense_out, uint64_t* __restrict__ part_key,
-                                                                 uint32_t* __restrict__ part_row) {
+                                                                 uint32_t* __restrict__ part_row, int range_begin,
+                                                                 const uint64_t* __restrict__ tau_key) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sc = reinterpret_cast<double*>(smem);                       // [BM_RANGE]
     int* hist = reinterpret_cast<int*>(smem + BM_SC_DOUBLES * 8);       // [256]
     int* wsum = hist + 256;                                             // [16] scratch
-    const int q = blockIdx.y, r = blockIdx.x, tid = threadIdx.x;
+    const int q = blockIdx.y, r = range_begin + blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int64_t base = (int64_t)r * BM_RANGE;
     const int lim = (int)min((int64_t)BM_RANGE, n_docs - base);
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
         return;
     }
     // ---- exact top-k of sc[0..lim): radix select of the k-th largest key, ties by lower doc ------------
-    const size_t po = ((size_t)q * gridDim.x + r) * k;
+    const size_t po = ((size_t)q * n_ranges + r) * k;
     if (lim <= k) {
         for (int i = tid; i < k; i += BM_THREADS) {
             part_key[po + i] = i < lim ? f64_orderable(sc[SC_IDX(i)]) : 0ull;
@@ -156,6 +159,42 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
     uint64_t keys[BM_SEG];           // this thread's 32 docs, read once (conflict-free thanks to the padding)
 #pragma unroll
     for (int j = 0; j < BM_SEG; ++j) keys[j] = (seg0 + j) < lim ? f64_orderable(sc[SC_IDX(seg0 + j)]) : 0ull;
+    // Thresholded ranges (second stage, see bm25_launch_topk): tau_key[q] is the k-th best key over the first-stage
+    // ranges, a lower bound of the global k-th. Only keys >= tau can reach the global top-k; a later range holds
+    // about k * 16384 / (docs of stage one) of them, so they are compacted in doc order (the merge sorts anyway) and the
+    // 8-pass radix select — 26 us per block, three quarters of this kernel's time when run for every range — is
+    // skipped. More than k survivors (possible, e.g. a tie plateau) falls through to the exact select below.
+    if (tau_key != nullptr) {
+        const uint64_t tk = tau_key[q];
+        int n_in = 0;
+#pragma unroll
+        for (int j = 0; j < BM_SEG; ++j) n_in += (seg0 + j) < lim && keys[j] >= tk;
+        int sc_in = n_in;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(sc_in, o);
+            if (lane >= o) sc_in += up;
+        }
+        if (lane == 63) hist[wv] = sc_in;
+        __syncthreads();
+        int off = sc_in - n_in, total_in = 0;
+        for (int u = 0; u < BM_THREADS / 64; ++u) {
+            if (u < wv) off += hist[u];
+            total_in += hist[u];
+        }
+        __syncthreads();                                   // hist is reused by the select below
+        if (total_in <= k) {
+#pragma unroll
+            for (int j = 0; j < BM_SEG; ++j)
+                if ((seg0 + j) < lim && keys[j] >= tk) {
+                    part_key[po + off] = keys[j];
+                    part_row[po + off] = (uint32_t)(base + seg0 + j);
+                    ++off;
+                }
+            for (int i = total_in + tid; i < k; i += BM_THREADS) { part_key[po + i] = 0ull; part_row[po + i] = 0xFFFFFFFFu; }
+            return;
+        }
+    }
     uint64_t prefix = 0ull;          // matched high bytes of the pivot
     int remaining = k;               // the pivot is the `remaining`-th largest among keys matching `prefix`
     for (int pass = 0; pass < 8; ++pass) {
@@ -266,6 +305,54 @@ __device__ __forceinline__ void bm_sort_pairs(uint64_t* k1, uint32_t* k2, int P,
     }
 }
 
+// k-th best key of the first-stage partial lists of a query (n_first ranges x k slots, 0 = empty) -> tau_key[q];
+// 0 (everything passes) when the first stage found fewer than k docs. One workgroup per query, bitonic sort in LDS.
+__global__ __launch_bounds__(256) void bm25_tau_kernel(const uint64_t* __restrict__ part_key, int n_ranges, int n_first, int k,
+                                                        uint64_t* __restrict__ tau_key) {
+    extern __shared__ uint64_t tk_s[];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int n = n_first * k;
+    int P = 1;
+    while (P < n) P <<= 1;
+    const uint64_t* pk = part_key + (size_t)q * n_ranges * k;          // the first-stage ranges are ranges 0..n_first-1
+    for (int i = tid; i < P; i += 256) tk_s[i] = i < n ? pk[i] : 0ull;
+    __syncthreads();
+    for (int kk = 2; kk <= P; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool desc = (i & kk) == 0;
+                    const uint64_t a = tk_s[i], b = tk_s[ixj];
+                    if (desc ? a < b : a > b) { tk_s[i] = b; tk_s[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    if (tid == 0) tau_key[q] = tk_s[k - 1];                             // 0 if fewer than k real keys
+}
+
+#define BM_FIRST_RANGES 4      // exact per-range top-k for these, thresholded compaction for the rest
+
+// all ranges -> per-range partial lists part_key/part_row [Q][n_ranges][k]; tau_dev: scratch [Q]
+static void bm25_launch_topk(const rag_bm25_index* ix, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k,
+                             uint64_t* part_key, uint32_t* part_row, uint64_t* tau_dev, hipStream_t st) {
+    const int nr = ix->n_ranges;
+    static const int first_cfg = [] { const char* e = getenv("RAG_BM25_FIRST_RANGES"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? v : BM_FIRST_RANGES; }();
+    const bool staged = nr > 2 * first_cfg && tau_dev != nullptr && !getenv("RAG_BM25_NO_STAGING");
+    const int first = staged ? first_cfg : nr;
+    hipLaunchKernelGGL(bm25_range_kernel, dim3(first, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc, ix->w, ix->idf,
+                       ix->range_off, nr, term_ptr_dev, terms_dev, ix->n_docs, ix->n_terms, k, 0, (double*)nullptr, part_key,
+                       part_row, 0, (const uint64_t*)nullptr);
+    if (!staged) return;
+    int P = 1;
+    while (P < first * k) P <<= 1;
+    hipLaunchKernelGGL(bm25_tau_kernel, dim3(Q), dim3(256), (size_t)P * sizeof(uint64_t), st, part_key, nr, first, k, tau_dev);
+    hipLaunchKernelGGL(bm25_range_kernel, dim3(nr - first, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc, ix->w,
+                       ix->idf, ix->range_off, nr, term_ptr_dev, terms_dev, ix->n_docs, ix->n_terms, k, 0, (double*)nullptr,
+                       part_key, part_row, first, (const uint64_t*)tau_dev);
+}
+
 __global__ __launch_bounds__(256) void bm25_merge_kernel(const uint64_t* __restrict__ part_key, const uint32_t* __restrict__ part_row,
                                                           int n_ranges, int k, const int64_t* __restrict__ idmap,
                                                           int64_t id_base, int64_t* __restrict__ ids_out,
@@ -315,7 +402,7 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(const uint64_t* __restr
 void bm25_free(rag_ctx* h) {
     if (!h->bm25) return;
     hipFree(h->bm25->indptr); hipFree(h->bm25->doc); hipFree(h->bm25->w); hipFree(h->bm25->idf); hipFree(h->bm25->range_off);
-    hipFree(h->bm25->ws_key); hipFree(h->bm25->ws_row);
+    hipFree(h->bm25->ws_key); hipFree(h->bm25->ws_row); hipFree(h->bm25->ws_tau);
     delete h->bm25;
     h->bm25 = nullptr;
 }
@@ -399,13 +486,19 @@ static int bm25_run(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, i
     } else {
         if (e == hipSuccess) e = hipMalloc(&dd, (size_t)Q * ix->n_docs * sizeof(double));
     }
+    uint64_t* taud = nullptr;
+    if (e == hipSuccess && mode == 0) e = hipMalloc(&taud, (size_t)Q * sizeof(uint64_t));
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(bm25_range_kernel, dim3(n_ranges, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc,
-                           ix->w, ix->idf, ix->range_off, ix->n_ranges, tp, tm, ix->n_docs, ix->n_terms, k, mode, dd, pk, pr);
-        if (mode == 0)
+        if (mode == 0) {
+            bm25_launch_topk(ix, tp, tm, Q, k, pk, pr, taud, st);
             hipLaunchKernelGGL(bm25_merge_kernel, dim3(Q), dim3(256), 0, st, pk, pr, n_ranges, k,
                                h->n_rows == ix->n_docs ? h->ids : (const int64_t*)nullptr,
                                h->n_rows == ix->n_docs ? h->id_base : (int64_t)0, idd, rwd, scd, mxd, ix->normalize);
+        } else {
+            hipLaunchKernelGGL(bm25_range_kernel, dim3(n_ranges, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc,
+                               ix->w, ix->idf, ix->range_off, ix->n_ranges, tp, tm, ix->n_docs, ix->n_terms, k, mode, dd, pk, pr,
+                               0, (const uint64_t*)nullptr);
+        }
         e = hipGetLastError();
     }
     if (mode == 0) {
@@ -418,6 +511,7 @@ static int bm25_run(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, i
     }
     hipError_t e2 = hipStreamSynchronize(st);
     hipFree(tp); hipFree(tm); hipFree(pk); hipFree(pr); hipFree(idd); hipFree(rwd); hipFree(scd); hipFree(mxd); hipFree(dd);
+    hipFree(taud);
     if (e != hipSuccess || e2 != hipSuccess) {
         h->err = std::string("bm25: ") + hipGetErrorString(e != hipSuccess ? e : e2);
         return RAG_ERR_HIP;
@@ -446,9 +540,14 @@ int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_
         HIP_TRY(h, hipMalloc(&ix->ws_row, need * sizeof(uint32_t)));
         ix->ws_entries = need;
     }
-    hipLaunchKernelGGL(bm25_range_kernel, dim3(ix->n_ranges, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc, ix->w,
-                       ix->idf, ix->range_off, ix->n_ranges, term_ptr_dev, terms_dev, ix->n_docs, ix->n_terms, k, 0,
-                       (double*)nullptr, ix->ws_key, ix->ws_row);
+    if (Q > ix->ws_tau_q) {
+        hipFree(ix->ws_tau);
+        ix->ws_tau = nullptr;
+        ix->ws_tau_q = 0;
+        HIP_TRY(h, hipMalloc(&ix->ws_tau, (size_t)Q * sizeof(uint64_t)));
+        ix->ws_tau_q = Q;
+    }
+    bm25_launch_topk(ix, term_ptr_dev, terms_dev, Q, k, ix->ws_key, ix->ws_row, ix->ws_tau, st);
     // doc ids follow the dense index's mapping when both indexes cover the same rows (hybrid fusion needs one id space)
     const bool aligned = h->n_rows == ix->n_docs;
     hipLaunchKernelGGL(bm25_merge_kernel, dim3(Q), dim3(256), 0, st, ix->ws_key, ix->ws_row, ix->n_ranges, k,

@@ -469,3 +469,36 @@ def test_mmr_device_selection_matches_oracle(eng, variant):
         # explicit-candidate host entry gives the same picks
         hs, hsc = eng.mmr_select(q[qi], np.asarray([emb[rows[qi, j]] for j in live]), k, lam, variant)
         assert hs.tolist() == pos
+
+
+@pytest.mark.parametrize("k", [20, 100])
+def test_bm25_staged_threshold_path_vs_oracle(eng, k):
+    """More than 8 doc ranges (> 131072 docs): the first 4 ranges get the exact per-range select, the others only compact
+    keys >= the k-th best of stage one. Results must stay bit-identical to the oracle — including a query whose matches
+    are fewer than k (threshold 0: every later range falls back to the exact select), an unknown token (all-zero scores:
+    the top-k is the first k docs) and a score plateau far longer than k that straddles many ranges."""
+    from optimized_rag_amd.bm25 import Bm25Postings
+    rng = np.random.default_rng(31 + k)
+    n_docs = 180_000                                             # 11 doc ranges of 16384
+    lens = rng.poisson(6, n_docs)
+    toks = (rng.zipf(1.3, int(lens.sum())) - 1) % 3000
+    ptr_d = np.concatenate([[0], np.cumsum(lens)])
+    corpus = [" ".join(f"t{t}" for t in toks[ptr_d[i]:ptr_d[i + 1]]) for i in range(n_docs)]
+    for i in range(5000, n_docs, 37):
+        corpus[i] = "plateau same words"                          # ~4700 identical docs across all ranges: ties >> k
+    corpus[170_000] = "rareword appears once"
+    post = Bm25Postings.from_corpus(corpus).load(eng)
+    obm = O.BM25Okapi([O.tokenize(c) for c in corpus])
+    queries = ["t0 t5 t17", "t1 t2 t2 t300", "rareword", "plateau words", "nosuchtoken", "t2999 t40 rareword"]
+    for _ in range(6):
+        i = int(rng.integers(0, n_docs))
+        queries.append(" ".join(rng.choice(corpus[i].split() or ["t1"], size=3)))
+    ptr, terms = post.encode_queries(queries)
+    ids, rows, scores, mx = eng.bm25_topk(ptr, terms, k)
+    for qi, q in enumerate(queries):
+        raw = obm.get_scores(O.tokenize(q))
+        m = raw.max() if raw.max() > 0 else 1.0
+        top = O.stable_topk_desc(raw, k)
+        np.testing.assert_array_equal(rows[qi], top.astype(np.int32), err_msg=q)
+        np.testing.assert_array_equal(scores[qi], raw[top] / m, err_msg=q)
+        assert mx[qi] == m
