@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000, help="total corpus rows (sharded over the ranks)")
     ap.add_argument("--queries", type=int, default=1024)
     ap.add_argument("--k", type=int, default=20)
-    ap.add_argument("--mode", default="dense", choices=["dense", "hybrid", "rerank"],
+    ap.add_argument("--mode", default="dense", choices=["dense", "hybrid", "rerank", "pipeline"],
                     help="dense = the headline metric (default); hybrid / rerank = BASELINE configs[2] / [3], single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-query-latency", action="store_true",

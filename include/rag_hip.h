@@ -199,6 +199,20 @@ int rag_ce_score_host(rag_handle_t h, const int32_t* input_ids_host, const int32
 int rag_ce_score_dev(rag_handle_t h, const int32_t* input_ids_dev, const int32_t* token_type_ids_dev,
                      const int32_t* lens_dev, int n_pairs, int seq_len, float* logits_out_dev, void* stream);
 
+/* ---- retrieve + rerank in one device-resident call (BASELINE.json configs[3]): the composition of
+ *      HybridRetriever.retrieve (rag/retrieval.py:122-212) and CrossEncoderReranker.rerank (rag/reranker.py:320-384:
+ *      pairs [query, passage], raw logits, sigmoid, sort desc, [:top_k]) with the passages' token ids resident in HBM.
+ *      rag_tokens_load_host: tokens[n_rows][L] passage WordPiece ids (no [CLS]/[SEP]) + lens[n_rows], row-aligned with the
+ *      index. rag_retrieve_rerank_dev: mode 0 = dense top-pool candidates, mode 1 = dense + BM25 + RRF(rrf_k) top-pool;
+ *      pairs are [CLS] query [SEP] passage [SEP] padded to L_pair (only the passage is truncated); outputs per query:
+ *      ids_out[k] doc ids (-1 padded), scores_out[k] = sigmoid(logit) as float64, logits_out[k] raw logits,
+ *      cand_out[pool] (may be NULL) the candidate list that was reranked. Needs the default id mapping (id_base + row). */
+int rag_tokens_load_host(rag_handle_t h, const int32_t* tokens_host, const int32_t* lens_host, int64_t n_rows, int L);
+int rag_retrieve_rerank_dev(rag_handle_t h, const float* q_emb_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev,
+                            const int32_t* q_tok_dev, const int32_t* q_len_dev, int Lq, int n_queries, int pool, int k,
+                            int rrf_k, int tenant, int mode, int cls_id, int sep_id, int L_pair, int64_t* ids_out_dev,
+                            double* scores_out_dev, float* logits_out_dev, int64_t* cand_out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

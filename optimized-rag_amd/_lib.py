@@ -74,6 +74,9 @@ _SIGS = {
     "rag_linear_fuse_topk_host": ([_P, _P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _P, _P], C.c_int),
     "rag_ce_load_host": ([_P, C.POINTER(CeConfig), C.POINTER(_P), C.c_int], C.c_int),
     "rag_ce_score_host": ([_P, _P, _P, _P, C.c_int, C.c_int, _P], C.c_int),
+    "rag_tokens_load_host": ([_P, _P, _P, C.c_int64, C.c_int], C.c_int),
+    "rag_retrieve_rerank_dev": ([_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_int, _P, _P, _P, _P, _P], C.c_int),
     "rag_ce_score_dev": ([_P, _P, _P, _P, C.c_int, C.c_int, _P, _P], C.c_int),
 }
 
@@ -436,6 +439,35 @@ class RagEngine:
         arrs = [_np(t, np.float32) for t in tensors]
         ptrs = (_P * len(arrs))(*[a.ctypes.data for a in arrs])
         self._check(self.lib.rag_ce_load_host(self.h, C.byref(c), ptrs, len(arrs)), "rag_ce_load_host")
+
+    def tokens_load(self, tokens, lens):
+        """Passage token store: tokens [N, L] int32 WordPiece ids without [CLS]/[SEP], lens [N]; row-aligned with the index."""
+        tokens = _np(tokens, np.int32)
+        lens = _np(lens, np.int32)
+        self._check(self.lib.rag_tokens_load_host(self.h, _ptr(tokens), _ptr(lens), tokens.shape[0], tokens.shape[1]),
+                    "rag_tokens_load_host")
+
+    def retrieve_rerank_dev(self, q_emb, q_tok, q_len, pool, k, term_ptr=None, terms=None, rrf_k=60, tenant=-1, L_pair=256,
+                            cls_id=101, sep_id=102, stream=None):
+        """Dense (term_ptr None) or hybrid candidates -> cross-encoder -> top-k, all on the device (CUDA tensors).
+        Returns (ids [Q,k] int64, scores [Q,k] float64 sigmoid, logits [Q,k] float32, candidates [Q,pool] int64)."""
+        import torch
+        Q, dev = q_emb.shape[0], q_emb.device
+        key = ("rr", Q, pool, k)
+        if getattr(self, "_rr_key", None) != key:
+            self._rr = (torch.empty((Q, k), dtype=torch.int64, device=dev), torch.empty((Q, k), dtype=torch.float64, device=dev),
+                        torch.empty((Q, k), dtype=torch.float32, device=dev), torch.empty((Q, pool), dtype=torch.int64, device=dev))
+            self._rr_key = key
+        ids, sc, lg, cand = self._rr
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        mode = 0 if term_ptr is None else 1
+        self._check(self.lib.rag_retrieve_rerank_dev(
+            self.h, C.c_void_p(q_emb.data_ptr()), C.c_void_p(term_ptr.data_ptr() if mode else 0),
+            C.c_void_p(terms.data_ptr() if mode else 0), C.c_void_p(q_tok.data_ptr()), C.c_void_p(q_len.data_ptr()),
+            int(q_tok.shape[1]), Q, int(pool), int(k), int(rrf_k), int(tenant), mode, int(cls_id), int(sep_id), int(L_pair),
+            C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr()), C.c_void_p(lg.data_ptr()), C.c_void_p(cand.data_ptr()), st),
+            "rag_retrieve_rerank_dev")
+        return ids, sc, lg, cand
 
     def ce_score_dev(self, input_ids, token_type_ids, lens, logits_out, stream=None):
         """int32 CUDA tensors [P, L], [P, L], [P] -> float32 logits_out [P]; asynchronous on `stream`."""

@@ -31,6 +31,12 @@ int ce_load_host(rag_ctx* h, const rag_ce_config* cfg, const float* const* tenso
 int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L, float* out,
              hipStream_t st, bool host_ptrs);
 void ce_free(rag_ctx* h);
+void pipeline_free(rag_ctx* h);
+int tokens_load_host(rag_ctx* h, const int32_t* tokens, const int32_t* lens, int64_t n_rows, int L);
+int retrieve_rerank_dev(rag_ctx* h, const float* q_emb_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev,
+                        const int32_t* q_tok_dev, const int32_t* q_len_dev, int Lq, int Q, int pool, int k, int rrf_k, int tenant,
+                        int mode, int cls_id, int sep_id, int L_pair, int64_t* ids_out, double* scores_out, float* logits_out,
+                        int64_t* cand_out, hipStream_t st);
 
 static thread_local std::string g_null_err = "null handle";
 
@@ -73,6 +79,7 @@ int rag_destroy(rag_handle_t h) {
     dense_free(h);
     bm25_free(h);
     ce_free(h);
+    pipeline_free(h);
     hipFree(h->q32); hipFree(h->q16); hipFree(h->cand); hipFree(h->cnt); hipFree(h->tau); hipFree(h->bound);
     hipFree(h->n_sorted); hipFree(h->exact); hipFree(h->flag); hipFree(h->stats); hipFree(h->out_ids);
     hipFree(h->out_rows); hipFree(h->out_scores);
@@ -461,6 +468,23 @@ int rag_chunk_chain_host(rag_handle_t h, const float* emb, const int32_t* sent_l
     if (!h) return RAG_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     return chunk_chain_host(h, emb, sent_len, n, dim, threshold, max_chunk, min_chunk, group_out);
+}
+
+int rag_tokens_load_host(rag_handle_t h, const int32_t* tokens, const int32_t* lens, int64_t n_rows, int L) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return tokens_load_host(h, tokens, lens, n_rows, L);
+}
+
+int rag_retrieve_rerank_dev(rag_handle_t h, const float* q_emb_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev,
+                            const int32_t* q_tok_dev, const int32_t* q_len_dev, int Lq, int Q, int pool, int k, int rrf_k,
+                            int tenant, int mode, int cls_id, int sep_id, int L_pair, int64_t* ids_out_dev,
+                            double* scores_out_dev, float* logits_out_dev, int64_t* cand_out_dev, void* stream) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return retrieve_rerank_dev(h, q_emb_dev, term_ptr_dev, terms_dev, q_tok_dev, q_len_dev, Lq, Q, pool, k, rrf_k, tenant, mode,
+                               cls_id, sep_id, L_pair, ids_out_dev, scores_out_dev, logits_out_dev, cand_out_dev,
+                               (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -71,6 +71,13 @@ struct rag_ctx {
     double last_eps = 0;
 
     rag_bm25_index* bm25 = nullptr;
+    // passage token store (pipeline.hip): [tok_rows][tok_L] int32 + lengths, row-aligned with the index
+    int32_t* tok = nullptr;
+    int32_t* tok_len = nullptr;
+    int64_t tok_rows = 0;
+    int tok_L = 0;
+    void* pipe_ws = nullptr;
+    size_t pipe_ws_bytes = 0;
     rag_ce_model* ce = nullptr;
 };
 

@@ -1,0 +1,154 @@
+// Retrieve + rerank as ONE device-resident call (BASELINE.json configs[3]: "hybrid top-100 -> ms-marco-MiniLM-L-6
+// cross-encoder rerank -> top-20"): the composition the reference performs across
+//   HybridRetriever.retrieve            /root/reference/rag/retrieval.py:122-212
+//   CrossEncoderReranker.rerank         /root/reference/rag/reranker.py:320-384   (pairs [query, content] :346-352,
+//                                        raw logits :355, sigmoid :359, sort desc by sigmoid, [:top_k] :372-376)
+// with the passages' token ids resident in HBM next to their embeddings ("token store"), so
+// between the query arriving and the top-k leaving nothing crosses PCIe.
+//   1. candidates: dense top-pool (mode 0) or dense + BM25 + RRF -> top-pool (mode 1)
+//   2. ce_build_pairs_kernel: [CLS] query [SEP] passage [SEP], token_type 0 | 1, passage truncated to fit L_pair
+//   3. ce_score (cross_encoder.hip)
+//   4. rerank_topk_kernel: sigmoid in float64, stable order (score desc, candidate order on ties), top-k
+#include "common.h"
+
+int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev, double* scores_dev,
+                 hipStream_t st);
+int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int64_t* ids_dev,
+                  int32_t* rows_dev, double* scores_dev, double* raw_max_dev, hipStream_t st);
+int rrf_fuse_dev(rag_ctx* h, const int64_t* lists_dev, int Q, int L, int len, int64_t list_stride, int64_t query_stride, int rrf_k,
+                 int top_k, int64_t* keys_dev, double* scores_dev, int32_t* ranks_dev, hipStream_t st);
+int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L, float* out, hipStream_t st,
+             bool host_ptrs);
+
+void pipeline_free(rag_ctx* h) {
+    hipFree(h->tok); hipFree(h->tok_len); hipFree(h->pipe_ws);
+    h->tok = nullptr; h->tok_len = nullptr; h->pipe_ws = nullptr;
+    h->tok_rows = 0; h->tok_L = 0; h->pipe_ws_bytes = 0;
+}
+
+int tokens_load_host(rag_ctx* h, const int32_t* tokens, const int32_t* lens, int64_t n_rows, int L) {
+    ARG_CHECK(h, tokens && lens && n_rows > 0 && L > 0 && L <= 512, "tokens_load: bad arguments (passage length <= 512)");
+    hipFree(h->tok); hipFree(h->tok_len);
+    h->tok = nullptr; h->tok_len = nullptr; h->tok_rows = 0;
+    HIP_TRY(h, hipMalloc(&h->tok, (size_t)n_rows * L * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc(&h->tok_len, (size_t)n_rows * sizeof(int32_t)));
+    HIP_TRY(h, hipMemcpy(h->tok, tokens, (size_t)n_rows * L * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->tok_len, lens, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->tok_rows = n_rows;
+    h->tok_L = L;
+    return RAG_OK;
+}
+
+// one wave per pair: cand[q][j] is a doc id (id_base + row) or -1
+__global__ __launch_bounds__(256) void ce_build_pairs_kernel(const int32_t* __restrict__ q_tok, const int32_t* __restrict__ q_len,
+                                                              int Lq, const int64_t* __restrict__ cand, int64_t id_base,
+                                                              const int32_t* __restrict__ tok, const int32_t* __restrict__ tok_len,
+                                                              int Ld, int64_t n_rows, int n_pairs, int pool, int L, int cls_id,
+                                                              int sep_id, int32_t* __restrict__ ids, int32_t* __restrict__ tt,
+                                                              int32_t* __restrict__ lens) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= n_pairs) return;
+    const int q = p / pool;
+    const int64_t row = cand[p] < 0 ? -1 : cand[p] - id_base;
+    const int ql = max(0, min(q_len[q], min(Lq, L - 3)));
+    int dl = 0;
+    if (row >= 0 && row < n_rows) dl = max(0, min(min(tok_len[row], Ld), L - 3 - ql));   // only the passage is truncated
+    const int total = ql + dl + 3;
+    const int32_t* qt = q_tok + (size_t)q * Lq;
+    const int32_t* dt = tok + (size_t)(row < 0 ? 0 : row) * Ld;
+    for (int t = lane; t < L; t += 64) {
+        int v = 0, ty = 0;
+        if (t == 0) v = cls_id;
+        else if (t <= ql) v = qt[t - 1];
+        else if (t == ql + 1) v = sep_id;
+        else if (t < ql + 2 + dl) { v = dt[t - ql - 2]; ty = 1; }
+        else if (t == ql + 2 + dl) { v = sep_id; ty = 1; }
+        ids[(size_t)p * L + t] = v;
+        tt[(size_t)p * L + t] = ty;
+    }
+    if (lane == 0) lens[p] = total;
+}
+
+// one workgroup per query, pool <= 256: stable rank by (sigmoid desc, candidate position asc)
+__global__ __launch_bounds__(256) void rerank_topk_kernel(const float* __restrict__ logits, const int64_t* __restrict__ cand, int pool,
+                                                           int k, int64_t* __restrict__ ids_out, double* __restrict__ score_out,
+                                                           float* __restrict__ logit_out) {
+    __shared__ double s[256];
+    __shared__ int ok[256];
+    const int q = blockIdx.x, j = threadIdx.x;
+    double mine = -1.0;
+    int valid = 0;
+    if (j < pool) {
+        valid = cand[(size_t)q * pool + j] >= 0;
+        if (valid) mine = 1.0 / (1.0 + exp(-(double)logits[(size_t)q * pool + j]));          // reranker.py:359
+    }
+    s[j] = mine;
+    ok[j] = valid;
+    __syncthreads();
+    for (int i = j; i < k; i += 256) { ids_out[(size_t)q * k + i] = -1; score_out[(size_t)q * k + i] = 0.0; logit_out[(size_t)q * k + i] = 0.f; }
+    __syncthreads();
+    if (j < pool && valid) {
+        int rank = 0;
+        for (int i = 0; i < pool; ++i) rank += ok[i] && (s[i] > mine || (s[i] == mine && i < j));
+        if (rank < k) {
+            ids_out[(size_t)q * k + rank] = cand[(size_t)q * pool + j];
+            score_out[(size_t)q * k + rank] = mine;
+            logit_out[(size_t)q * k + rank] = logits[(size_t)q * pool + j];
+        }
+    }
+}
+
+int retrieve_rerank_dev(rag_ctx* h, const float* q_emb_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev,
+                        const int32_t* q_tok_dev, const int32_t* q_len_dev, int Lq, int Q, int pool, int k, int rrf_k, int tenant,
+                        int mode, int cls_id, int sep_id, int L_pair, int64_t* ids_out, double* scores_out, float* logits_out,
+                        int64_t* cand_out, hipStream_t st) {
+    ARG_CHECK(h, h->ce != nullptr, "retrieve_rerank: no cross-encoder loaded");
+    ARG_CHECK(h, h->tok != nullptr && h->tok_rows == h->n_rows, "retrieve_rerank: token store missing or not row-aligned with the index");
+    ARG_CHECK(h, h->ids == nullptr, "retrieve_rerank: needs the default id mapping (id = id_base + row)");
+    ARG_CHECK(h, Q > 0 && pool > 0 && pool <= RAG_MAX_K && k > 0 && k <= pool, "retrieve_rerank: 0 < k <= pool <= 256");
+    ARG_CHECK(h, L_pair >= 8 && L_pair <= 512 && Lq > 0 && q_emb_dev && q_tok_dev && q_len_dev && ids_out && scores_out && logits_out,
+              "retrieve_rerank: bad arguments");
+    ARG_CHECK(h, mode == 0 || (mode == 1 && term_ptr_dev && h->bm25 != nullptr), "retrieve_rerank: mode 1 needs BM25 postings and query terms");
+    const size_t P = (size_t)Q * pool;
+    // workspace: lists [2][Q][pool] i64 | scores [Q][pool] f64 | cand [Q][pool] i64 | rrf [Q][pool] f64 | ranks [Q][pool][2] i32
+    //            | pair ids [P][L] | pair tt [P][L] | lens [P] | logits [P]
+    const size_t need = P * (16 + 8 + 8 + 8 + 8) + P * L_pair * 8 + P * 8 + 256;
+    if (need > h->pipe_ws_bytes) {
+        hipFree(h->pipe_ws);
+        h->pipe_ws = nullptr;
+        h->pipe_ws_bytes = 0;
+        HIP_TRY(h, hipMalloc(&h->pipe_ws, need));
+        h->pipe_ws_bytes = need;
+    }
+    char* w = (char*)h->pipe_ws;
+    int64_t* lists = (int64_t*)w;              w += P * 16;
+    double* sc = (double*)w;                   w += P * 8;
+    int64_t* cand = (int64_t*)w;               w += P * 8;
+    double* rrf = (double*)w;                  w += P * 8;
+    int32_t* ranks = (int32_t*)w;              w += P * 8;
+    int32_t* pid = (int32_t*)w;                w += P * L_pair * 4;
+    int32_t* ptt = (int32_t*)w;                w += P * L_pair * 4;
+    int32_t* plen = (int32_t*)w;               w += P * 4;
+    float* logit = (float*)w;
+    int rc;
+    if (mode == 0) {
+        rc = dense_search(h, q_emb_dev, Q, pool, tenant, cand, nullptr, sc, st);
+        if (rc) return rc;
+    } else {
+        rc = dense_search(h, q_emb_dev, Q, pool, tenant, lists, nullptr, sc, st);
+        if (rc) return rc;
+        rc = bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, lists + P, nullptr, sc, nullptr, st);
+        if (rc) return rc;
+        rc = rrf_fuse_dev(h, lists, Q, 2, pool, (int64_t)P, pool, rrf_k, pool, cand, rrf, ranks, st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(ce_build_pairs_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, q_tok_dev, q_len_dev, Lq, cand, h->id_base,
+                       h->tok, h->tok_len, h->tok_L, h->tok_rows, (int)P, pool, L_pair, cls_id, sep_id, pid, ptt, plen);
+    HIP_TRY(h, hipGetLastError());
+    rc = ce_score(h, pid, ptt, plen, (int)P, L_pair, logit, st, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rerank_topk_kernel, dim3(Q), dim3(256), 0, st, logit, cand, pool, k, ids_out, scores_out, logits_out);
+    HIP_TRY(h, hipGetLastError());
+    if (cand_out) HIP_TRY(h, hipMemcpyAsync(cand_out, cand, P * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    return RAG_OK;
+}

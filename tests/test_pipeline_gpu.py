@@ -1,0 +1,92 @@
+"""GPU parity of the one-call retrieve + rerank pipeline (BASELINE.json configs[3]) against the oracle composition:
+oracle dense top-pool (or dense + BM25 + RRF), numpy pair assembly, float64 BERT oracle, sigmoid, stable sort.
+Candidate lists are bit-exact; scores within 1e-3; final order identical wherever the oracle's scores are not
+closer than the score tolerance."""
+import numpy as np
+import pytest
+
+from oracle import bert_oracle as B
+from oracle import rag_oracle as O
+
+pytestmark = pytest.mark.gpu
+SCORE_TOL = 1e-3
+CLS, SEP = 101, 102
+
+
+def build_pairs(q_tok, q_len, cand, tok, tok_len, L):
+    Q, pool = cand.shape
+    ids = np.zeros((Q * pool, L), dtype=np.int64)
+    tt = np.zeros((Q * pool, L), dtype=np.int64)
+    lens = np.zeros(Q * pool, dtype=np.int64)
+    for q in range(Q):
+        ql = int(min(q_len[q], q_tok.shape[1], L - 3))
+        for j in range(pool):
+            r = int(cand[q, j])
+            dl = 0 if r < 0 else int(min(tok_len[r], tok.shape[1], L - 3 - ql))
+            row = [CLS] + list(q_tok[q, :ql]) + [SEP] + ([] if r < 0 else list(tok[r, :dl])) + [SEP]
+            p = q * pool + j
+            ids[p, :len(row)] = row
+            tt[p, ql + 2:len(row)] = 1
+            lens[p] = len(row)
+    return ids, tt, lens
+
+
+@pytest.mark.parametrize("hybrid", [False, True])
+def test_retrieve_rerank_matches_oracle_composition(hybrid):
+    import torch
+    from optimized_rag_amd import RagEngine
+    from optimized_rag_amd.bm25 import Bm25Postings
+    from optimized_rag_amd.cross_encoder import flatten_state_dict
+    rng = np.random.default_rng(123 + hybrid)
+    N, D, Q, pool, k, Ld, Lq, L = 300, 1536, 3, 6, 4, 20, 8, 32
+    cfg = dict(vocab_size=2000, hidden=384, layers=2, heads=12, ffn=1536, max_pos=64, type_vocab=2, eps=1e-12)
+    w = B.seeded_weights(cfg, 17)
+    emb = rng.standard_normal((N, D)).astype(np.float32)
+    q_emb = (emb[rng.integers(0, N, Q)] + 0.5 * rng.standard_normal((Q, D))).astype(np.float32)
+    tok = rng.integers(200, cfg["vocab_size"], (N, Ld)).astype(np.int32)
+    tok_len = rng.integers(3, Ld + 1, N).astype(np.int32)
+    tok_len[:5] = Ld                                                   # some passages need truncation (ql + dl + 3 > L)
+    q_tok = rng.integers(200, cfg["vocab_size"], (Q, Lq)).astype(np.int32)
+    q_len = np.array([Lq, 3, 5], dtype=np.int32)
+    corpus = [" ".join(f"t{t}" for t in tok[i, :tok_len[i]] % 40) for i in range(N)]
+    queries = [" ".join(f"t{t}" for t in q_tok[i, :q_len[i]] % 40) for i in range(Q)]
+    eng = RagEngine(dim=D, device=0)
+    try:
+        eng.index_load(emb, id_base=1000)
+        eng.tokens_load(tok, tok_len)
+        eng.ce_load(cfg, flatten_state_dict(w, cfg["layers"]))
+        post = Bm25Postings.from_corpus(corpus).load(eng)
+        ptr, terms = post.encode_queries(queries)
+        args = dict(term_ptr=torch.from_numpy(ptr).cuda(), terms=torch.from_numpy(terms).cuda()) if hybrid else {}
+        ids, sc, lg, cand = eng.retrieve_rerank_dev(torch.from_numpy(q_emb).cuda(), torch.from_numpy(q_tok).cuda(),
+                                                    torch.from_numpy(q_len).cuda(), pool, k, L_pair=L, cls_id=CLS, sep_id=SEP, **args)
+        torch.cuda.synchronize()
+        ids, sc, lg, cand = ids.cpu().numpy(), sc.cpu().numpy(), lg.cpu().numpy(), cand.cpu().numpy()
+    finally:
+        eng.close()
+    # ---- oracle composition ------------------------------------------------------------------------------------
+    d_rows, _ = O.dense_topk(emb, q_emb, pool)
+    if hybrid:
+        obm = O.BM25Okapi([O.tokenize(c) for c in corpus])
+        ocand = np.full((Q, pool), -1, dtype=np.int64)
+        for qi in range(Q):
+            b_rows = O.stable_topk_desc(obm.get_scores(O.tokenize(queries[qi])), pool)
+            keys, _, _ = O.rrf_fuse([[int(r) for r in d_rows[qi]], [int(r) for r in b_rows]], k=60, top_k=pool)
+            ocand[qi, :len(keys)] = keys
+    else:
+        ocand = d_rows.astype(np.int64)
+    np.testing.assert_array_equal(cand, np.where(ocand >= 0, ocand + 1000, -1))          # candidates: bit-exact doc ids
+    pid, ptt, plen = build_pairs(q_tok, q_len, ocand, tok, tok_len, L)
+    ologit = B.forward_logits(w, cfg, pid, ptt, plen).reshape(Q, pool)
+    oscore = np.array([[O.sigmoid(float(x)) for x in row] for row in ologit])
+    for qi in range(Q):
+        order = sorted(range(pool), key=lambda j: -oscore[qi, j])                         # Python's stable sort, as the reference
+        want = [int(ocand[qi, j]) + 1000 for j in order[:k]]
+        wsc = [oscore[qi, j] for j in order[:k]]
+        np.testing.assert_allclose(sc[qi], wsc, atol=SCORE_TOL)
+        np.testing.assert_allclose(lg[qi], [ologit[qi, j] for j in order[:k]], atol=4 * SCORE_TOL)
+        gaps = np.abs(np.diff([oscore[qi, j] for j in order[:k + 1]]))
+        if gaps.min() > 2 * SCORE_TOL:                                                    # unambiguous order -> identical ids
+            assert ids[qi].tolist() == want
+        else:
+            assert sorted(ids[qi].tolist()) == sorted(want) or set(ids[qi].tolist()) <= {int(c) + 1000 for c in ocand[qi]}
