@@ -45,6 +45,9 @@ struct rag_ce_model {
     float *x32 = nullptr, *y32 = nullptr;
     half_t *x16 = nullptr, *q16 = nullptr, *kf16 = nullptr, *vf16 = nullptr, *ctx16 = nullptr, *h16 = nullptr;
     int32_t *ids = nullptr, *tt = nullptr, *lens = nullptr;
+    // packed (variable-length) row layout of the current chunk: pair p owns rows [pair_off[p], pair_off[p+1]) where
+    // pair_off[p+1] - pair_off[p] = len rounded up to 32; row_pair[m] = owning pair (-1 past the end); m_packed[0] = rows
+    int32_t *pair_off = nullptr, *row_pair = nullptr, *m_packed = nullptr;
     float* logits = nullptr;
 };
 
@@ -103,9 +106,11 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
                                                        size_t x_plane, int N, int K, const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ out32,
                                                        half_t* __restrict__ out16, size_t out_plane, half_t* __restrict__ kf16,
-                                                       half_t* __restrict__ vf16, size_t kv_plane, int L, int hidden, int heads,
-                                                       int64_t m_valid) {
+                                                       half_t* __restrict__ vf16, size_t kv_plane, int hidden, int heads,
+                                                       const int32_t* __restrict__ m_packed, const int32_t* __restrict__ row_pair,
+                                                       const int32_t* __restrict__ pair_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.y * CE_BN >= m_packed[0]) return;       // the grid covers the padded worst case; packed rows end earlier
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
@@ -239,12 +244,13 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int hl = it >> 2, tl = it & 3;               // head, 16-token tile inside the wave's 64 tokens
-                const int64_t m = mb + tl * 16;
-                if (m >= m_valid) continue;                        // padded token rows have no (pair, token) slot
-                const int pair = (int)(m / L), t = (int)(m % L) >> 4;
+                const int m = mb + tl * 16;
+                const int pair = row_pair[m];                       // 16-token tiles never straddle pairs (offsets are multiples of 32)
+                if (pair < 0) continue;                            // rows past the packed end have no (pair, token) slot
+                const int po = pair_off[pair], Lp = pair_off[pair + 1] - po, t = (m - po) >> 4;
                 const half8 hi = *reinterpret_cast<const half8*>(wl + (tl * 16 + fr) * 144 + (hl * 4 + fq) * 16);
                 const half8 lo = *reinterpret_cast<const half8*>(wl + CE_EPI_PLANE + (tl * 16 + fr) * 144 + (hl * 4 + fq) * 16);
-                half_t* o = kf16 + ((((size_t)pair * heads + head0 + hl) * (L >> 4) + t) * 64 + lane) * 8;
+                half_t* o = kf16 + ((size_t)po * heads + (size_t)(head0 + hl) * Lp) * 32 + ((size_t)t * 64 + lane) * 8;
                 *reinterpret_cast<half8*>(o) = hi;
                 *reinterpret_cast<half8*>(o + kv_plane) = lo;
             }
@@ -274,15 +280,16 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int hl = it >> 2, kl = (it >> 1) & 1, dh = it & 1;    // head, 32-key block, d half
-            const int64_t m = mb + kl * 32;
-            if (m >= m_valid) continue;
-            const int pair = (int)(m / L), kb = (int)(m % L) >> 5;
+            const int m = mb + kl * 32;
+            const int pair = row_pair[m];
+            if (pair < 0) continue;
+            const int po = pair_off[pair], Lp = pair_off[pair + 1] - po, kb = (m - po) >> 5;
             const char* rowp = wl + (hl * 32 + dh * 16 + fr) * 144 + (kl * 32 + fq * 4) * 2;
             const half4 h0 = *reinterpret_cast<const half4*>(rowp), h1 = *reinterpret_cast<const half4*>(rowp + 32);
             const half4 l0 = *reinterpret_cast<const half4*>(rowp + CE_EPI_PLANE), l1 = *reinterpret_cast<const half4*>(rowp + CE_EPI_PLANE + 32);
             const half8 hi = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
             const half8 lo = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-            half_t* o = vf16 + (((((size_t)pair * heads + head0 + hl) * (L >> 5) + kb) * 2 + dh) * 64 + lane) * 8;
+            half_t* o = vf16 + ((size_t)po * heads + (size_t)(head0 + hl) * Lp) * 32 + (((size_t)kb * 2 + dh) * 64 + lane) * 8;
             *reinterpret_cast<half8*>(o) = hi;
             *reinterpret_cast<half8*>(o + kv_plane) = lo;
         }
@@ -317,35 +324,74 @@ __device__ __forceinline__ void wave_layernorm(float (&v)[PER], const float* __r
     }
 }
 
+// ---- packing: pair p owns len_p rounded up to 32 rows; offsets by one block-wide scan, then the row -> pair map
+__global__ __launch_bounds__(1024) void ce_pack_scan_kernel(const int32_t* __restrict__ lens, int P, int L, int32_t* __restrict__ pair_off,
+                                                             int32_t* __restrict__ m_packed) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (P + 1023) / 1024;
+    const int b = tid * per, e = min(P, b + per);
+    int s = 0;
+    for (int p = b; p < e; ++p) s += (max(1, min(lens[p], L)) + 31) & ~31;
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int off = part[tid] - s;
+    for (int p = b; p < e; ++p) {
+        pair_off[p] = off;
+        off += (max(1, min(lens[p], L)) + 31) & ~31;
+    }
+    if (tid == 1023) { pair_off[P] = part[1023]; m_packed[0] = part[1023]; }
+}
+
+__global__ void ce_pack_rows_kernel(const int32_t* __restrict__ pair_off, int P, int L, int64_t rows_total,
+                                    int32_t* __restrict__ row_pair) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows_total && i >= pair_off[P]) row_pair[i] = -1;             // tail up to the allocated rows
+    if (i >= (int64_t)P * L) return;
+    const int p = (int)(i / L), t = (int)(i % L);
+    if (t < pair_off[p + 1] - pair_off[p]) row_pair[pair_off[p] + t] = p;
+}
+
 template <int PER>
 __global__ __launch_bounds__(256) void ce_embed_ln_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ tt,
                                                            const float* __restrict__ word, const float* __restrict__ pos,
                                                            const float* __restrict__ type, const float* __restrict__ g,
-                                                           const float* __restrict__ b, int64_t M, int L, int hidden, int vocab,
-                                                           float eps, float* __restrict__ x32, half_t* __restrict__ x16, size_t plane) {
+                                                           const float* __restrict__ b, const int32_t* __restrict__ m_packed,
+                                                           const int32_t* __restrict__ row_pair, const int32_t* __restrict__ pair_off,
+                                                           int L, int hidden, int vocab, float eps, float* __restrict__ x32,
+                                                           half_t* __restrict__ x16, size_t plane) {
     const int lane = threadIdx.x & 63;
-    const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tok >= M) return;
-    int id = ids[tok];
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m_packed[0]) return;
+    const int pr = row_pair[row];
+    const int p = (int)row - pair_off[pr];                    // position inside the pair (< L: the rounded length never exceeds L)
+    const size_t src = (size_t)pr * L + p;
+    int id = ids[src];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-    const int ty = tt[tok] != 0;
-    const int p = (int)(tok % L);
+    const int ty = tt[src] != 0;
     float v[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int c = lane + i * 64;
         v[i] = word[(size_t)id * hidden + c] + type[(size_t)ty * hidden + c] + pos[(size_t)p * hidden + c];
     }
-    wave_layernorm<PER>(v, g, b, hidden, eps, lane, x32 + tok * hidden, x16 + tok * hidden, plane);
+    wave_layernorm<PER>(v, g, b, hidden, eps, lane, x32 + row * hidden, x16 + row * hidden, plane);
 }
 
 template <int PER>
 __global__ __launch_bounds__(256) void ce_layernorm_kernel(const float* __restrict__ y32, const float* __restrict__ g,
-                                                            const float* __restrict__ b, int64_t M, int hidden, float eps,
-                                                            float* __restrict__ x32, half_t* __restrict__ x16, size_t plane) {
+                                                            const float* __restrict__ b, const int32_t* __restrict__ m_packed,
+                                                            int hidden, float eps, float* __restrict__ x32,
+                                                            half_t* __restrict__ x16, size_t plane) {
     const int lane = threadIdx.x & 63;
     const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tok >= M) return;
+    if (tok >= m_packed[0]) return;
     float v[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) v[i] = y32[tok * hidden + lane + i * 64];
@@ -375,7 +421,8 @@ __device__ __forceinline__ void ce_dma_at(const half_t* __restrict__ g, char* ld
 template <int QB>
 __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __restrict__ q16, size_t q_plane,
                                                              const half_t* __restrict__ kf16, const half_t* __restrict__ vf16,
-                                                             size_t kv_plane, const int32_t* __restrict__ lens, int L, int hidden,
+                                                             size_t kv_plane, const int32_t* __restrict__ lens,
+                                                             const int32_t* __restrict__ pair_off, int L, int hidden,
                                                              int heads, half_t* __restrict__ ctx16, size_t ctx_plane) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -384,14 +431,15 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
     const int len = max(1, min(lens[pair], L));
     const int nkb = (len + 31) >> 5;                                  // 32-key blocks that hold at least one real key
     const int fr = lane & 15, fq = lane >> 4;
+    const int po = pair_off[pair], Lp = pair_off[pair + 1] - po;     // this pair's packed rows: len rounded up to 32
     const size_t plane_b = (size_t)L * 64;                            // bytes of one K (or V) plane of this (pair, head)
     char* const k_hi = smem;
     char* const k_lo = smem + plane_b;
     char* const v_hi = smem + 2 * plane_b;
     char* const v_lo = smem + 3 * plane_b;
     {
-        const half_t* kg = kf16 + ((size_t)pair * heads + head) * L * 32 + lane * 8;
-        const half_t* vg = vf16 + ((size_t)pair * heads + head) * L * 32 + lane * 8;
+        const half_t* kg = kf16 + ((size_t)po * heads + (size_t)head * Lp) * 32 + lane * 8;
+        const half_t* vg = vf16 + ((size_t)po * heads + (size_t)head * Lp) * 32 + lane * 8;
         for (int c = wv; c < 2 * nkb; c += nwaves) {                  // 1 KiB fragment tiles: 2 per key block and plane
             ce_dma_at(kg + (size_t)c * 512, k_hi + c * 1024);
             ce_dma_at(kg + kv_plane + (size_t)c * 512, k_lo + c * 1024);
@@ -399,8 +447,9 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
             ce_dma_at(vg + kv_plane + (size_t)c * 512, v_lo + c * 1024);
         }
     }
-    const size_t row0 = (size_t)pair * L;
+    const size_t row0 = (size_t)po;
     const int qb0 = wv * QB;
+    const bool has_rows = qb0 * 16 < Lp;                              // waves past the pair's rows only helped with the DMA
     // B operand = Q rows (query fr of block b, dims 8*fq..+8)
     half8 qh[QB], ql[QB];
 #pragma unroll
@@ -421,6 +470,7 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
     const float cs = (float)(0.17677669529663687 * 1.4426950408889634);    // 32^-0.5 * log2(e)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (!has_rows) return;
     for (int kb = 0; kb < nkb; ++kb) {
         const int fo = kb * 2048 + lane * 16;
         const half8 k0h = *reinterpret_cast<const half8*>(k_hi + fo), k1h = *reinterpret_cast<const half8*>(k_hi + fo + 1024);
@@ -492,12 +542,12 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
 
 __global__ __launch_bounds__(256) void ce_pool_classify_kernel(const float* __restrict__ x32, const float* __restrict__ wp,
                                                                 const float* __restrict__ bp, const float* __restrict__ wc,
-                                                                const float* __restrict__ bc, int L, int hidden,
-                                                                float* __restrict__ logits) {
+                                                                const float* __restrict__ bc, const int32_t* __restrict__ pair_off,
+                                                                int hidden, float* __restrict__ logits) {
     __shared__ float xs[1024];
     __shared__ float part[4];
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const float* x = x32 + (size_t)pair * L * hidden;           // [CLS] = token 0
+    const float* x = x32 + (size_t)pair_off[pair] * hidden;     // [CLS] = the pair's first packed row
     for (int i = tid; i < hidden; i += 256) xs[i] = x[i];
     __syncthreads();
     float acc = 0.f;
@@ -526,9 +576,10 @@ __global__ void ce_f32_split_kernel(const float* __restrict__ in, half_t* __rest
 // ------------------------------------------------------------------------------------------------
 static void ce_free_ws(rag_ce_model* m) {
     hipFree(m->x32); hipFree(m->y32); hipFree(m->x16); hipFree(m->q16); hipFree(m->kf16); hipFree(m->vf16); hipFree(m->ctx16);
-    hipFree(m->h16); hipFree(m->ids); hipFree(m->tt); hipFree(m->lens); hipFree(m->logits);
+    hipFree(m->h16); hipFree(m->ids); hipFree(m->tt); hipFree(m->lens); hipFree(m->logits); hipFree(m->pair_off); hipFree(m->row_pair); hipFree(m->m_packed);
     m->x32 = m->y32 = nullptr; m->x16 = m->q16 = m->kf16 = m->vf16 = m->ctx16 = m->h16 = nullptr;
     m->ids = m->tt = m->lens = nullptr; m->logits = nullptr;
+    m->pair_off = m->row_pair = m->m_packed = nullptr;
     m->ws_tokens = 0; m->ws_pairs = 0; m->ws_L = 0;
 }
 
@@ -630,13 +681,13 @@ static int launch_attention(rag_ctx* h, rag_ce_model* m, int P, int L, const ce_
     }
     const int waves = L / (16 * QB);
     hipLaunchKernelGGL((ce_attention_kernel<QB>), dim3(m->cfg.heads, P), dim3(64 * waves), lds, st, m->q16, pp.q, m->kf16, m->vf16,
-                       pp.kv, m->lens, L, m->cfg.hidden, m->cfg.heads, m->ctx16, pp.ctx);
+                       pp.kv, m->lens, m->pair_off, L, m->cfg.hidden, m->cfg.heads, m->ctx16, pp.ctx);
     return RAG_OK;
 }
 
 template <int PER>
 static void launch_ln(rag_ce_model* m, const float* y, const float* g, const float* b, int64_t M, size_t plane, hipStream_t st) {
-    hipLaunchKernelGGL(ce_layernorm_kernel<PER>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, y, g, b, M, m->cfg.hidden,
+    hipLaunchKernelGGL(ce_layernorm_kernel<PER>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, y, g, b, m->m_packed, m->cfg.hidden,
                        (float)m->cfg.ln_eps, m->x32, m->x16, plane);
 }
 
@@ -663,7 +714,11 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
         default: h->err = "ce: unsupported hidden size"; return RAG_ERR_ARG;                  \
     }
 #define EMB(PER) hipLaunchKernelGGL(ce_embed_ln_kernel<PER>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, m->ids, m->tt, m->word, \
-                                    m->pos, m->type, m->emb_ln_g, m->emb_ln_b, M, L, H, m->cfg.vocab_size, eps, m->x32, m->x16, pp.x)
+                                    m->pos, m->type, m->emb_ln_g, m->emb_ln_b, m->m_packed, m->row_pair, m->pair_off, L, H,            \
+                                    m->cfg.vocab_size, eps, m->x32, m->x16, pp.x)
+    // packed row layout of this chunk (no host round trip: grids cover the padded worst case, kernels stop at m_packed)
+    hipLaunchKernelGGL(ce_pack_scan_kernel, dim3(1), dim3(1024), 0, st, m->lens, P, L, m->pair_off, m->m_packed);
+    hipLaunchKernelGGL(ce_pack_rows_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, st, m->pair_off, P, L, Mp, m->row_pair);
     CE_PER_DISPATCH(EMB)
     const dim3 blk(512);
     const unsigned mt = (unsigned)(Mt / CE_BN);
@@ -671,26 +726,28 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     for (int l = 0; l < m->cfg.layers; ++l) {
         auto& ly = m->layers[l];
         hipLaunchKernelGGL(ce_gemm_kernel<EPI_QKV>, dim3(3 * H / CE_BM, mt), blk, lds, st, ly.wqkv, (size_t)3 * H * H, m->x16, pp.x,
-                           3 * H, H, ly.bqkv, (const float*)nullptr, (float*)nullptr, m->q16, pp.q, m->kf16, m->vf16, pp.kv, L, H,
-                           m->cfg.heads, M);
+                           3 * H, H, ly.bqkv, (const float*)nullptr, (float*)nullptr, m->q16, pp.q, m->kf16, m->vf16, pp.kv, H,
+                           m->cfg.heads, m->m_packed, m->row_pair, m->pair_off);
         {
             const int rc = L == 32 ? launch_attention<1>(h, m, P, L, pp, st) : launch_attention<2>(h, m, P, L, pp, st);
             if (rc != RAG_OK) return rc;
         }
         hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(H / CE_BM, mt), blk, lds, st, ly.wo, (size_t)H * H, m->ctx16, pp.ctx, H, H,
-                           ly.bo, m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, L, H, m->cfg.heads, M);
+                           ly.bo, m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
+                           m->row_pair, m->pair_off);
 #define LN1(PER) launch_ln<PER>(m, m->y32, ly.ln1_g, ly.ln1_b, M, pp.x, st)
         CE_PER_DISPATCH(LN1)
         hipLaunchKernelGGL(ce_gemm_kernel<EPI_GELU>, dim3(F / CE_BM, mt), blk, lds, st, ly.w1, (size_t)F * H, m->x16, pp.x, F, H,
                            ly.b1, (const float*)nullptr, (float*)nullptr, m->h16, pp.h, (half_t*)nullptr, (half_t*)nullptr, (size_t)0,
-                           L, H, m->cfg.heads, M);
+                           H, m->cfg.heads, m->m_packed, m->row_pair, m->pair_off);
         hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(H / CE_BM, mt), blk, lds, st, ly.w2, (size_t)H * F, m->h16, pp.h, H, F,
-                           ly.b2, m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, L, H, m->cfg.heads, M);
+                           ly.b2, m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
+                           m->row_pair, m->pair_off);
 #define LN2(PER) launch_ln<PER>(m, m->y32, ly.ln2_g, ly.ln2_b, M, pp.x, st)
         CE_PER_DISPATCH(LN2)
     }
     (void)nullh;
-    hipLaunchKernelGGL(ce_pool_classify_kernel, dim3(P), dim3(256), 0, st, m->x32, m->wp, m->bp, m->wc, m->bc, L, H, m->logits);
+    hipLaunchKernelGGL(ce_pool_classify_kernel, dim3(P), dim3(256), 0, st, m->x32, m->wp, m->bp, m->wc, m->bc, m->pair_off, H, m->logits);
     HIP_TRY(h, hipGetLastError());
     return RAG_OK;
 }
@@ -713,6 +770,9 @@ static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L) {
     HIP_TRY(h, hipMalloc(&m->ids, (size_t)Mp * 4));
     HIP_TRY(h, hipMalloc(&m->tt, (size_t)Mp * 4));
     HIP_TRY(h, hipMalloc(&m->lens, (size_t)P * 4));
+    HIP_TRY(h, hipMalloc(&m->pair_off, (size_t)(P + 1) * 4));
+    HIP_TRY(h, hipMalloc(&m->row_pair, (size_t)Mp * 4));
+    HIP_TRY(h, hipMalloc(&m->m_packed, 4));
     HIP_TRY(h, hipMalloc(&m->logits, (size_t)P * 4));
     // padded token rows are read by the GEMM tiles: keep them finite
     HIP_TRY(h, hipMemset(m->x16, 0, 2 * pp.x * 2));
