@@ -58,8 +58,7 @@ struct rag_ce_model {
 #define CE_X_BYTES (CE_BN * CE_BK * 2)                    // one plane of the token tile: 16 KiB
 #define CE_STAGE_BYTES (2 * CE_W_BYTES + 2 * CE_X_BYTES)  // W_hi | W_lo | X_hi | X_lo = 48 KiB
 #define CE_GEMM_LDS (3 * CE_STAGE_BYTES)                  // three stages = 144 KiB
-#define CE_EPI_BYTES (CE_GEMM_LDS / 8)                    // per-wave epilogue transpose region: 18 KiB
-#define CE_EPI_PLANE (64 * 144)                           // one fp16 plane of a 64 x 64 tile, rows padded to 144 B
+#define CE_EPI_PLANE16 (16 * 144)                         // one fp16 plane of a 16-token x 64-feature epilogue pass, rows padded to 144 B
 
 enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2 };
 
@@ -101,6 +100,14 @@ __device__ __forceinline__ void ce_dma(const half_t* __restrict__ g, char* lds, 
 // lgkmcnt(0)) and an M-part (48 MFMAs = 16 products x {lo*hi, hi*lo, hi*hi}), each closed by s_barrier; waves 4-7 run
 // half a phase behind waves 0-3 so one group's MFMAs cover the other's reads. RAW: one counted s_waitcnt vmcnt(6)
 // per K-step (step t+1 landed, step t+2 in flight); WAR: stage (t+2)%3 was last read in I(t-1).
+//
+// PERSISTENT workgroups (one per CU) with a CONTINUOUS DMA stream across tiles: the K = 384 GEMMs have only 12 K-steps, so
+// a per-tile prologue (two stages from cold) and epilogue cost a quarter of the tile. The last two K-steps of a tile
+// therefore issue steps 0 and 1 of the workgroup's NEXT tile into the stage ring, and the epilogue transposes through
+// the one stage that is free at that point (48 KiB = 6 KiB per wave, four 16-token passes), so the next main loop
+// starts with both stages resident. The packed row count lives on the device (no host sync): the loop stops at the
+// first token tile past it.
+#define CE_EPI_WAVE_BYTES (CE_STAGE_BYTES / 8)            // 6 KiB of the free stage per wave
 template <int EPI>
 __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__ W, size_t w_plane, const half_t* __restrict__ X,
                                                        size_t x_plane, int N, int K, const float* __restrict__ bias,
@@ -110,190 +117,225 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
                                                        const int32_t* __restrict__ m_packed, const int32_t* __restrict__ row_pair,
                                                        const int32_t* __restrict__ pair_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.y * CE_BN >= m_packed[0]) return;       // the grid covers the padded worst case; packed rows end earlier
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
     const bool lag = wm != 0;
-    const int n0 = blockIdx.x * CE_BM;          // feature tile (fast index: all feature tiles of a token tile are adjacent)
-    const int m0 = blockIdx.y * CE_BN;          // token tile
+    const int n_ft = N / CE_BM;
+    const int m_end = m_packed[0];
+    int tile = blockIdx.x;                       // feature tile fastest: workgroups running together share token tiles in L2
+    if ((tile / n_ft) * CE_BN >= m_end) return;
     // DMA source per thread: linear chunk i = tid (+512): row i>>2, position i&3 -> source chunk (i&3) ^ ((-(row>>2))&3)
     const int sr = tid >> 2;                                          // 0..127
     const int schunk = (tid & 3) ^ ((-(sr >> 2)) & 3);                // (row+128)>>2 has the same low 2 bits
-    const half_t* w_src = W + (size_t)(n0 + sr) * K + schunk * 8;
-    const half_t* x_src = X + (size_t)(m0 + sr) * K + schunk * 8;     // rows 0..127 of the token tile; +128*K for the rest
     const size_t x_half = (size_t)128 * K;
     const int fr = lane & 15, fq = lane >> 4;
     // fragment row r = base16 + fr (base16 multiple of 16 -> (r>>2)&3 == (fr>>2)&3): byte offset inside a plane tile
     const int off = fr * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
     const int a_base = wm * 64 * 64, b_base = wn * 64 * 64;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nt = K / CE_BK;
     const int last = nt - 1;
-#define CE_STEP(u) (((u) < last ? (u) : last) * CE_BK)
-#define CE_ISSUE(u)                                                                                               \
+    const half_t* w_cur = W + (size_t)((tile % n_ft) * CE_BM + sr) * K + schunk * 8;
+    const half_t* x_cur = X + (size_t)((tile / n_ft) * CE_BN + sr) * K + schunk * 8;   // rows 0..127 of the tile; +128*K for the rest
+    const half_t *w_nxt = w_cur, *x_nxt = x_cur;
+    bool has_next = false;
+    int sbase = 0;                               // ring stage of step 0 of the current tile
+#define CE_ISSUE(u)   /* step u of the current tile; u >= nt: step u - nt of the next tile (or a harmless re-load) */     \
     {                                                                                                             \
-        char* st_ = smem + ((u) % 3) * CE_STAGE_BYTES;                                                            \
-        const int ko_ = CE_STEP(u);                                                                               \
-        ce_dma(w_src + ko_, st_, wid);                                                                            \
-        ce_dma(w_src + w_plane + ko_, st_ + CE_W_BYTES, wid);                                                     \
-        ce_dma(x_src + ko_, st_ + 2 * CE_W_BYTES, wid);                                                           \
-        ce_dma(x_src + x_half + ko_, st_ + 2 * CE_W_BYTES + 512 * 16, wid);                                       \
-        ce_dma(x_src + x_plane + ko_, st_ + 2 * CE_W_BYTES + CE_X_BYTES, wid);                                    \
-        ce_dma(x_src + x_plane + x_half + ko_, st_ + 2 * CE_W_BYTES + CE_X_BYTES + 512 * 16, wid);                \
+        const int u_ = (u);                                                                                       \
+        const half_t* ws_ = u_ < nt ? w_cur + u_ * CE_BK : (has_next ? w_nxt + (u_ - nt) * CE_BK : w_cur + last * CE_BK);  \
+        const half_t* xs_ = u_ < nt ? x_cur + u_ * CE_BK : (has_next ? x_nxt + (u_ - nt) * CE_BK : x_cur + last * CE_BK);  \
+        char* st_ = smem + ((sbase + u_) % 3) * CE_STAGE_BYTES;                                                   \
+        ce_dma(ws_, st_, wid);                                                                                    \
+        ce_dma(ws_ + w_plane, st_ + CE_W_BYTES, wid);                                                             \
+        ce_dma(xs_, st_ + 2 * CE_W_BYTES, wid);                                                                   \
+        ce_dma(xs_ + x_half, st_ + 2 * CE_W_BYTES + 512 * 16, wid);                                               \
+        ce_dma(xs_ + x_plane, st_ + 2 * CE_W_BYTES + CE_X_BYTES, wid);                                            \
+        ce_dma(xs_ + x_plane + x_half, st_ + 2 * CE_W_BYTES + CE_X_BYTES + 512 * 16, wid);                        \
     }
 #define CE_BAR __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
     CE_ISSUE(0)
     CE_ISSUE(1)
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     CE_BAR
-    if (lag) { CE_BAR }
-    for (int t = 0; t < nt; ++t) {
-        const char* st = smem + (t % 3) * CE_STAGE_BYTES;
-        half8 ah[4], al[4], bh[4], bl[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ah[i] = *reinterpret_cast<const half8*>(st + a_base + i * 16 * 64 + off);
-            al[i] = *reinterpret_cast<const half8*>(st + CE_W_BYTES + a_base + i * 16 * 64 + off);
+    for (bool first = true;; first = false) {
+        const int n0 = (tile % n_ft) * CE_BM;    // feature tile
+        const int m0 = (tile / n_ft) * CE_BN;    // token tile
+        const int nb = n0 + wm * 64, mb = m0 + wn * 64;
+        {
+            const int nx = tile + gridDim.x;
+            has_next = (nx / n_ft) * CE_BN < m_end;
+            if (has_next) {
+                w_nxt = W + (size_t)((nx % n_ft) * CE_BM + sr) * K + schunk * 8;
+                x_nxt = X + (size_t)((nx / n_ft) * CE_BN + sr) * K + schunk * 8;
+            }
         }
+        // bias in registers before the main loop: the epilogue must not start with a global load behind the in-flight DMA
+        float4 bv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bh[j] = *reinterpret_cast<const half8*>(st + 2 * CE_W_BYTES + b_base + j * 16 * 64 + off);
-            bl[j] = *reinterpret_cast<const half8*>(st + 2 * CE_W_BYTES + CE_X_BYTES + b_base + j * 16 * 64 + off);
-        }
-        CE_ISSUE(t + 2)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lag) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        CE_BAR
-        __builtin_amdgcn_s_setprio(1);
+        for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const float4*>(bias + nb + i * 16 + fq * 4);
+        f32x4 acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (lag) { CE_BAR }
+        for (int t = 0; t < nt; ++t) {
+            const char* st = smem + ((sbase + t) % 3) * CE_STAGE_BYTES;
+            half8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ah[i] = *reinterpret_cast<const half8*>(st + a_base + i * 16 * 64 + off);
+                al[i] = *reinterpret_cast<const half8*>(st + CE_W_BYTES + a_base + i * 16 * 64 + off);
             }
-        __builtin_amdgcn_s_setprio(0);
-        if (!lag) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        CE_BAR
-    }
-    if (!lag) { CE_BAR }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // epilogue: acc[i][j][r] = C^T[n = nb + i*16 + fq*4 + r][m = mb + j*16 + fr]. Each wave transposes its 64 x 64
-    // tile through a private 18 KiB LDS region (the pipeline stages are dead by now) so that every global store /
-    // residual load instruction covers whole 128 B lines of the row-major outputs instead of 32 B row fragments.
-    CE_BAR
-    char* wl = smem + wid * CE_EPI_BYTES;
-    const int nb = n0 + wm * 64, mb = m0 + wn * 64;
-    if (EPI == EPI_RESID) {
-        // fp32 tile [token][feature], row stride 272 B
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 bv = *reinterpret_cast<const float4*>(bias + nb + i * 16 + fq * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<float4*>(wl + (j * 16 + fr) * 272 + (i * 16 + fq * 4) * 4) =
-                    make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int rr = lane >> 4, cc = lane & 15;
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int row = it * 4 + rr;
-            const float4 v = *reinterpret_cast<const float4*>(wl + row * 272 + cc * 16);
-            const size_t g = (size_t)(mb + row) * N + nb + cc * 4;
-            const float4 rv = *reinterpret_cast<const float4*>(resid + g);
-            *reinterpret_cast<float4*>(out32 + g) = make_float4(v.x + rv.x, v.y + rv.y, v.z + rv.z, v.w + rv.w);
-        }
-    } else if (EPI == EPI_GELU || nb < 2 * hidden) {
-        // split-fp16 tile [token][feature]: hi plane then lo plane, row stride 144 B
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 bv = *reinterpret_cast<const float4*>(bias + nb + i * 16 + fq * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
-                if (EPI == EPI_GELU) { v0 = ce_gelu(v0); v1 = ce_gelu(v1); v2 = ce_gelu(v2); v3 = ce_gelu(v3); }
-                store_split4(reinterpret_cast<half_t*>(wl + (j * 16 + fr) * 144 + (i * 16 + fq * 4) * 2), CE_EPI_PLANE / 2, v0, v1,
-                             v2, v3);
+                bh[j] = *reinterpret_cast<const half8*>(st + 2 * CE_W_BYTES + b_base + j * 16 * 64 + off);
+                bl[j] = *reinterpret_cast<const half8*>(st + 2 * CE_W_BYTES + CE_X_BYTES + b_base + j * 16 * 64 + off);
             }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (EPI == EPI_GELU || nb < hidden) {
-            // FFN activations [token][ffn], or Q rows [token][hidden]: 8 lanes cover one 128 B line of a row
-            const int ldo = EPI == EPI_GELU ? N : hidden;
-            const int rr = lane >> 3, cc = lane & 7;
+            CE_ISSUE(t + 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // step t+1 must have landed before the next I-part. On a continued tile steps 0 and 1 were resident before the
+            // loop started (see below), so its first wait is skipped: it would only wait for the previous epilogue's stores.
+            const bool need_wait = first || t > 0;
+            if (lag && need_wait) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            CE_BAR
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = it * 8 + rr;
-                const half8 hi = *reinterpret_cast<const half8*>(wl + row * 144 + cc * 16);
-                const half8 lo = *reinterpret_cast<const half8*>(wl + CE_EPI_PLANE + row * 144 + cc * 16);
-                half_t* o = out16 + (size_t)(mb + row) * ldo + nb + cc * 8;
-                *reinterpret_cast<half8*>(o) = hi;
-                *reinterpret_cast<half8*>(o + out_plane) = lo;
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            if (!lag && need_wait) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            CE_BAR
+        }
+        if (!lag) { CE_BAR }
+        // Both groups are past their last fragment reads. Steps 0 and 1 of the next tile are in flight into the other two
+        // stages; wait for them here, where no store is outstanding yet (a counted wait across the epilogue's stores
+        // would rely on loads and stores retiring in one order).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // epilogue: acc[i][j][r] = C^T[n = nb + i*16 + fq*4 + r][m = mb + j*16 + fr]. Each wave transposes its 64 x 64 tile,
+        // 16 tokens (32 for V) at a time, through its 6 KiB of the free stage so that every global store / residual load
+        // covers whole 128 B lines of the row-major outputs (or one whole 1 KiB MFMA fragment tile for K and V).
+        char* wl = smem + ((sbase + nt + 2) % 3) * CE_STAGE_BYTES + wid * CE_EPI_WAVE_BYTES;
+        if (EPI == EPI_RESID) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                       // fp32 [16 tokens][64 features], row stride 272 B
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4*>(wl + fr * 272 + (i * 16 + fq * 4) * 4) =
+                        make_float4(acc[i][j][0] + bv[i].x, acc[i][j][1] + bv[i].y, acc[i][j][2] + bv[i].z, acc[i][j][3] + bv[i].w);
+                __builtin_amdgcn_wave_barrier();
+                const int rr = lane >> 4, cc = lane & 15;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 4 + rr;
+                    const float4 v = *reinterpret_cast<const float4*>(wl + row * 272 + cc * 16);
+                    const size_t g = (size_t)(mb + j * 16 + row) * N + nb + cc * 4;
+                    const float4 rv = *reinterpret_cast<const float4*>(resid + g);
+                    *reinterpret_cast<float4*>(out32 + g) = make_float4(v.x + rv.x, v.y + rv.y, v.z + rv.z, v.w + rv.w);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else if (EPI == EPI_GELU || nb < 2 * hidden) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                       // split fp16 [16 tokens][64 features]: hi plane | lo plane, rows 144 B
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y, v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
+                    if (EPI == EPI_GELU) { v0 = ce_gelu(v0); v1 = ce_gelu(v1); v2 = ce_gelu(v2); v3 = ce_gelu(v3); }
+                    store_split4(reinterpret_cast<half_t*>(wl + fr * 144 + (i * 16 + fq * 4) * 2), CE_EPI_PLANE16 / 2, v0, v1, v2, v3);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (EPI == EPI_GELU || nb < hidden) {
+                    // FFN activations [token][ffn], or Q rows [token][hidden]: 8 lanes cover one 128 B line of a row
+                    const int ldo = EPI == EPI_GELU ? N : hidden;
+                    const int rr = lane >> 3, cc = lane & 7;
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int row = it * 8 + rr;
+                        const half8 hi = *reinterpret_cast<const half8*>(wl + row * 144 + cc * 16);
+                        const half8 lo = *reinterpret_cast<const half8*>(wl + CE_EPI_PLANE16 + row * 144 + cc * 16);
+                        half_t* o = out16 + (size_t)(mb + j * 16 + row) * ldo + nb + cc * 8;
+                        *reinterpret_cast<half8*>(o) = hi;
+                        *reinterpret_cast<half8*>(o + out_plane) = lo;
+                    }
+                } else {
+                    // K features -> kf16[pair rows][head][key tile][lane = fq*16 + key%16][8 dims fq*8..]: the MFMA A-fragment
+                    // order the attention kernel DMAs straight into LDS. One store instruction = one whole 1 KiB fragment tile.
+                    const int head0 = (nb - hidden) >> 5;          // this wave's 64 features = heads head0, head0+1
+                    const int m = mb + j * 16;
+                    const int pair = row_pair[m];                   // 16-token tiles never straddle pairs (offsets are multiples of 32)
+                    if (pair >= 0) {                                // rows past the packed end have no (pair, token) slot
+                        const int po = pair_off[pair], Lp = pair_off[pair + 1] - po, t16 = (m - po) >> 4;
+#pragma unroll
+                        for (int hl = 0; hl < 2; ++hl) {
+                            const half8 hi = *reinterpret_cast<const half8*>(wl + fr * 144 + (hl * 4 + fq) * 16);
+                            const half8 lo = *reinterpret_cast<const half8*>(wl + CE_EPI_PLANE16 + fr * 144 + (hl * 4 + fq) * 16);
+                            half_t* o = kf16 + ((size_t)po * heads + (size_t)(head0 + hl) * Lp) * 32 + ((size_t)t16 * 64 + lane) * 8;
+                            *reinterpret_cast<half8*>(o) = hi;
+                            *reinterpret_cast<half8*>(o + kv_plane) = lo;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         } else {
-            // K features -> kf16[pair][head][key tile][lane = fq*16 + key%16][8 dims fq*8..]: the MFMA A-fragment order the
-            // attention kernel DMAs straight into LDS. One store instruction = one whole 1 KiB fragment tile.
-            const int head0 = (nb - hidden) >> 5;                  // this wave's 64 features = heads head0, head0+1
+            // EPI_QKV, V features: one fp16 plane of [64 features][32 tokens] at a time (rows 80 B), then
+            // vf16[pair rows][head][32-key block][d half][lane = fq*16 + d%16][8 key slots]: slot e < 4 is key fq*4 + e of the
+            // block, slot e >= 4 is key 16 + fq*4 + e - 4 (the order in which the S^T accumulators of two adjacent key tiles sit
+            // in a lane's registers, so P never leaves registers in the attention kernel).
+            const int head0 = (nb - 2 * hidden) >> 5;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int hl = it >> 2, tl = it & 3;               // head, 16-token tile inside the wave's 64 tokens
-                const int m = mb + tl * 16;
-                const int pair = row_pair[m];                       // 16-token tiles never straddle pairs (offsets are multiples of 32)
-                if (pair < 0) continue;                            // rows past the packed end have no (pair, token) slot
-                const int po = pair_off[pair], Lp = pair_off[pair + 1] - po, t = (m - po) >> 4;
-                const half8 hi = *reinterpret_cast<const half8*>(wl + (tl * 16 + fr) * 144 + (hl * 4 + fq) * 16);
-                const half8 lo = *reinterpret_cast<const half8*>(wl + CE_EPI_PLANE + (tl * 16 + fr) * 144 + (hl * 4 + fq) * 16);
-                half_t* o = kf16 + ((size_t)po * heads + (size_t)(head0 + hl) * Lp) * 32 + ((size_t)t * 64 + lane) * 8;
-                *reinterpret_cast<half8*>(o) = hi;
-                *reinterpret_cast<half8*>(o + kv_plane) = lo;
+            for (int kl = 0; kl < 2; ++kl) {
+                const int m = mb + kl * 32;
+                const int pair = row_pair[m];
+                const int po = pair >= 0 ? pair_off[pair] : 0, Lp = pair >= 0 ? pair_off[pair + 1] - po : 32;
+                const int kb = pair >= 0 ? (m - po) >> 5 : 0;
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float v = acc[i][kl * 2 + jj][r] + (r == 0 ? bv[i].x : r == 1 ? bv[i].y : r == 2 ? bv[i].z : bv[i].w);
+                                const half_t hi = (half_t)v;
+                                *reinterpret_cast<half_t*>(wl + (i * 16 + fq * 4 + r) * 80 + (jj * 16 + fr) * 2) =
+                                    pl == 0 ? hi : (half_t)(v - (float)hi);
+                            }
+                    __builtin_amdgcn_wave_barrier();
+                    if (pair >= 0) {
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int hl = it >> 1, dh = it & 1;            // head, d half
+                            const char* rowp = wl + (hl * 32 + dh * 16 + fr) * 80 + fq * 8;
+                            const half4 h0 = *reinterpret_cast<const half4*>(rowp), h1 = *reinterpret_cast<const half4*>(rowp + 32);
+                            const half8 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                            half_t* o = vf16 + ((size_t)po * heads + (size_t)(head0 + hl) * Lp) * 32 + (((size_t)kb * 2 + dh) * 64 + lane) * 8;
+                            *reinterpret_cast<half8*>(o + (pl ? kv_plane : 0)) = hv;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
-    } else {
-        // EPI_QKV, V features: split-fp16 tile [feature][token] in LDS, then vf16[pair][head][32-key block][d half]
-        // [lane = fq*16 + d%16][8 key slots]: slot e < 4 is key fq*4 + e of the block, slot e >= 4 is key 16 + fq*4 + e - 4
-        // (the order in which the S^T accumulators of two adjacent key tiles sit in a lane's registers, so P never
-        // leaves registers in the attention kernel).
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 bv = *reinterpret_cast<const float4*>(bias + nb + i * 16 + fq * 4);
-            const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc[i][j][r] + bb[r];
-                    const half_t hi = (half_t)v;
-                    half_t* q = reinterpret_cast<half_t*>(wl + (i * 16 + fq * 4 + r) * 144 + (j * 16 + fr) * 2);
-                    q[0] = hi;
-                    q[CE_EPI_PLANE / 2] = (half_t)(v - (float)hi);
-                }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int head0 = (nb - 2 * hidden) >> 5;
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int hl = it >> 2, kl = (it >> 1) & 1, dh = it & 1;    // head, 32-key block, d half
-            const int m = mb + kl * 32;
-            const int pair = row_pair[m];
-            if (pair < 0) continue;
-            const int po = pair_off[pair], Lp = pair_off[pair + 1] - po, kb = (m - po) >> 5;
-            const char* rowp = wl + (hl * 32 + dh * 16 + fr) * 144 + (kl * 32 + fq * 4) * 2;
-            const half4 h0 = *reinterpret_cast<const half4*>(rowp), h1 = *reinterpret_cast<const half4*>(rowp + 32);
-            const half4 l0 = *reinterpret_cast<const half4*>(rowp + CE_EPI_PLANE), l1 = *reinterpret_cast<const half4*>(rowp + CE_EPI_PLANE + 32);
-            const half8 hi = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-            const half8 lo = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-            half_t* o = vf16 + ((size_t)po * heads + (size_t)(head0 + hl) * Lp) * 32 + (((size_t)kb * 2 + dh) * 64 + lane) * 8;
-            *reinterpret_cast<half8*>(o) = hi;
-            *reinterpret_cast<half8*>(o + kv_plane) = lo;
-        }
+        if (!has_next) break;
+        // next tile: its steps 0 and 1 are resident (waited above); the stage this epilogue used is refilled by CE_ISSUE(2)
+        // in the coming I-part, so every wave must be done reading it first
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        CE_BAR
+        tile += gridDim.x;
+        w_cur = w_nxt;
+        x_cur = x_nxt;
+        sbase = (sbase + nt) % 3;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // clamped tail re-loads of the last tile: retire them before exit
 }
 
 // ---- LayerNorm helpers: one wave per token row of `hidden` floats (hidden % 64 == 0, <= 1024) --------------
@@ -721,26 +763,27 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     hipLaunchKernelGGL(ce_pack_rows_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, st, m->pair_off, P, L, Mp, m->row_pair);
     CE_PER_DISPATCH(EMB)
     const dim3 blk(512);
+    static const unsigned n_cu = [] { int d = 0, n = 0; hipGetDevice(&d); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return (unsigned)(n > 0 ? n : 256); }();
     const unsigned mt = (unsigned)(Mt / CE_BN);
     const half_t* nullh = nullptr;
     for (int l = 0; l < m->cfg.layers; ++l) {
         auto& ly = m->layers[l];
-        hipLaunchKernelGGL(ce_gemm_kernel<EPI_QKV>, dim3(3 * H / CE_BM, mt), blk, lds, st, ly.wqkv, (size_t)3 * H * H, m->x16, pp.x,
+        hipLaunchKernelGGL(ce_gemm_kernel<EPI_QKV>, dim3(std::min<unsigned>(n_cu, 3 * H / CE_BM * mt)), blk, lds, st, ly.wqkv, (size_t)3 * H * H, m->x16, pp.x,
                            3 * H, H, ly.bqkv, (const float*)nullptr, (float*)nullptr, m->q16, pp.q, m->kf16, m->vf16, pp.kv, H,
                            m->cfg.heads, m->m_packed, m->row_pair, m->pair_off);
         {
             const int rc = L == 32 ? launch_attention<1>(h, m, P, L, pp, st) : launch_attention<2>(h, m, P, L, pp, st);
             if (rc != RAG_OK) return rc;
         }
-        hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(H / CE_BM, mt), blk, lds, st, ly.wo, (size_t)H * H, m->ctx16, pp.ctx, H, H,
+        hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(std::min<unsigned>(n_cu, H / CE_BM * mt)), blk, lds, st, ly.wo, (size_t)H * H, m->ctx16, pp.ctx, H, H,
                            ly.bo, m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
                            m->row_pair, m->pair_off);
 #define LN1(PER) launch_ln<PER>(m, m->y32, ly.ln1_g, ly.ln1_b, M, pp.x, st)
         CE_PER_DISPATCH(LN1)
-        hipLaunchKernelGGL(ce_gemm_kernel<EPI_GELU>, dim3(F / CE_BM, mt), blk, lds, st, ly.w1, (size_t)F * H, m->x16, pp.x, F, H,
+        hipLaunchKernelGGL(ce_gemm_kernel<EPI_GELU>, dim3(std::min<unsigned>(n_cu, F / CE_BM * mt)), blk, lds, st, ly.w1, (size_t)F * H, m->x16, pp.x, F, H,
                            ly.b1, (const float*)nullptr, (float*)nullptr, m->h16, pp.h, (half_t*)nullptr, (half_t*)nullptr, (size_t)0,
                            H, m->cfg.heads, m->m_packed, m->row_pair, m->pair_off);
-        hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(H / CE_BM, mt), blk, lds, st, ly.w2, (size_t)H * F, m->h16, pp.h, H, F,
+        hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(std::min<unsigned>(n_cu, H / CE_BM * mt)), blk, lds, st, ly.w2, (size_t)H * F, m->h16, pp.h, H, F,
                            ly.b2, m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
                            m->row_pair, m->pair_off);
 #define LN2(PER) launch_ln<PER>(m, m->y32, ly.ln2_g, ly.ln2_b, M, pp.x, st)
