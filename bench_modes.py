@@ -142,8 +142,7 @@ def run_mode(args):
         })
     elif args.mode == "pipeline":
         # BASELINE.json configs[3]: hybrid top-100 -> cross-encoder rerank -> top-20, batch = 256 queries, ONE call
-        from oracle import bert_oracle as B          # weights only (seeded); the forward measured here is the HIP one
-        from optimized_rag_amd.cross_encoder import flatten_state_dict
+        from optimized_rag_amd.cross_encoder import MINILM_L6_CONFIG, random_init_tensors
         N, Q, k, pool, L, Ld, Lq = args.rows, min(args.queries, 256), args.k, 100, 256, 224, 16
         g = torch.Generator(device=device)
         g.manual_seed(1234)
@@ -168,8 +167,8 @@ def run_mode(args):
             ptr.append(len(terms))
         ptr_d = torch.from_numpy(np.asarray(ptr, np.int32)).to(device)
         terms_d = torch.from_numpy(np.asarray(terms, np.int32)).to(device)
-        cfg = B.minilm_config()
-        eng.ce_load(cfg, flatten_state_dict(B.seeded_weights(cfg, 2024), cfg["layers"]))
+        cfg = MINILM_L6_CONFIG
+        eng.ce_load(cfg, random_init_tensors(cfg, 2024))
         # passage token store: WordPiece ids ~U[1000, vocab), lengths ~U[96, 224], 16-token queries
         tok_store = torch.randint(1000, cfg["vocab_size"], (N, Ld), generator=torch.Generator().manual_seed(5), dtype=torch.int32)
         tok_len = torch.randint(96, Ld + 1, (N,), generator=torch.Generator().manual_seed(6), dtype=torch.int32)
@@ -212,10 +211,9 @@ def run_mode(args):
             "sanity": {"all_slots_filled_and_sorted": ok},
         })
     else:
-        from oracle import bert_oracle as B          # weights only (seeded); the forward measured here is the HIP one
-        from optimized_rag_amd.cross_encoder import flatten_state_dict
-        cfg = B.minilm_config()
-        eng.ce_load(cfg, flatten_state_dict(B.seeded_weights(cfg, 2024), cfg["layers"]))
+        from optimized_rag_amd.cross_encoder import MINILM_L6_CONFIG, random_init_tensors
+        cfg = MINILM_L6_CONFIG
+        eng.ce_load(cfg, random_init_tensors(cfg, 2024))
         Q, pool, L = min(args.queries, 256), 100, 256
         P = Q * pool
         rng = np.random.default_rng(5)

@@ -42,6 +42,32 @@ def config_from_hf(cfg):
                 type_vocab=cfg.get("type_vocab_size", 2), eps=cfg.get("layer_norm_eps", 1e-12))
 
 
+MINILM_L6_CONFIG = dict(vocab_size=30522, hidden=384, layers=6, heads=12, ffn=1536, max_pos=512, type_vocab=2, eps=1e-12)
+"""Shape of cross-encoder/ms-marco-MiniLM-L-6-v2 (the checkpoint the reference names at config.py:49), for benchmarks
+that run without the downloaded weights; a real deployment takes the shape from the checkpoint's config.json."""
+
+
+def random_init_tensors(cfg, seed=0):
+    """Random-init weights of the architecture in rag_ce_load_host's tensor order (benchmarks have no checkpoint: there
+    is no network). Scales are those of a trained BERT (0.02-0.1), LayerNorm gains around 1."""
+    rng = np.random.default_rng(seed)
+    H, F = cfg["hidden"], cfg["ffn"]
+
+    def mat(*shape, s=0.05):
+        return (rng.standard_normal(shape) * s).astype(np.float32)
+
+    def gain():
+        return (1.0 + mat(H, s=0.1)).astype(np.float32)
+
+    out = [mat(cfg["vocab_size"], H, s=0.1), mat(cfg["max_pos"], H, s=0.1), mat(cfg.get("type_vocab", 2), H, s=0.1), gain(), mat(H, s=0.1)]
+    for _ in range(cfg["layers"]):
+        out += [mat(H, H, s=0.08), mat(H), mat(H, H, s=0.08), mat(H), mat(H, H, s=0.08), mat(H),      # q, k, v
+                mat(H, H), mat(H), gain(), mat(H, s=0.1),                                              # attention output + LN
+                mat(F, H), mat(F), mat(H, F), mat(H), gain(), mat(H, s=0.1)]                           # FFN + LN
+    out += [mat(H, H), mat(H), mat(1, H, s=0.5), mat(1, s=0.5)]                                        # pooler, classifier
+    return out
+
+
 class LocalCrossEncoder:
     def __init__(self, cfg, tensors, tokenizer, max_length=512, engine=None, batch_pairs=4096):
         self.cfg = cfg
