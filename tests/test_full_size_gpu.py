@@ -88,3 +88,66 @@ def test_float64_spot_check_of_a_query_subset(world):
         order = np.lexsort((short, -exact))[:K]
         np.testing.assert_array_equal(got_i[qi], short[order])
         np.testing.assert_allclose(got_s[qi], exact[order], atol=1e-9)
+
+
+def test_bm25_full_size_staged_equals_exhaustive_select(world, monkeypatch):
+    """BASELINE.json configs[2] at FULL size (1M docs, ~9.5e7 postings, 1024 queries, top-100): the staged-threshold BM25
+    path must return bit-identical ids and scores to the path that runs the exact per-range select on every range, its
+    scores are max-normalised and sorted, and the sharded pipeline property holds: scoring two doc partitions with the
+    global statistics and merging == scoring the whole corpus."""
+    import torch
+    import bench_modes as BM
+    from optimized_rag_amd.bm25 import Bm25Postings
+    eng = world["whole"]
+    indptr, d, tf, dl, tok, doc_ptr = BM.synthetic_csr(N, 100_000, 120)
+    post = Bm25Postings(indptr, d, tf, dl, Bm25Postings.idf_table(np.diff(indptr).clip(min=0), N), float(dl.sum()) / N)
+    post.idf[np.diff(indptr) == 0] = 0.0
+    post.load(eng)
+    rng = np.random.default_rng(7)
+    ptr, terms = [0], []
+    for i in range(Q):
+        di = int(rng.integers(0, N))
+        toks = tok[doc_ptr[di]:doc_ptr[di + 1]]
+        n = int(rng.integers(4, 13))
+        terms.extend(int(x) for x in (rng.choice(toks, n) if len(toks) else [0] * n))
+        ptr.append(len(terms))
+    ptr, terms = np.asarray(ptr, np.int32), np.asarray(terms, np.int32)
+    ptr_d, terms_d = torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda()
+    pool = 100
+
+    def run(e):
+        ids = torch.empty((Q, pool), dtype=torch.int64, device="cuda")
+        sc = torch.empty((Q, pool), dtype=torch.float64, device="cuda")
+        mx = torch.empty((Q,), dtype=torch.float64, device="cuda")
+        e.bm25_topk_dev(ptr_d, terms_d, pool, ids, None, sc, mx)
+        torch.cuda.synchronize()
+        return ids.cpu().numpy(), sc.cpu().numpy(), mx.cpu().numpy()
+
+    ids_s, sc_s, mx_s = run(eng)                                   # staged threshold (default)
+    monkeypatch.setenv("RAG_BM25_NO_STAGING", "1")
+    ids_e, sc_e, mx_e = run(eng)                                   # exact select on all 62 ranges
+    monkeypatch.delenv("RAG_BM25_NO_STAGING")
+    np.testing.assert_array_equal(ids_s, ids_e)
+    np.testing.assert_array_equal(sc_s, sc_e)
+    np.testing.assert_array_equal(mx_s, mx_e)
+    assert (sc_s[:, 0] == 1.0).all() and (np.diff(sc_s, axis=1) <= 0).all() and (ids_s >= 0).all()
+    # two doc partitions with global statistics, raw scores, merged on the device == the whole corpus
+    cut = 437_000
+    parts = []
+    for lo, hi in ((0, cut), (cut, N)):
+        e = world["RagEngine"](dim=D, device=0)
+        e.index_reserve(hi - lo, id_base=lo)
+        e.index_append(world["corpus"][lo:hi].contiguous())          # row-aligned ids for the BM25 doc numbers
+        post.shard(lo, hi).load(e)
+        e.bm25_set_normalize(False)
+        parts.append(run(e))
+        e.close()
+    ids = torch.from_numpy(np.stack([p[0] for p in parts])).cuda()
+    sc = torch.from_numpy(np.stack([p[1] for p in parts])).cuda()
+    oi = torch.empty((Q, pool), dtype=torch.int64, device="cuda")
+    os_ = torch.empty((Q, pool), dtype=torch.float64, device="cuda")
+    eng.merge_topk_dev(ids, sc, oi, os_)
+    torch.cuda.synchronize()
+    merged = os_.cpu().numpy()
+    np.testing.assert_array_equal(oi.cpu().numpy(), ids_s)
+    np.testing.assert_array_equal(merged / np.where(merged[:, :1] > 0, merged[:, :1], 1.0), sc_s)
