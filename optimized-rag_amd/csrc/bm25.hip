@@ -460,7 +460,7 @@ static int bm25_run(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, i
     if (mode == 0) ARG_CHECK(h, k > 0 && k <= BM_MERGE / 2 && k <= BM_RANGE, "bm25: 0 < k <= 1024");
     hipStream_t st = h->stream;
     const int n_ranges = (int)((ix->n_docs + BM_RANGE - 1) / BM_RANGE);
-    static bool attr = false;
+    bool& attr = h->attr_bm25;
     if (!attr) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bm25_range_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, BM_LDS_BYTES));
@@ -526,7 +526,7 @@ int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_
     ARG_CHECK(h, Q > 0 && Q <= 65535 && term_ptr_dev && ids_dev && scores_dev, "bm25_topk_dev: bad arguments");
     ARG_CHECK(h, k > 0 && k <= BM_MERGE / 2 && k <= BM_RANGE, "bm25: 0 < k <= 1024");
     rag_bm25_index* ix = h->bm25;
-    static bool attr = false;
+    bool& attr = h->attr_bm25;
     if (!attr) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bm25_range_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, BM_LDS_BYTES));

@@ -78,6 +78,9 @@ struct rag_ctx {
     int tok_L = 0;
     void* pipe_ws = nullptr;
     size_t pipe_ws_bytes = 0;
+    // hipFuncSetAttribute (dynamic LDS above 64 KiB) is per device: remembered per handle, not per process
+    bool attr_dense = false, attr_bm25 = false, attr_ce_gemm = false;
+    int attr_ce_attn_lds[3] = {0, 0, 0};
     rag_ce_model* ce = nullptr;
 };
 

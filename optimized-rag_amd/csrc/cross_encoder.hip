@@ -123,8 +123,15 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
     const bool lag = wm != 0;
     const int n_ft = N / CE_BM;
     const int m_end = m_packed[0];
-    int tile = blockIdx.x;                       // feature tile fastest: workgroups running together share token tiles in L2
-    if ((tile / n_ft) * CE_BN >= m_end) return;
+    // XCD-aware work order (speed only): workgroup b runs on XCD b & 7, and every XCD has its own L2. XCD x owns the token
+    // tiles m = x (mod 8); its gridDim.x / 8 workgroups walk the (token tile, feature tile) pairs of those tiles feature
+    // tile fastest, so the n_ft workgroups that share a token tile read it through ONE L2 (before this, the tile was
+    // fetched once per XCD: 20 GB of HBM/fabric reads per FFN-up GEMM against 2.3 GB of activations).
+    const int xcd = blockIdx.x & 7, n_slots = gridDim.x >> 3;
+    int work = blockIdx.x >> 3;
+#define CE_TILE_M(w) (((w) / n_ft) * 8 + xcd)
+#define CE_TILE_N(w) ((w) % n_ft)
+    if (CE_TILE_M(work) * CE_BN >= m_end) return;
     // DMA source per thread: linear chunk i = tid (+512): row i>>2, position i&3 -> source chunk (i&3) ^ ((-(row>>2))&3)
     const int sr = tid >> 2;                                          // 0..127
     const int schunk = (tid & 3) ^ ((-(sr >> 2)) & 3);                // (row+128)>>2 has the same low 2 bits
@@ -135,8 +142,8 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
     const int a_base = wm * 64 * 64, b_base = wn * 64 * 64;
     const int nt = K / CE_BK;
     const int last = nt - 1;
-    const half_t* w_cur = W + (size_t)((tile % n_ft) * CE_BM + sr) * K + schunk * 8;
-    const half_t* x_cur = X + (size_t)((tile / n_ft) * CE_BN + sr) * K + schunk * 8;   // rows 0..127 of the tile; +128*K for the rest
+    const half_t* w_cur = W + (size_t)(CE_TILE_N(work) * CE_BM + sr) * K + schunk * 8;
+    const half_t* x_cur = X + (size_t)(CE_TILE_M(work) * CE_BN + sr) * K + schunk * 8;   // rows 0..127 of the tile; +128*K for the rest
     const half_t *w_nxt = w_cur, *x_nxt = x_cur;
     bool has_next = false;
     int sbase = 0;                               // ring stage of step 0 of the current tile
@@ -159,15 +166,15 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     CE_BAR
     for (bool first = true;; first = false) {
-        const int n0 = (tile % n_ft) * CE_BM;    // feature tile
-        const int m0 = (tile / n_ft) * CE_BN;    // token tile
+        const int n0 = CE_TILE_N(work) * CE_BM;  // feature tile
+        const int m0 = CE_TILE_M(work) * CE_BN;  // token tile
         const int nb = n0 + wm * 64, mb = m0 + wn * 64;
         {
-            const int nx = tile + gridDim.x;
-            has_next = (nx / n_ft) * CE_BN < m_end;
+            const int nx = work + n_slots;
+            has_next = CE_TILE_M(nx) * CE_BN < m_end;
             if (has_next) {
-                w_nxt = W + (size_t)((nx % n_ft) * CE_BM + sr) * K + schunk * 8;
-                x_nxt = X + (size_t)((nx / n_ft) * CE_BN + sr) * K + schunk * 8;
+                w_nxt = W + (size_t)(CE_TILE_N(nx) * CE_BM + sr) * K + schunk * 8;
+                x_nxt = X + (size_t)(CE_TILE_M(nx) * CE_BN + sr) * K + schunk * 8;
             }
         }
         // bias in registers before the main loop: the epilogue must not start with a global load behind the in-flight DMA
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
         // in the coming I-part, so every wave must be done reading it first
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         CE_BAR
-        tile += gridDim.x;
+        work += n_slots;
         w_cur = w_nxt;
         x_cur = x_nxt;
         sbase = (sbase + nt) % 3;
@@ -715,7 +722,7 @@ static ce_planes planes_for(const rag_ce_model* m, int64_t Mp) {
 template <int QB>
 static int launch_attention(rag_ctx* h, rag_ce_model* m, int P, int L, const ce_planes& pp, hipStream_t st) {
     const int lds = L * 256;                                           // K hi | K lo | V hi | V lo fragment planes
-    static int attr_lds = 0;
+    int& attr_lds = h->attr_ce_attn_lds[QB];
     if (lds > attr_lds) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_attention_kernel<QB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -737,11 +744,10 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     const int H = m->cfg.hidden, F = m->cfg.ffn;
     const int64_t M = (int64_t)P * L;
     const int64_t Mp = round_up((int64_t)m->ws_pairs * L, CE_BN);      // plane strides follow the ALLOCATED size
-    const int64_t Mt = round_up(M, CE_BN);                            // token tiles actually computed
     const ce_planes pp = planes_for(m, Mp);
     const int per = H / 64;
     const float eps = (float)m->cfg.ln_eps;
-    static bool attr = false;
+    bool& attr = h->attr_ce_gemm;
     const size_t lds = CE_GEMM_LDS;
     if (!attr) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_kernel<EPI_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -763,27 +769,26 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     hipLaunchKernelGGL(ce_pack_rows_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, st, m->pair_off, P, L, Mp, m->row_pair);
     CE_PER_DISPATCH(EMB)
     const dim3 blk(512);
-    static const unsigned n_cu = [] { int d = 0, n = 0; hipGetDevice(&d); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return (unsigned)(n > 0 ? n : 256); }();
-    const unsigned mt = (unsigned)(Mt / CE_BN);
+    static const unsigned n_cu = [] { int d = 0, n = 0; hipGetDevice(&d); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return (unsigned)(n >= 8 ? n / 8 * 8 : 256); }();
     const half_t* nullh = nullptr;
     for (int l = 0; l < m->cfg.layers; ++l) {
         auto& ly = m->layers[l];
-        hipLaunchKernelGGL(ce_gemm_kernel<EPI_QKV>, dim3(std::min<unsigned>(n_cu, 3 * H / CE_BM * mt)), blk, lds, st, ly.wqkv, (size_t)3 * H * H, m->x16, pp.x,
+        hipLaunchKernelGGL(ce_gemm_kernel<EPI_QKV>, dim3(n_cu), blk, lds, st, ly.wqkv, (size_t)3 * H * H, m->x16, pp.x,
                            3 * H, H, ly.bqkv, (const float*)nullptr, (float*)nullptr, m->q16, pp.q, m->kf16, m->vf16, pp.kv, H,
                            m->cfg.heads, m->m_packed, m->row_pair, m->pair_off);
         {
             const int rc = L == 32 ? launch_attention<1>(h, m, P, L, pp, st) : launch_attention<2>(h, m, P, L, pp, st);
             if (rc != RAG_OK) return rc;
         }
-        hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(std::min<unsigned>(n_cu, H / CE_BM * mt)), blk, lds, st, ly.wo, (size_t)H * H, m->ctx16, pp.ctx, H, H,
+        hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(n_cu), blk, lds, st, ly.wo, (size_t)H * H, m->ctx16, pp.ctx, H, H,
                            ly.bo, m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
                            m->row_pair, m->pair_off);
 #define LN1(PER) launch_ln<PER>(m, m->y32, ly.ln1_g, ly.ln1_b, M, pp.x, st)
         CE_PER_DISPATCH(LN1)
-        hipLaunchKernelGGL(ce_gemm_kernel<EPI_GELU>, dim3(std::min<unsigned>(n_cu, F / CE_BM * mt)), blk, lds, st, ly.w1, (size_t)F * H, m->x16, pp.x, F, H,
+        hipLaunchKernelGGL(ce_gemm_kernel<EPI_GELU>, dim3(n_cu), blk, lds, st, ly.w1, (size_t)F * H, m->x16, pp.x, F, H,
                            ly.b1, (const float*)nullptr, (float*)nullptr, m->h16, pp.h, (half_t*)nullptr, (half_t*)nullptr, (size_t)0,
                            H, m->cfg.heads, m->m_packed, m->row_pair, m->pair_off);
-        hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(std::min<unsigned>(n_cu, H / CE_BM * mt)), blk, lds, st, ly.w2, (size_t)H * F, m->h16, pp.h, H, F,
+        hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(n_cu), blk, lds, st, ly.w2, (size_t)H * F, m->h16, pp.h, H, F,
                            ly.b2, m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
                            m->row_pair, m->pair_off);
 #define LN2(PER) launch_ln<PER>(m, m->y32, ly.ln2_g, ly.ln2_b, M, pp.x, st)

@@ -790,7 +790,7 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
                        h->dim_pad, (int*)nullptr);
     hipLaunchKernelGGL(search_init_kernel, dim3((qpad + 255) / 256), dim3(256), 0, st, tau, h->bound, h->cnt, h->stats, qpad);
 
-    static bool attr_set = false;
+    bool& attr_set = h->attr_dense;
     if (!attr_set) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<true, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES));
