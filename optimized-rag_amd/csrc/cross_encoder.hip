@@ -228,6 +228,8 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
         // epilogue: acc[i][j][r] = C^T[n = nb + i*16 + fq*4 + r][m = mb + j*16 + fr]. Each wave transposes its 64 x 64 tile,
         // 16 tokens (32 for V) at a time, through its 6 KiB of the free stage so that every global store / residual load
         // covers whole 128 B lines of the row-major outputs (or one whole 1 KiB MFMA fragment tile for K and V).
+        // outputs are streamed with non-temporal stores: they are read again only by a later kernel (GBs later), and as
+        // ordinary stores they pushed the shared token tile and the weights out of the XCD's 4 MiB L2
         char* wl = smem + ((sbase + nt + 2) % 3) * CE_STAGE_BYTES + wid * CE_EPI_WAVE_BYTES;
         if (EPI == EPI_RESID) {
 #pragma unroll
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
                     const float4 v = *reinterpret_cast<const float4*>(wl + row * 272 + cc * 16);
                     const size_t g = (size_t)(mb + j * 16 + row) * N + nb + cc * 4;
                     const float4 rv = *reinterpret_cast<const float4*>(resid + g);
-                    *reinterpret_cast<float4*>(out32 + g) = make_float4(v.x + rv.x, v.y + rv.y, v.z + rv.z, v.w + rv.w);
+                    __builtin_nontemporal_store((f32x4){v.x + rv.x, v.y + rv.y, v.z + rv.z, v.w + rv.w}, reinterpret_cast<f32x4*>(out32 + g));
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -268,8 +270,8 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
                         const half8 hi = *reinterpret_cast<const half8*>(wl + row * 144 + cc * 16);
                         const half8 lo = *reinterpret_cast<const half8*>(wl + CE_EPI_PLANE16 + row * 144 + cc * 16);
                         half_t* o = out16 + (size_t)(mb + j * 16 + row) * ldo + nb + cc * 8;
-                        *reinterpret_cast<half8*>(o) = hi;
-                        *reinterpret_cast<half8*>(o + out_plane) = lo;
+                        __builtin_nontemporal_store(hi, reinterpret_cast<half8*>(o));
+                        __builtin_nontemporal_store(lo, reinterpret_cast<half8*>(o + out_plane));
                     }
                 } else {
                     // K features -> kf16[pair rows][head][key tile][lane = fq*16 + key%16][8 dims fq*8..]: the MFMA A-fragment
@@ -284,8 +286,8 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
                             const half8 hi = *reinterpret_cast<const half8*>(wl + fr * 144 + (hl * 4 + fq) * 16);
                             const half8 lo = *reinterpret_cast<const half8*>(wl + CE_EPI_PLANE16 + fr * 144 + (hl * 4 + fq) * 16);
                             half_t* o = kf16 + ((size_t)po * heads + (size_t)(head0 + hl) * Lp) * 32 + ((size_t)t16 * 64 + lane) * 8;
-                            *reinterpret_cast<half8*>(o) = hi;
-                            *reinterpret_cast<half8*>(o + kv_plane) = lo;
+                            __builtin_nontemporal_store(hi, reinterpret_cast<half8*>(o));
+                            __builtin_nontemporal_store(lo, reinterpret_cast<half8*>(o + kv_plane));
                         }
                     }
                 }
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
                             const half4 h0 = *reinterpret_cast<const half4*>(rowp), h1 = *reinterpret_cast<const half4*>(rowp + 32);
                             const half8 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                             half_t* o = vf16 + ((size_t)po * heads + (size_t)(head0 + hl) * Lp) * 32 + (((size_t)kb * 2 + dh) * 64 + lane) * 8;
-                            *reinterpret_cast<half8*>(o + (pl ? kv_plane : 0)) = hv;
+                            __builtin_nontemporal_store(hv, reinterpret_cast<half8*>(o + (pl ? kv_plane : 0)));
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
