@@ -15,6 +15,8 @@
 //            Python's stable sort), then a per-query merge of the n_ranges*k partials.
 #include "common.h"
 
+typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));          // posting segments start at any posting
+typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
 #define BM_RANGE 16384
 #define BM_THREADS 1024
 #define BM_SEG (BM_RANGE / BM_THREADS)      // 16 contiguous docs per thread
@@ -43,9 +45,16 @@ struct rag_bm25_index {
 
 __global__ void bm25_weights_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ doc,
                                     const int32_t* __restrict__ tf, const int32_t* __restrict__ doc_len, int64_t nnz,
-                                    double avgdl, double k1, double b, double* __restrict__ w) {
+                                    double avgdl, double k1, double b, const double* __restrict__ idf, int64_t n_terms,
+                                    double* __restrict__ w) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nnz) return;
+    // term of posting p: last t with indptr[t] <= p
+    int64_t lo = 0, hi = n_terms;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (indptr[mid] <= p) lo = mid; else hi = mid;
+    }
     const double f = (double)tf[p];
     const double dl = (double)doc_len[doc[p]];
     // q_freq * (k1 + 1) / (q_freq + k1 * (1 - b + b * doc_len / avgdl))   -- same association as rank-bm25
@@ -53,7 +62,9 @@ __global__ void bm25_weights_kernel(const int64_t* __restrict__ indptr, const in
     const double t1 = (b * dl) / avgdl;
     const double t2 = (1.0 - b) + t1;
     const double den = f + k1 * t2;
-    w[p] = num / den;
+    // the impact is stored already multiplied by the term's idf: `idf * (...)` is the product rank-bm25 adds to the score, so
+    // the scoring loop is a pure load + add (one float64 multiply and one LDS lookup fewer per posting)
+    w[p] = idf[lo] * (num / den);
 }
 
 __device__ __forceinline__ int64_t lower_bound_doc(const int32_t* __restrict__ doc, int64_t lo, int64_t hi, int target) {
@@ -119,28 +130,72 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
             m_n[tid] = f == 0.0 ? 0 : n;                     // (idf or 0) * x == 0: adds nothing
         }
         __syncthreads();
-        for (int ti = 0; ti < nb; ++ti) {
-            const int n = m_n[ti];
-            if (n == 0) continue;
-            const double f = m_idf[ti];
-            const int64_t a = m_a[ti];
-            // docs are unique inside one posting list: exactly one add per accumulator per token, so a no-return LDS
-            // atomic (ds_add_f64) gives the same float64 result as load-add-store without the dependent round trip
-            const int32_t* dp = doc + a;
-            const double* wp = w + a;
-            int p = tid;
-            for (; p + 3 * BM_THREADS < n; p += 4 * BM_THREADS) {        // 4 independent loads in flight per thread
-                const int d0 = dp[p], d1 = dp[p + BM_THREADS], d2 = dp[p + 2 * BM_THREADS], d3 = dp[p + 3 * BM_THREADS];
-                const double w0 = wp[p], w1 = wp[p + BM_THREADS], w2 = wp[p + 2 * BM_THREADS], w3 = wp[p + 3 * BM_THREADS];
-                __hip_atomic_fetch_add(&sc[SC_IDX(d0 - (int)base)], f * w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&sc[SC_IDX(d1 - (int)base)], f * w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&sc[SC_IDX(d2 - (int)base)], f * w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&sc[SC_IDX(d3 - (int)base)], f * w3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // Docs are unique inside one posting list: exactly one add per accumulator per token, so a no-return LDS atomic
+        // (ds_add_f64) gives the same float64 result as load-add-store; tokens are separated by a barrier so that the
+        // per-document summation order is the token order (bit-identical to numpy). A (token, range) segment is only a few
+        // postings per thread, so the loop is bound by one global round trip per token unless the NEXT chunk (4
+        // consecutive postings per thread = 4096 per block, possibly of the next token) is already in flight while the
+        // current one is added: two register sets ping-pong, loads are unconditional (the arrays carry 4 postings of
+        // padding) so the compiler keeps counted vmcnt waits, and the token barrier is a raw s_barrier behind
+        // lgkmcnt(0) — __syncthreads would drain vmcnt and the prefetch with it.
+        int ti = 0, c = 0;
+        while (ti < nb && m_n[ti] == 0) ++ti;
+        if (ti < nb) {
+            int4u da, db;
+            double2u wa0, wa1, wb0, wb1;
+#define BM_LOAD(TI, C, D, W0, W1)                                                                  \
+            {                                                                                      \
+                const int64_t o_ = m_a[TI] + min((C) * 4 * BM_THREADS + tid * 4, max(m_n[TI] - 1, 0));   \
+                D = *reinterpret_cast<const int4u*>(doc + o_);                                     \
+                W0 = *reinterpret_cast<const double2u*>(w + o_);                                   \
+                W1 = *reinterpret_cast<const double2u*>(w + o_ + 2);                               \
             }
-            for (; p < n; p += BM_THREADS)
-                __hip_atomic_fetch_add(&sc[SC_IDX(dp[p] - (int)base)], f * wp[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __syncthreads();                                 // token order = per-document summation order
+#define BM_ADD(TI, C, D, W0, W1)                                                                   \
+            {                                                                                      \
+                const int p_ = (C) * 4 * BM_THREADS + tid * 4, n_ = m_n[TI];                       \
+                if (p_ + 3 < n_) {                                                                 \
+                    __hip_atomic_fetch_add(&sc[SC_IDX(D[0] - (int)base)], W0[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
+                    __hip_atomic_fetch_add(&sc[SC_IDX(D[1] - (int)base)], W0[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
+                    __hip_atomic_fetch_add(&sc[SC_IDX(D[2] - (int)base)], W1[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
+                    __hip_atomic_fetch_add(&sc[SC_IDX(D[3] - (int)base)], W1[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
+                } else if (p_ < n_) {                  /* the one thread that holds the end of the segment */                      \
+                    __hip_atomic_fetch_add(&sc[SC_IDX(D[0] - (int)base)], W0[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
+                    if (p_ + 1 < n_) __hip_atomic_fetch_add(&sc[SC_IDX(D[1] - (int)base)], W0[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    if (p_ + 2 < n_) __hip_atomic_fetch_add(&sc[SC_IDX(D[2] - (int)base)], W1[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                }                                                                                  \
+            }
+#define BM_NEXT(TI, C, NTI, NC)                                                                    \
+            NTI = TI; NC = C + 1;                                                                  \
+            if (NC * 4 * BM_THREADS >= m_n[TI]) {                                                  \
+                NC = 0;                                                                            \
+                ++NTI;                                                                             \
+                while (NTI < nb && m_n[NTI] == 0) ++NTI;                                           \
+            }
+#define BM_TOKEN_BARRIER asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+            BM_LOAD(ti, c, da, wa0, wa1)
+            for (;;) {
+                int nti, nc;
+                BM_NEXT(ti, c, nti, nc)
+                const bool more1 = nti < nb;
+                { const int lt = more1 ? nti : ti, lc = more1 ? nc : c; BM_LOAD(lt, lc, db, wb0, wb1) }
+                BM_ADD(ti, c, da, wa0, wa1)
+                if (nti != ti) BM_TOKEN_BARRIER;
+                if (!more1) break;
+                ti = nti; c = nc;
+                BM_NEXT(ti, c, nti, nc)
+                const bool more2 = nti < nb;
+                { const int lt = more2 ? nti : ti, lc = more2 ? nc : c; BM_LOAD(lt, lc, da, wa0, wa1) }
+                BM_ADD(ti, c, db, wb0, wb1)
+                if (nti != ti) BM_TOKEN_BARRIER;
+                if (!more2) break;
+                ti = nti; c = nc;
+            }
+#undef BM_LOAD
+#undef BM_ADD
+#undef BM_NEXT
+#undef BM_TOKEN_BARRIER
         }
+        __syncthreads();                                     // adds done before the next batch's metadata / the select
     }
     if (mode == 1) {
         for (int i = tid; i < lim; i += BM_THREADS) dense_out[(size_t)q * n_docs + base + i] = sc[SC_IDX(i)];
@@ -420,8 +475,11 @@ int bm25_load_host(rag_ctx* h, const int64_t* indptr, const int32_t* doc, const 
     hipStream_t st = h->stream;
     int32_t *tfd = nullptr, *dld = nullptr;
     HIP_TRY(h, hipMalloc(&ix->indptr, (size_t)(n_terms + 1) * sizeof(int64_t)));
-    HIP_TRY(h, hipMalloc(&ix->doc, std::max<size_t>(1, nnz) * sizeof(int32_t)));
-    HIP_TRY(h, hipMalloc(&ix->w, std::max<size_t>(1, nnz) * sizeof(double)));
+    // + 4 postings of padding: the scoring kernel reads 4 consecutive postings per thread without a bounds branch
+    HIP_TRY(h, hipMalloc(&ix->doc, (size_t)(nnz + 4) * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc(&ix->w, (size_t)(nnz + 4) * sizeof(double)));
+    HIP_TRY(h, hipMemsetAsync(ix->doc + nnz, 0, 4 * sizeof(int32_t), h->stream));
+    HIP_TRY(h, hipMemsetAsync(ix->w + nnz, 0, 4 * sizeof(double), h->stream));
     HIP_TRY(h, hipMalloc(&ix->idf, std::max<size_t>(1, n_terms) * sizeof(double)));
     HIP_TRY(h, hipMalloc(&tfd, std::max<size_t>(1, nnz) * sizeof(int32_t)));
     HIP_TRY(h, hipMalloc(&dld, (size_t)n_docs * sizeof(int32_t)));
@@ -434,7 +492,7 @@ int bm25_load_host(rag_ctx* h, const int64_t* indptr, const int32_t* doc, const 
     HIP_TRY(h, hipMemcpyAsync(dld, doc_len, (size_t)n_docs * sizeof(int32_t), hipMemcpyHostToDevice, st));
     if (nnz) {
         hipLaunchKernelGGL(bm25_weights_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, ix->indptr, ix->doc, tfd,
-                           dld, nnz, avgdl, k1, b, ix->w);
+                           dld, nnz, avgdl, k1, b, ix->idf, n_terms, ix->w);
         HIP_TRY(h, hipGetLastError());
     }
     ix->n_ranges = (int)((n_docs + BM_RANGE - 1) / BM_RANGE);
