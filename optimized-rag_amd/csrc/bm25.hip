@@ -104,6 +104,9 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
     const int lane = tid & 63, wv = tid >> 6;
     const int64_t base = (int64_t)r * BM_RANGE;
     const int lim = (int)min((int64_t)BM_RANGE, n_docs - base);
+    // the query's threshold (second-stage launches) is fetched up front: at the compaction step it would be an exposed
+    // global round trip for every workgroup
+    const uint64_t tk = tau_key != nullptr ? tau_key[q] : 0ull;
     for (int i = tid; i < BM_SC_DOUBLES; i += BM_THREADS) sc[i] = 0.0;
     __syncthreads();
     // per-token metadata (idf, posting sub-range of this doc range) is fetched for up to 64 tokens IN PARALLEL into
@@ -220,7 +223,6 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
     // 8-pass radix select — 26 us per block, three quarters of this kernel's time when run for every range — is
     // skipped. More than k survivors (possible, e.g. a tie plateau) falls through to the exact select below.
     if (tau_key != nullptr) {
-        const uint64_t tk = tau_key[q];
         int n_in = 0;
 #pragma unroll
         for (int j = 0; j < BM_SEG; ++j) n_in += (seg0 + j) < lim && keys[j] >= tk;
