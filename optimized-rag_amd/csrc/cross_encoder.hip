@@ -6,20 +6,20 @@
 // 6 layers (measured), so every MFMA operand is a SPLIT fp16 pair x = hi + lo (hi = fp16(x), lo = fp16(x - hi),
 // ~22 significand bits) stored as two planes, and every product is 3 MFMAs: hi*hi + hi*lo + lo*hi with fp32
 // accumulation (3/16 of the f32-MFMA cost for the same accuracy class). Residual stream / LayerNorm / softmax /
-// GELU (exact erf) / pooler are fp32. Layout: tokens are rows ([M = pairs*L][feature], feature contiguous), weights are
-// nn.Linear [out][in] = K-contiguous, so every GEMM is the "both operands K-contiguous" form MFMA wants.
+// GELU (erf form, A&S 7.1.26) / pooler are fp32. Layout: tokens are rows, PACKED per pair (pair p owns len_p rounded up
+// to 32 rows, offsets computed on the device), feature contiguous; weights are nn.Linear [out][in] = K-contiguous, so
+// every GEMM is the "both operands K-contiguous" form MFMA wants.
 //
 // Kernels
-//   ce_embed_ln        word+pos+type gather -> LayerNorm -> x32 (fp32 residual) + x16 (fp16 GEMM operand)
-//   ce_gemm<EPI>       128(out features) x 128(tokens) tile, BK=64, 4 waves (2x2 of 64x64), LDS-DMA double buffer,
-//                      source-swizzled conflict-free ds_read_b128 (same scheme as dense.hip). Output features sit
-//                      on the MFMA ROW so a lane owns 4 consecutive features of one token: bias is 4 registers and
-//                      stores are 8/16-byte. Epilogues: QKV (bias, Q/K token-major, V written TRANSPOSED
-//                      [pair][head][d][L] so P.V's B operand is a contiguous 16-byte load), bias+erf-GELU -> fp16,
-//                      bias+residual -> fp32.
-//   ce_attention<NT>   one wave per (pair, head, 16-query block): S = Q.K^T is ONE mfma_16x16x32 per 16 keys
-//                      (d_head = 32 = MFMA K), softmax in registers (row = 16 lanes, xor-shuffle reduce), P -> LDS
-//                      as fp16 -> A operand of P.V; key padding masked to -inf.
+//   ce_pack_scan/rows  lens -> pair_off / row_pair / m_packed (the packed row layout of the chunk)
+//   ce_embed_ln        word+pos+type gather -> LayerNorm -> x32 (fp32 residual) + x16 (split-fp16 GEMM operand)
+//   ce_gemm<EPI>       persistent, XCD-aware; 128 (out features) x 256 (tokens) tiles, BK = 32, three LDS stages by
+//                      LDS-DMA with a continuous stream across tiles, 8 staggered waves (2 x 4 of 64 x 64), source-swizzled
+//                      conflict-free ds_read_b128. Output features sit on the MFMA ROW (bias = 4 registers per lane).
+//                      Epilogues through the free ring stage, non-temporal stores: QKV (Q token-major; K and V in MFMA
+//                      FRAGMENT order per (pair, head)), bias + GELU -> split fp16, bias + residual -> fp32.
+//   ce_attention<QB>   one workgroup per (head, pair); K/V fragments by LDS-DMA, S computed transposed so that P stays in
+//                      registers as the next MFMA's operand, online softmax over 32-key blocks, keys past len skipped.
 //   ce_layernorm       one wave per token (384 = 6/lane), fp32 statistics, eps from config
 //   ce_pool_classify   tanh(Wp.x_cls + bp) -> wc.pooled + bc, fp32
 #include "common.h"
