@@ -1,18 +1,21 @@
 // K4: BM25 over CSR postings. Replaces BM25Okapi(tokenized_corpus).get_scores(tokenized_query) and the /max
 // normalisation of /root/reference/rag/retrieval.py:324-347 (rank-bm25 0.2.2 semantics, float64).
 //
-// HBM-bound integer/gather work, not a GEMM:
-//   load   : per-posting weight w = tf*(k1+1) / (tf + k1*(1 - b + b*dl/avgdl)) precomputed once in float64 with
-//            rank-bm25's operation order -> postings are (doc int32, w float64): 12 B each, no doc_len gather later.
-//            A per-term range table (first posting of each 16384-doc range, built once on the GPU) replaces the
+// Integer/gather work, not a GEMM (89 % of the posting reads hit L2: frequent terms are shared by the batch's queries):
+//   load   : per-posting impact w = idf * tf*(k1+1) / (tf + k1*(1 - b + b*dl/avgdl)) precomputed once in float64 with
+//            rank-bm25's operation order -> postings are (doc int32, w float64): 12 B each, no doc_len gather, no multiply
+//            later. A per-term range table (first posting of each 16384-doc range, built once on the GPU) replaces the
 //            two 20-step dependent binary searches per (block, token) that dominated the first version (36 ms/batch).
-//   score  : one workgroup per (query, 16384-doc range). The range's float64 accumulators live in LDS (128 KiB);
-//            for each query token IN ORDER the block binary-searches the term's posting list for its doc range and
-//            adds idf*w (docs are unique inside one posting list -> no atomics, and per-document summation order
-//            is the query-token order, exactly as `score += ...` in get_scores -> bit-identical float64).
+//   score  : one workgroup per (query, 16384-doc range). The range's float64 accumulators live in LDS (132 KiB padded);
+//            for each query token IN ORDER the block adds the term's impacts of this doc range (docs are unique inside one
+//            posting list -> one add per accumulator per token, and per-document summation order is the query-token
+//            order, exactly as `score += ...` in get_scores -> bit-identical float64). 4 consecutive postings per thread
+//            per trip, the next trip in flight across the token barrier.
 //            Algorithmic traffic per query = sum over tokens of df*12 B; accumulators never touch HBM.
-//   select : per-range exact top-k by 8-pass radix select on order-preserving keys (ties -> lower doc id, i.e.
-//            Python's stable sort), then a per-query merge of the n_ranges*k partials.
+//   select : STAGED. The first BM_FIRST_RANGES ranges get an exact per-range top-k (8-pass radix select on order-
+//            preserving keys, ties -> lower doc id, i.e. Python's stable sort); bm25_tau_kernel takes the k-th best key
+//            over them (a lower bound of the global k-th); every other range only compacts its keys >= tau (exact select
+//            as the fallback when more than k survive). Then a per-query merge of the partial lists.
 #include "common.h"
 
 typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));          // posting segments start at any posting
