@@ -213,6 +213,15 @@ int rag_retrieve_rerank_dev(rag_handle_t h, const float* q_emb_dev, const int32_
                             int rrf_k, int tenant, int mode, int cls_id, int sep_id, int L_pair, int64_t* ids_out_dev,
                             double* scores_out_dev, float* logits_out_dev, int64_t* cand_out_dev, void* stream);
 
+/* The pipeline's two small kernels on their own (row-sharded composition): pair assembly from GLOBAL
+ * candidate doc ids against a replicated token store whose first row has id token_id_base; and sigmoid + stable top-k of
+ * the logits of a [Q][pool] candidate table (rag/reranker.py:359,372-376). */
+int rag_ce_build_pairs_dev(rag_handle_t h, const int32_t* q_tok_dev, const int32_t* q_len_dev, int Lq, const int64_t* cand_dev,
+                           int n_queries, int pool, int64_t token_id_base, int L_pair, int cls_id, int sep_id,
+                           int32_t* ids_out_dev, int32_t* tt_out_dev, int32_t* lens_out_dev, void* stream);
+int rag_rerank_topk_dev(rag_handle_t h, const float* logits_dev, const int64_t* cand_dev, int n_queries, int pool, int k,
+                        int64_t* ids_out_dev, double* scores_out_dev, float* logits_out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,8 @@ _SIGS = {
     "rag_tokens_load_host": ([_P, _P, _P, C.c_int64, C.c_int], C.c_int),
     "rag_retrieve_rerank_dev": ([_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, _P, _P, _P, _P, _P], C.c_int),
+    "rag_ce_build_pairs_dev": ([_P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
+    "rag_rerank_topk_dev": ([_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
     "rag_ce_score_dev": ([_P, _P, _P, _P, C.c_int, C.c_int, _P, _P], C.c_int),
 }
 
@@ -468,6 +470,28 @@ class RagEngine:
             C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr()), C.c_void_p(lg.data_ptr()), C.c_void_p(cand.data_ptr()), st),
             "rag_retrieve_rerank_dev")
         return ids, sc, lg, cand
+
+    def ce_build_pairs_dev(self, q_tok, q_len, cand, ids_out, tt_out, lens_out, token_id_base=0, cls_id=101, sep_id=102, stream=None):
+        """[CLS] query [SEP] passage [SEP] rows for a [Q, pool] table of GLOBAL candidate ids (-1 = empty) against the
+        loaded token store; ids_out / tt_out are [Q*pool, L_pair] int32, lens_out [Q*pool]."""
+        import torch
+        Q, pool = cand.shape
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        self._check(self.lib.rag_ce_build_pairs_dev(self.h, C.c_void_p(q_tok.data_ptr()), C.c_void_p(q_len.data_ptr()), int(q_tok.shape[1]),
+                                                    C.c_void_p(cand.data_ptr()), Q, pool, int(token_id_base), int(ids_out.shape[1]),
+                                                    int(cls_id), int(sep_id), C.c_void_p(ids_out.data_ptr()),
+                                                    C.c_void_p(tt_out.data_ptr()), C.c_void_p(lens_out.data_ptr()), st),
+                    "rag_ce_build_pairs_dev")
+
+    def rerank_topk_dev(self, logits, cand, ids_out, scores_out, logits_out, stream=None):
+        """sigmoid + stable (score desc, candidate order) top-k of logits [Q*pool] over the candidate table [Q, pool]."""
+        import torch
+        Q, pool = cand.shape
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        self._check(self.lib.rag_rerank_topk_dev(self.h, C.c_void_p(logits.data_ptr()), C.c_void_p(cand.data_ptr()), Q, pool,
+                                                 int(ids_out.shape[1]), C.c_void_p(ids_out.data_ptr()),
+                                                 C.c_void_p(scores_out.data_ptr()), C.c_void_p(logits_out.data_ptr()), st),
+                    "rag_rerank_topk_dev")
 
     def ce_score_dev(self, input_ids, token_type_ids, lens, logits_out, stream=None):
         """int32 CUDA tensors [P, L], [P, L], [P] -> float32 logits_out [P]; asynchronous on `stream`."""

@@ -32,6 +32,11 @@ int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* l
              hipStream_t st, bool host_ptrs);
 void ce_free(rag_ctx* h);
 void pipeline_free(rag_ctx* h);
+int ce_build_pairs_dev(rag_ctx* h, const int32_t* q_tok_dev, const int32_t* q_len_dev, int Lq, const int64_t* cand_dev, int Q, int pool,
+                       int64_t token_id_base, int L_pair, int cls_id, int sep_id, int32_t* ids_out, int32_t* tt_out, int32_t* lens_out,
+                       hipStream_t st);
+int rerank_topk_dev(rag_ctx* h, const float* logits_dev, const int64_t* cand_dev, int Q, int pool, int k, int64_t* ids_out, double* scores_out,
+                    float* logits_out, hipStream_t st);
 int tokens_load_host(rag_ctx* h, const int32_t* tokens, const int32_t* lens, int64_t n_rows, int L);
 int retrieve_rerank_dev(rag_ctx* h, const float* q_emb_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev,
                         const int32_t* q_tok_dev, const int32_t* q_len_dev, int Lq, int Q, int pool, int k, int rrf_k, int tenant,
@@ -485,6 +490,22 @@ int rag_retrieve_rerank_dev(rag_handle_t h, const float* q_emb_dev, const int32_
     return retrieve_rerank_dev(h, q_emb_dev, term_ptr_dev, terms_dev, q_tok_dev, q_len_dev, Lq, Q, pool, k, rrf_k, tenant, mode,
                                cls_id, sep_id, L_pair, ids_out_dev, scores_out_dev, logits_out_dev, cand_out_dev,
                                (hipStream_t)stream);
+}
+
+int rag_ce_build_pairs_dev(rag_handle_t h, const int32_t* q_tok_dev, const int32_t* q_len_dev, int Lq, const int64_t* cand_dev, int Q,
+                           int pool, int64_t token_id_base, int L_pair, int cls_id, int sep_id, int32_t* ids_out_dev,
+                           int32_t* tt_out_dev, int32_t* lens_out_dev, void* stream) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return ce_build_pairs_dev(h, q_tok_dev, q_len_dev, Lq, cand_dev, Q, pool, token_id_base, L_pair, cls_id, sep_id, ids_out_dev,
+                              tt_out_dev, lens_out_dev, (hipStream_t)stream);
+}
+
+int rag_rerank_topk_dev(rag_handle_t h, const float* logits_dev, const int64_t* cand_dev, int Q, int pool, int k, int64_t* ids_out_dev,
+                        double* scores_out_dev, float* logits_out_dev, void* stream) {
+    if (!h) return RAG_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return rerank_topk_dev(h, logits_dev, cand_dev, Q, pool, k, ids_out_dev, scores_out_dev, logits_out_dev, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -98,6 +98,30 @@ __global__ __launch_bounds__(256) void rerank_topk_kernel(const float* __restric
     }
 }
 
+// The two pipeline kernels on their own, for the row-sharded composition (sharded.py::ShardedPipeline): candidates are
+// GLOBAL doc ids from the merged lists; the token store is replicated (token_id_base = id of its first row).
+int ce_build_pairs_dev(rag_ctx* h, const int32_t* q_tok_dev, const int32_t* q_len_dev, int Lq, const int64_t* cand_dev, int Q, int pool,
+                       int64_t token_id_base, int L_pair, int cls_id, int sep_id, int32_t* ids_out, int32_t* tt_out, int32_t* lens_out,
+                       hipStream_t st) {
+    ARG_CHECK(h, h->tok != nullptr, "build_pairs: no token store loaded");
+    ARG_CHECK(h, Q > 0 && pool > 0 && Lq > 0 && L_pair >= 8 && L_pair <= 512 && q_tok_dev && q_len_dev && cand_dev && ids_out && tt_out && lens_out,
+              "build_pairs: bad arguments");
+    const size_t P = (size_t)Q * pool;
+    hipLaunchKernelGGL(ce_build_pairs_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, q_tok_dev, q_len_dev, Lq, cand_dev, token_id_base,
+                       h->tok, h->tok_len, h->tok_L, h->tok_rows, (int)P, pool, L_pair, cls_id, sep_id, ids_out, tt_out, lens_out);
+    HIP_TRY(h, hipGetLastError());
+    return RAG_OK;
+}
+
+int rerank_topk_dev(rag_ctx* h, const float* logits_dev, const int64_t* cand_dev, int Q, int pool, int k, int64_t* ids_out, double* scores_out,
+                    float* logits_out, hipStream_t st) {
+    ARG_CHECK(h, Q > 0 && pool > 0 && pool <= RAG_MAX_K && k > 0 && k <= pool && logits_dev && cand_dev && ids_out && scores_out && logits_out,
+              "rerank_topk: 0 < k <= pool <= 256");
+    hipLaunchKernelGGL(rerank_topk_kernel, dim3(Q), dim3(256), 0, st, logits_dev, cand_dev, pool, k, ids_out, scores_out, logits_out);
+    HIP_TRY(h, hipGetLastError());
+    return RAG_OK;
+}
+
 int retrieve_rerank_dev(rag_ctx* h, const float* q_emb_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev,
                         const int32_t* q_tok_dev, const int32_t* q_len_dev, int Lq, int Q, int pool, int k, int rrf_k, int tenant,
                         int mode, int cls_id, int sep_id, int L_pair, int64_t* ids_out, double* scores_out, float* logits_out,

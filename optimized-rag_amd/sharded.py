@@ -161,3 +161,34 @@ class ShardedReranker:
         out = torch.empty((self.world, per), dtype=torch.float32, device=input_ids.device)
         _gather(out, mine, self.group)
         return out.reshape(-1)[:P]
+
+
+class ShardedPipeline:
+    """BASELINE.json configs[4]: row-sharded hybrid retrieval + cross-encoder rerank. Every rank holds its row shard
+    (embeddings + doc-partitioned postings), the cross-encoder weights and a REPLICATED passage token store (it fits:
+    100M x 256 tokens x 2 B = 51 GB of 288 GB; loaded with ids starting at token_id_base). Three small collectives per
+    batch: the candidate lists (ShardedHybridIndex), nothing for the pair assembly (every rank builds all pairs from the
+    merged global ids), the logits (ShardedReranker). Every rank ends with the same top-k."""
+
+    def __init__(self, engine, rank=None, world=None, group=None, token_id_base=0):
+        self.engine = engine
+        self.index = ShardedHybridIndex(engine, rank=rank, world=world, group=group)
+        self.reranker = ShardedReranker(engine, rank=rank, world=world, group=group)
+        self.token_id_base = token_id_base
+        self._bufs = {}
+
+    def retrieve_rerank(self, queries, term_ptr, terms, q_tok, q_len, pool, k, L_pair=256, rrf_k=60, cls_id=101, sep_id=102):
+        """Returns (ids [Q,k] int64, scores [Q,k] float64 = sigmoid(logit), logits [Q,k] float32, candidates [Q,pool])."""
+        Q, dev = queries.shape[0], queries.device
+        cand = self.index.search_hybrid(queries, term_ptr, terms, pool, pool, rrf_k=rrf_k)["keys"]
+        key = (Q, pool, k, L_pair, str(dev))
+        if key not in self._bufs:
+            P = Q * pool
+            self._bufs[key] = (torch.empty((P, L_pair), dtype=torch.int32, device=dev), torch.empty((P, L_pair), dtype=torch.int32, device=dev),
+                               torch.empty((P,), dtype=torch.int32, device=dev), torch.empty((Q, k), dtype=torch.int64, device=dev),
+                               torch.empty((Q, k), dtype=torch.float64, device=dev), torch.empty((Q, k), dtype=torch.float32, device=dev))
+        pid, ptt, plen, ids, sc, lg = self._bufs[key]
+        self.engine.ce_build_pairs_dev(q_tok, q_len, cand, pid, ptt, plen, token_id_base=self.token_id_base, cls_id=cls_id, sep_id=sep_id)
+        logits = self.reranker.score(pid, ptt, plen).contiguous()
+        self.engine.rerank_topk_dev(logits, cand, ids, sc, lg)
+        return ids, sc, lg, cand

@@ -90,3 +90,43 @@ def test_retrieve_rerank_matches_oracle_composition(hybrid):
             assert ids[qi].tolist() == want
         else:
             assert sorted(ids[qi].tolist()) == sorted(want) or set(ids[qi].tolist()) <= {int(c) + 1000 for c in ocand[qi]}
+
+
+def test_sharded_pipeline_world1_equals_one_call():
+    """ShardedPipeline (the configs[4] composition: sharded hybrid -> pair assembly -> pair-split rerank -> top-k) on a
+    single rank must reproduce rag_retrieve_rerank_dev bit for bit; the multi-rank exchanges are covered by
+    tests/test_sharded_gloo.py."""
+    import torch
+    from optimized_rag_amd import RagEngine
+    from optimized_rag_amd.bm25 import Bm25Postings
+    from optimized_rag_amd.cross_encoder import random_init_tensors
+    from optimized_rag_amd.sharded import ShardedPipeline
+    rng = np.random.default_rng(5)
+    N, D, Q, pool, k, Ld, Lq, L = 500, 1536, 4, 10, 5, 24, 6, 32
+    cfg = dict(vocab_size=3000, hidden=384, layers=2, heads=12, ffn=1536, max_pos=64, type_vocab=2, eps=1e-12)
+    emb = rng.standard_normal((N, D)).astype(np.float32)
+    q_emb = (emb[rng.integers(0, N, Q)] + 0.5 * rng.standard_normal((Q, D))).astype(np.float32)
+    tok = rng.integers(200, cfg["vocab_size"], (N, Ld)).astype(np.int32)
+    tok_len = rng.integers(3, Ld + 1, N).astype(np.int32)
+    q_tok = rng.integers(200, cfg["vocab_size"], (Q, Lq)).astype(np.int32)
+    q_len = rng.integers(2, Lq + 1, Q).astype(np.int32)
+    corpus = [" ".join(f"t{t}" for t in tok[i, :tok_len[i]] % 50) for i in range(N)]
+    queries = [" ".join(f"t{t}" for t in q_tok[i, :q_len[i]] % 50) for i in range(Q)]
+    eng = RagEngine(dim=D, device=0)
+    try:
+        pipe = ShardedPipeline(eng, rank=0, world=1)
+        post = Bm25Postings.from_corpus(corpus)
+        pipe.index.load_shard(emb, 0, post)
+        eng.tokens_load(tok, tok_len)
+        eng.ce_load(cfg, random_init_tensors(cfg, 3))
+        ptr, terms = post.encode_queries(queries)
+        t = lambda a: torch.from_numpy(a).cuda()
+        got = [x.cpu().numpy().copy() for x in pipe.retrieve_rerank(t(q_emb), t(ptr), t(terms), t(q_tok), t(q_len), pool, k, L_pair=L)]
+        eng.bm25_set_normalize(True)
+        ref = [x.cpu().numpy().copy() for x in eng.retrieve_rerank_dev(t(q_emb), t(q_tok), t(q_len), pool, k, term_ptr=t(ptr),
+                                                                       terms=t(terms), L_pair=L)]
+        torch.cuda.synchronize()
+    finally:
+        eng.close()
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)

@@ -83,6 +83,38 @@ class OracleEngine:
     def ce_score_dev(self, input_ids, token_type_ids, lens, logits_out, stream=None):
         logits_out.copy_(fake_logits(input_ids, token_type_ids, lens))
 
+    def tokens_load(self, tokens, lens):
+        self.tok, self.tok_len = np.asarray(tokens), np.asarray(lens)
+
+    def ce_build_pairs_dev(self, q_tok, q_len, cand, ids_out, tt_out, lens_out, token_id_base=0, cls_id=101, sep_id=102, stream=None):
+        Q, pool = cand.shape
+        L = ids_out.shape[1]
+        ids_out.zero_()
+        tt_out.zero_()
+        for q in range(Q):
+            ql = int(min(int(q_len[q]), q_tok.shape[1], L - 3))
+            for j in range(pool):
+                r = int(cand[q, j]) - token_id_base if int(cand[q, j]) >= 0 else -1
+                dl = 0 if r < 0 else int(min(self.tok_len[r], self.tok.shape[1], L - 3 - ql))
+                row = [cls_id] + q_tok[q, :ql].tolist() + [sep_id] + ([] if r < 0 else self.tok[r, :dl].tolist()) + [sep_id]
+                p = q * pool + j
+                ids_out[p, :len(row)] = torch.tensor(row, dtype=torch.int32)
+                tt_out[p, ql + 2:len(row)] = 1
+                lens_out[p] = len(row)
+
+    def rerank_topk_dev(self, logits, cand, ids_out, scores_out, logits_out, stream=None):
+        Q, pool = cand.shape
+        k = ids_out.shape[1]
+        for q in range(Q):
+            sc = [(O.sigmoid(float(logits[q * pool + j])), j) for j in range(pool) if int(cand[q, j]) >= 0]
+            order = sorted(sc, key=lambda x: -x[0])
+            for i in range(k):
+                if i < len(order):
+                    s_, j = order[i]
+                    ids_out[q, i], scores_out[q, i], logits_out[q, i] = int(cand[q, j]), s_, float(logits[q * pool + j])
+                else:
+                    ids_out[q, i], scores_out[q, i], logits_out[q, i] = -1, 0.0, 0.0
+
 
 def fake_logits(ids, tt, lens):
     """Any deterministic per-pair function: the reranker test checks the pair split / gather, not BERT."""
@@ -160,6 +192,35 @@ def _hybrid_worker(rank, world, port, ret):
         lens = torch.from_numpy(rng.integers(6, L + 1, P).astype(np.int32))
         got = ShardedReranker(OracleEngine(), rank=rank, world=world).score(ids, tt, lens)
         ok &= bool(torch.equal(got, fake_logits(ids, tt, lens)))
+        # the whole configs[4] composition: sharded hybrid candidates -> pairs from a replicated token store -> split rerank
+        from optimized_rag_amd.sharded import ShardedPipeline
+        Ld, Lq, Lp = 10, 4, 16
+        tok = rng.integers(100, 999, (N, Ld)).astype(np.int32)
+        tok_len = rng.integers(1, Ld + 1, N).astype(np.int32)
+        q_tok = torch.from_numpy(rng.integers(100, 999, (Q, Lq)).astype(np.int32))
+        q_len = torch.from_numpy(rng.integers(1, Lq + 1, Q).astype(np.int32))
+        eng2 = OracleEngine()
+        pipe = ShardedPipeline(eng2, rank=rank, world=world)
+        pipe.index.load_shard(emb[b:e], b, post.shard(b, e))
+        eng2.tokens_load(tok, tok_len)                                              # replicated store, ids from 0
+        ids_k, sc_k, lg_k, cand = pipe.retrieve_rerank(torch.from_numpy(q), torch.from_numpy(ptr), torch.from_numpy(terms), q_tok, q_len,
+                                                       pool, k, L_pair=Lp)
+        whole = OracleEngine()                                                     # expectation: the same steps unsharded
+        whole.tokens_load(tok, tok_len)
+        want_cand = torch.full((Q, pool), -1, dtype=torch.int64)
+        for qi in range(Q):
+            raw = obm.get_scores(O.tokenize(queries[qi]))
+            keys, _, _ = O.rrf_fuse([[int(r) for r in d_rows[qi]], [int(r) for r in O.stable_topk_desc(raw, pool)]], k=60, top_k=pool)
+            want_cand[qi, :len(keys)] = torch.tensor(keys)
+        pid = torch.zeros((Q * pool, Lp), dtype=torch.int32)
+        ptt = torch.zeros((Q * pool, Lp), dtype=torch.int32)
+        pln = torch.zeros((Q * pool,), dtype=torch.int32)
+        whole.ce_build_pairs_dev(q_tok, q_len, want_cand, pid, ptt, pln)
+        wi = torch.empty((Q, k), dtype=torch.int64)
+        ws = torch.empty((Q, k), dtype=torch.float64)
+        wl = torch.empty((Q, k), dtype=torch.float32)
+        whole.rerank_topk_dev(fake_logits(pid, ptt, pln), want_cand, wi, ws, wl)
+        ok &= bool(torch.equal(cand, want_cand) and torch.equal(ids_k, wi) and torch.equal(sc_k, ws) and torch.equal(lg_k, wl))
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
