@@ -11,7 +11,7 @@
 //                    with S~ >= tau[q] into a per-query candidate buffer.  Run as a few stages over
 //                    growing row ranges; after each stage `select` finds the k-th best score so far,
 //                    sets tau[q] = that - 2*eps and drops every key below it.
-//   rescore          float64 cosine of the surviving rows (~1.5 k per query) against the fp32 master rows
+//   rescore          float64 cosine of the surviving rows (~50 per query at k = 20) against the fp32 master rows
 //   finalize         order by (float64 cosine desc, row asc), write top-k. EXACTNESS IS STRUCTURAL: with
 //                    |S~ - S| <= eps, a row below tau cannot be in the exact top-k (proof at select_kernel), so the
 //                    survivors always contain it. Only two escapes exist:
