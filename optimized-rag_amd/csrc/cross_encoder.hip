@@ -48,6 +48,7 @@ struct rag_ce_model {
     // packed (variable-length) row layout of the current chunk: pair p owns rows [pair_off[p], pair_off[p+1]) where
     // pair_off[p+1] - pair_off[p] = len rounded up to 32; row_pair[m] = owning pair (-1 past the end); m_packed[0] = rows
     int32_t *pair_off = nullptr, *row_pair = nullptr, *m_packed = nullptr;
+    int32_t *sid = nullptr, *stt = nullptr;          // staging of one chunk's [pairs][L_in] token / type ids
     float* logits = nullptr;
 };
 
@@ -627,10 +628,11 @@ __global__ void ce_f32_split_kernel(const float* __restrict__ in, half_t* __rest
 // ------------------------------------------------------------------------------------------------
 static void ce_free_ws(rag_ce_model* m) {
     hipFree(m->x32); hipFree(m->y32); hipFree(m->x16); hipFree(m->q16); hipFree(m->kf16); hipFree(m->vf16); hipFree(m->ctx16);
-    hipFree(m->h16); hipFree(m->ids); hipFree(m->tt); hipFree(m->lens); hipFree(m->logits); hipFree(m->pair_off); hipFree(m->row_pair); hipFree(m->m_packed);
+    hipFree(m->h16); hipFree(m->ids); hipFree(m->tt); hipFree(m->lens); hipFree(m->logits); hipFree(m->pair_off); hipFree(m->row_pair); hipFree(m->m_packed); hipFree(m->sid); hipFree(m->stt);
     m->x32 = m->y32 = nullptr; m->x16 = m->q16 = m->kf16 = m->vf16 = m->ctx16 = m->h16 = nullptr;
     m->ids = m->tt = m->lens = nullptr; m->logits = nullptr;
     m->pair_off = m->row_pair = m->m_packed = nullptr;
+    m->sid = m->stt = nullptr;
     m->ws_tokens = 0; m->ws_pairs = 0; m->ws_L = 0;
 }
 
@@ -823,6 +825,8 @@ static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L) {
     HIP_TRY(h, hipMalloc(&m->pair_off, (size_t)(P + 1) * 4));
     HIP_TRY(h, hipMalloc(&m->row_pair, (size_t)Mp * 4));
     HIP_TRY(h, hipMalloc(&m->m_packed, 4));
+    HIP_TRY(h, hipMalloc(&m->sid, (size_t)P * L * 4));            // L_in <= L
+    HIP_TRY(h, hipMalloc(&m->stt, (size_t)P * L * 4));
     HIP_TRY(h, hipMalloc(&m->logits, (size_t)P * 4));
     // padded token rows are read by the GEMM tiles: keep them finite
     HIP_TRY(h, hipMemset(m->x16, 0, 2 * pp.x * 2));
@@ -861,9 +865,7 @@ int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* l
     if (rc) return rc;
     const hipMemcpyKind kin = host_ptrs ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     const hipMemcpyKind kout = host_ptrs ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    int32_t *sid = nullptr, *stt = nullptr;
-    HIP_TRY(h, hipMalloc(&sid, (size_t)chunk * L_in * 4));
-    HIP_TRY(h, hipMalloc(&stt, (size_t)chunk * L_in * 4));
+    int32_t *sid = m->sid, *stt = m->stt;
     for (int p0 = 0; p0 < P; p0 += chunk) {
         const int pc = std::min(chunk, P - p0);
         HIP_TRY(h, hipMemcpyAsync(sid, ids + (size_t)p0 * L_in, (size_t)pc * L_in * 4, kin, st));
@@ -875,8 +877,9 @@ int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* l
         if (rc) break;
         HIP_TRY(h, hipMemcpyAsync(out + p0, m->logits, (size_t)pc * 4, kout, st));
     }
-    hipError_t e = hipStreamSynchronize(st);
-    hipFree(sid); hipFree(stt);
+    // device-pointer calls stay asynchronous on the caller's stream (all buffers belong to the model workspace);
+    // host-pointer calls return results, so they wait
+    hipError_t e = host_ptrs ? hipStreamSynchronize(st) : hipGetLastError();
     if (rc) return rc;
     if (e != hipSuccess) {
         h->err = std::string("ce_score: ") + hipGetErrorString(e);
