@@ -81,11 +81,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # RAG_BENCH_BACKEND=gloo lets the multi-rank path be rehearsed with all ranks on ONE GPU (collectives through the host);
+    # the real runs use nccl (= RCCL over xGMI), one GPU per rank
+    backend = os.environ.get("RAG_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from optimized_rag_amd import RagEngine
     Q, k = args.queries, args.k

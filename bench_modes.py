@@ -69,10 +69,16 @@ def run_mode(args):
     from optimized_rag_amd.sharded import ShardedHybridIndex, ShardedReranker, shard_bounds
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("RAG_BENCH_BACKEND", "nccl")       # gloo: rehearsal with all ranks on one GPU
+    if backend != "nccl":
+        local %= max(1, torch.cuda.device_count())
     device = torch.device("cuda", local)
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     eng = RagEngine(dim=DIM, device=local)
     out = {"mode": args.mode, "n_gpus": world, "data": "synthetic", "scaling": "strong",
            "steps": args.steps, "warmup": args.warmup}
