@@ -42,6 +42,8 @@ struct rag_bm25_index {
     size_t ws_entries = 0;
     uint64_t* ws_tau = nullptr;        // [ws_tau_q] first-stage threshold per query
     int ws_tau_q = 0;
+    int* ws_cnt = nullptr;             // [ws_cnt_n] valid entries per (query, range) partial list
+    size_t ws_cnt_n = 0;
     double avgdl = 0, k1 = 1.5, b = 0.75;
     int normalize = 1;                 // 0: top-k scores stay raw (row-sharded search divides by the GLOBAL max after the merge)
 };
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
                                                                  int64_t n_docs, int64_t n_terms, int k, int mode,
                                                                  double* __restrict__ dense_out, uint64_t* __restrict__ part_key,
                                                                  uint32_t* __restrict__ part_row, int range_begin,
-                                                                 const uint64_t* __restrict__ tau_key) {
+                                                                 const uint64_t* __restrict__ tau_key, int* __restrict__ part_cnt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sc = reinterpret_cast<double*>(smem);                       // [BM_RANGE]
     int* hist = reinterpret_cast<int*>(smem + BM_SC_DOUBLES * 8);       // [256]
@@ -209,11 +211,13 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
     }
     // ---- exact top-k of sc[0..lim): radix select of the k-th largest key, ties by lower doc ------------
     const size_t po = ((size_t)q * n_ranges + r) * k;
+    // part_cnt[q][r] = number of valid entries at the front of this (query, range) slot group; the merge only reads those
     if (lim <= k) {
         for (int i = tid; i < k; i += BM_THREADS) {
             part_key[po + i] = i < lim ? f64_orderable(sc[SC_IDX(i)]) : 0ull;
             part_row[po + i] = (uint32_t)(base + i);
         }
+        if (tid == 0) part_cnt[(size_t)q * n_ranges + r] = lim;
         return;
     }
     const int seg0 = tid * BM_SEG;
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
                     part_row[po + off] = (uint32_t)(base + seg0 + j);
                     ++off;
                 }
-            for (int i = total_in + tid; i < k; i += BM_THREADS) { part_key[po + i] = 0ull; part_row[po + i] = 0xFFFFFFFFu; }
+            if (tid == 0) part_cnt[(size_t)q * n_ranges + r] = total_in;
             return;
         }
     }
@@ -343,6 +347,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
             ++off_eq;
         }
     }
+    if (tid == 0) part_cnt[(size_t)q * n_ranges + r] = k;
 }
 
 #define BM_MERGE 2048
@@ -396,34 +401,55 @@ __global__ __launch_bounds__(256) void bm25_tau_kernel(const uint64_t* __restric
 
 // all ranges -> per-range partial lists part_key/part_row [Q][n_ranges][k]; tau_dev: scratch [Q]
 static void bm25_launch_topk(const rag_bm25_index* ix, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k,
-                             uint64_t* part_key, uint32_t* part_row, uint64_t* tau_dev, hipStream_t st) {
+                             uint64_t* part_key, uint32_t* part_row, uint64_t* tau_dev, int* part_cnt, hipStream_t st) {
     const int nr = ix->n_ranges;
     static const int first_cfg = [] { const char* e = getenv("RAG_BM25_FIRST_RANGES"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? v : BM_FIRST_RANGES; }();
     const bool staged = nr > 2 * first_cfg && tau_dev != nullptr && !getenv("RAG_BM25_NO_STAGING");
     const int first = staged ? first_cfg : nr;
     hipLaunchKernelGGL(bm25_range_kernel, dim3(first, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc, ix->w, ix->idf,
                        ix->range_off, nr, term_ptr_dev, terms_dev, ix->n_docs, ix->n_terms, k, 0, (double*)nullptr, part_key,
-                       part_row, 0, (const uint64_t*)nullptr);
+                       part_row, 0, (const uint64_t*)nullptr, part_cnt);
     if (!staged) return;
     int P = 1;
     while (P < first * k) P <<= 1;
     hipLaunchKernelGGL(bm25_tau_kernel, dim3(Q), dim3(256), (size_t)P * sizeof(uint64_t), st, part_key, nr, first, k, tau_dev);
     hipLaunchKernelGGL(bm25_range_kernel, dim3(nr - first, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc, ix->w,
                        ix->idf, ix->range_off, nr, term_ptr_dev, terms_dev, ix->n_docs, ix->n_terms, k, 0, (double*)nullptr,
-                       part_key, part_row, first, (const uint64_t*)tau_dev);
+                       part_key, part_row, first, (const uint64_t*)tau_dev, part_cnt);
 }
 
 __global__ __launch_bounds__(256) void bm25_merge_kernel(const uint64_t* __restrict__ part_key, const uint32_t* __restrict__ part_row,
                                                           int n_ranges, int k, const int64_t* __restrict__ idmap,
                                                           int64_t id_base, int64_t* __restrict__ ids_out,
                                                           int32_t* __restrict__ rows_out, double* __restrict__ scores_out,
-                                                          double* __restrict__ raw_max_out, int normalize) {
+                                                          double* __restrict__ raw_max_out, int normalize,
+                                                          const int* __restrict__ part_cnt) {
     __shared__ uint64_t sk[BM_MERGE];
     __shared__ uint32_t sr[BM_MERGE];
+    __shared__ int pre[257];                        // exclusive prefix of the per-range entry counts (n_ranges <= 256)
+    __shared__ int wtot[4];
     const int q = blockIdx.x, tid = threadIdx.x;
-    const int total = n_ranges * k;
-    const uint64_t* pk = part_key + (size_t)q * total;
-    const uint32_t* pr = part_row + (size_t)q * total;
+    const uint64_t* pk = part_key + (size_t)q * n_ranges * k;
+    const uint32_t* pr = part_row + (size_t)q * n_ranges * k;
+    const bool compact = part_cnt != nullptr && n_ranges <= 256;      // thresholded ranges fill only a part of their k slots
+    int total = n_ranges * k;
+    if (compact) {
+        const int c = tid < n_ranges ? part_cnt[(size_t)q * n_ranges + tid] : 0;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if ((tid & 63) >= o) incl += up;
+        }
+        if ((tid & 63) == 63) wtot[tid >> 6] = incl;
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < (tid >> 6); ++w) off += wtot[w];
+        pre[tid + 1] = off + incl;
+        if (tid == 0) pre[0] = 0;
+        __syncthreads();
+        total = pre[n_ranges];
+    }
     for (int i = tid; i < BM_MERGE; i += 256) { sk[i] = 0ull; sr[i] = 0xFFFFFFFFu; }
     __syncthreads();
     int pos = 0;
@@ -431,8 +457,23 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(const uint64_t* __restr
         const int room = BM_MERGE - k;
         const int take = min(room, total - pos);
         for (int i = tid; i < room; i += 256) {
-            sk[k + i] = i < take ? pk[pos + i] : 0ull;
-            sr[k + i] = i < take ? pr[pos + i] : 0xFFFFFFFFu;
+            uint64_t key = 0ull;
+            uint32_t row = 0xFFFFFFFFu;
+            if (i < take) {
+                int slot = pos + i;
+                if (compact) {                      // entry e -> range r with pre[r] <= e < pre[r+1] -> slot r*k + (e - pre[r])
+                    int lo = 0, hi = n_ranges;
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (pre[mid] <= slot) lo = mid; else hi = mid;
+                    }
+                    slot = lo * k + (slot - pre[lo]);
+                }
+                key = pk[slot];
+                row = pr[slot];
+            }
+            sk[k + i] = key;
+            sr[k + i] = row;
         }
         __syncthreads();
         bm_sort_pairs(sk, sr, BM_MERGE, tid, 256);
@@ -462,7 +503,7 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(const uint64_t* __restr
 void bm25_free(rag_ctx* h) {
     if (!h->bm25) return;
     hipFree(h->bm25->indptr); hipFree(h->bm25->doc); hipFree(h->bm25->w); hipFree(h->bm25->idf); hipFree(h->bm25->range_off);
-    hipFree(h->bm25->ws_key); hipFree(h->bm25->ws_row); hipFree(h->bm25->ws_tau);
+    hipFree(h->bm25->ws_key); hipFree(h->bm25->ws_row); hipFree(h->bm25->ws_tau); hipFree(h->bm25->ws_cnt);
     delete h->bm25;
     h->bm25 = nullptr;
 }
@@ -550,17 +591,19 @@ static int bm25_run(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, i
         if (e == hipSuccess) e = hipMalloc(&dd, (size_t)Q * ix->n_docs * sizeof(double));
     }
     uint64_t* taud = nullptr;
+    int* cntd = nullptr;
     if (e == hipSuccess && mode == 0) e = hipMalloc(&taud, (size_t)Q * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc(&cntd, (size_t)Q * n_ranges * sizeof(int));
     if (e == hipSuccess) {
         if (mode == 0) {
-            bm25_launch_topk(ix, tp, tm, Q, k, pk, pr, taud, st);
+            bm25_launch_topk(ix, tp, tm, Q, k, pk, pr, taud, cntd, st);
             hipLaunchKernelGGL(bm25_merge_kernel, dim3(Q), dim3(256), 0, st, pk, pr, n_ranges, k,
                                h->n_rows == ix->n_docs ? h->ids : (const int64_t*)nullptr,
-                               h->n_rows == ix->n_docs ? h->id_base : (int64_t)0, idd, rwd, scd, mxd, ix->normalize);
+                               h->n_rows == ix->n_docs ? h->id_base : (int64_t)0, idd, rwd, scd, mxd, ix->normalize, cntd);
         } else {
             hipLaunchKernelGGL(bm25_range_kernel, dim3(n_ranges, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc,
                                ix->w, ix->idf, ix->range_off, ix->n_ranges, tp, tm, ix->n_docs, ix->n_terms, k, mode, dd, pk, pr,
-                               0, (const uint64_t*)nullptr);
+                               0, (const uint64_t*)nullptr, cntd);
         }
         e = hipGetLastError();
     }
@@ -574,7 +617,7 @@ static int bm25_run(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, i
     }
     hipError_t e2 = hipStreamSynchronize(st);
     hipFree(tp); hipFree(tm); hipFree(pk); hipFree(pr); hipFree(idd); hipFree(rwd); hipFree(scd); hipFree(mxd); hipFree(dd);
-    hipFree(taud);
+    hipFree(taud); hipFree(cntd);
     if (e != hipSuccess || e2 != hipSuccess) {
         h->err = std::string("bm25: ") + hipGetErrorString(e != hipSuccess ? e : e2);
         return RAG_ERR_HIP;
@@ -610,12 +653,20 @@ int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_
         HIP_TRY(h, hipMalloc(&ix->ws_tau, (size_t)Q * sizeof(uint64_t)));
         ix->ws_tau_q = Q;
     }
-    bm25_launch_topk(ix, term_ptr_dev, terms_dev, Q, k, ix->ws_key, ix->ws_row, ix->ws_tau, st);
+    const size_t need_cnt = (size_t)Q * ix->n_ranges;
+    if (need_cnt > ix->ws_cnt_n) {
+        hipFree(ix->ws_cnt);
+        ix->ws_cnt = nullptr;
+        ix->ws_cnt_n = 0;
+        HIP_TRY(h, hipMalloc(&ix->ws_cnt, need_cnt * sizeof(int)));
+        ix->ws_cnt_n = need_cnt;
+    }
+    bm25_launch_topk(ix, term_ptr_dev, terms_dev, Q, k, ix->ws_key, ix->ws_row, ix->ws_tau, ix->ws_cnt, st);
     // doc ids follow the dense index's mapping when both indexes cover the same rows (hybrid fusion needs one id space)
     const bool aligned = h->n_rows == ix->n_docs;
     hipLaunchKernelGGL(bm25_merge_kernel, dim3(Q), dim3(256), 0, st, ix->ws_key, ix->ws_row, ix->n_ranges, k,
                        aligned ? h->ids : (const int64_t*)nullptr, aligned ? h->id_base : (int64_t)0, ids_dev, rows_dev, scores_dev,
-                       raw_max_dev, ix->normalize);
+                       raw_max_dev, ix->normalize, ix->ws_cnt);
     HIP_TRY(h, hipGetLastError());
     return RAG_OK;
 }
