@@ -206,7 +206,7 @@ int rag_ce_score_dev(rag_handle_t h, const int32_t* input_ids_dev, const int32_t
  *      index. rag_retrieve_rerank_dev: mode 0 = dense top-pool candidates, mode 1 = dense + BM25 + RRF(rrf_k) top-pool;
  *      pairs are [CLS] query [SEP] passage [SEP] padded to L_pair (only the passage is truncated); outputs per query:
  *      ids_out[k] doc ids (-1 padded), scores_out[k] = sigmoid(logit) as float64, logits_out[k] raw logits,
- *      cand_out[pool] (may be NULL) the candidate list that was reranked. Needs the default id mapping (id_base + row). */
+ *      cand_out[pool] (may be NULL) the candidate list that was reranked. */
 int rag_tokens_load_host(rag_handle_t h, const int32_t* tokens_host, const int32_t* lens_host, int64_t n_rows, int L);
 int rag_retrieve_rerank_dev(rag_handle_t h, const float* q_emb_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev,
                             const int32_t* q_tok_dev, const int32_t* q_len_dev, int Lq, int n_queries, int pool, int k,

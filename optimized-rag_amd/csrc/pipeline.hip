@@ -122,13 +122,18 @@ int rerank_topk_dev(rag_ctx* h, const float* logits_dev, const int64_t* cand_dev
     return RAG_OK;
 }
 
+__global__ void map_rows_to_ids_kernel(int64_t* __restrict__ v, int64_t n, const int64_t* __restrict__ idmap, int64_t id_base) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || v[i] < 0) return;
+    v[i] = idmap ? idmap[v[i]] : id_base + v[i];
+}
+
 int retrieve_rerank_dev(rag_ctx* h, const float* q_emb_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev,
                         const int32_t* q_tok_dev, const int32_t* q_len_dev, int Lq, int Q, int pool, int k, int rrf_k, int tenant,
                         int mode, int cls_id, int sep_id, int L_pair, int64_t* ids_out, double* scores_out, float* logits_out,
                         int64_t* cand_out, hipStream_t st) {
     ARG_CHECK(h, h->ce != nullptr, "retrieve_rerank: no cross-encoder loaded");
     ARG_CHECK(h, h->tok != nullptr && h->tok_rows == h->n_rows, "retrieve_rerank: token store missing or not row-aligned with the index");
-    ARG_CHECK(h, h->ids == nullptr, "retrieve_rerank: needs the default id mapping (id = id_base + row)");
     ARG_CHECK(h, Q > 0 && pool > 0 && pool <= RAG_MAX_K && k > 0 && k <= pool, "retrieve_rerank: 0 < k <= pool <= 256");
     ARG_CHECK(h, L_pair >= 8 && L_pair <= 512 && Lq > 0 && q_emb_dev && q_tok_dev && q_len_dev && ids_out && scores_out && logits_out,
               "retrieve_rerank: bad arguments");
@@ -154,19 +159,25 @@ int retrieve_rerank_dev(rag_ctx* h, const float* q_emb_dev, const int32_t* term_
     int32_t* ptt = (int32_t*)w;                w += P * L_pair * 4;
     int32_t* plen = (int32_t*)w;               w += P * 4;
     float* logit = (float*)w;
+    // The candidate stage runs in ROW space (the token store is row-aligned and RRF only needs a consistent key space):
+    // the id mapping is switched off for these launches (pointers are kernel arguments, captured at launch) and applied to
+    // the outputs at the end, so explicit doc ids (e.g. primary keys of a loaded shard) work as well as id_base + row.
+    int64_t* const ids_saved = h->ids;
+    const int64_t id_base_saved = h->id_base;
+    h->ids = nullptr;
+    h->id_base = 0;
     int rc;
     if (mode == 0) {
         rc = dense_search(h, q_emb_dev, Q, pool, tenant, cand, nullptr, sc, st);
-        if (rc) return rc;
     } else {
         rc = dense_search(h, q_emb_dev, Q, pool, tenant, lists, nullptr, sc, st);
-        if (rc) return rc;
-        rc = bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, lists + P, nullptr, sc, nullptr, st);
-        if (rc) return rc;
-        rc = rrf_fuse_dev(h, lists, Q, 2, pool, (int64_t)P, pool, rrf_k, pool, cand, rrf, ranks, st);
-        if (rc) return rc;
+        if (!rc) rc = bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, lists + P, nullptr, sc, nullptr, st);
+        if (!rc) rc = rrf_fuse_dev(h, lists, Q, 2, pool, (int64_t)P, pool, rrf_k, pool, cand, rrf, ranks, st);
     }
-    hipLaunchKernelGGL(ce_build_pairs_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, q_tok_dev, q_len_dev, Lq, cand, h->id_base,
+    h->ids = ids_saved;
+    h->id_base = id_base_saved;
+    if (rc) return rc;
+    hipLaunchKernelGGL(ce_build_pairs_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, q_tok_dev, q_len_dev, Lq, cand, (int64_t)0,
                        h->tok, h->tok_len, h->tok_L, h->tok_rows, (int)P, pool, L_pair, cls_id, sep_id, pid, ptt, plen);
     HIP_TRY(h, hipGetLastError());
     rc = ce_score(h, pid, ptt, plen, (int)P, L_pair, logit, st, false);
@@ -174,5 +185,13 @@ int retrieve_rerank_dev(rag_ctx* h, const float* q_emb_dev, const int32_t* term_
     hipLaunchKernelGGL(rerank_topk_kernel, dim3(Q), dim3(256), 0, st, logit, cand, pool, k, ids_out, scores_out, logits_out);
     HIP_TRY(h, hipGetLastError());
     if (cand_out) HIP_TRY(h, hipMemcpyAsync(cand_out, cand, P * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    if (ids_saved != nullptr || id_base_saved != 0) {
+        hipLaunchKernelGGL(map_rows_to_ids_kernel, dim3((unsigned)(((size_t)Q * k + 255) / 256)), dim3(256), 0, st, ids_out, (int64_t)Q * k,
+                           ids_saved, id_base_saved);
+        if (cand_out)
+            hipLaunchKernelGGL(map_rows_to_ids_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, cand_out, (int64_t)P, ids_saved,
+                               id_base_saved);
+        HIP_TRY(h, hipGetLastError());
+    }
     return RAG_OK;
 }

@@ -130,3 +130,43 @@ def test_sharded_pipeline_world1_equals_one_call():
         eng.close()
     for a, b in zip(got, ref):
         np.testing.assert_array_equal(a, b)
+
+
+def test_pipeline_with_explicit_doc_ids():
+    """The one-call pipeline works in row space and maps to doc ids at the end: explicit ids (e.g. primary keys set with
+    rag_index_set_ids_host) must give the same rows, scores and logits as the default id = row mapping."""
+    import torch
+    from optimized_rag_amd import RagEngine
+    from optimized_rag_amd.bm25 import Bm25Postings
+    from optimized_rag_amd.cross_encoder import random_init_tensors
+    rng = np.random.default_rng(9)
+    N, D, Q, pool, k, Ld, Lq, L = 400, 1536, 3, 8, 4, 16, 5, 32
+    cfg = dict(vocab_size=3000, hidden=384, layers=2, heads=12, ffn=1536, max_pos=64, type_vocab=2, eps=1e-12)
+    emb = rng.standard_normal((N, D)).astype(np.float32)
+    q_emb = (emb[rng.integers(0, N, Q)] + 0.5 * rng.standard_normal((Q, D))).astype(np.float32)
+    tok = rng.integers(200, cfg["vocab_size"], (N, Ld)).astype(np.int32)
+    tok_len = rng.integers(3, Ld + 1, N).astype(np.int32)
+    q_tok = rng.integers(200, cfg["vocab_size"], (Q, Lq)).astype(np.int32)
+    q_len = np.full(Q, Lq, dtype=np.int32)
+    corpus = [" ".join(f"t{t}" for t in tok[i, :tok_len[i]] % 30) for i in range(N)]
+    queries = [" ".join(f"t{t}" for t in q_tok[i] % 30) for i in range(Q)]
+    pk = (rng.permutation(N) + 10_000).astype(np.int64)
+    eng = RagEngine(dim=D, device=0)
+    try:
+        eng.index_load(emb)
+        eng.tokens_load(tok, tok_len)
+        eng.ce_load(cfg, random_init_tensors(cfg, 4))
+        post = Bm25Postings.from_corpus(corpus).load(eng)
+        ptr, terms = post.encode_queries(queries)
+        t = lambda a: torch.from_numpy(a).cuda()
+        args = (t(q_emb), t(q_tok), t(q_len), pool, k)
+        kw = dict(term_ptr=t(ptr), terms=t(terms), L_pair=L)
+        base = [x.cpu().numpy().copy() for x in eng.retrieve_rerank_dev(*args, **kw)]
+        eng.set_ids(pk)
+        got = [x.cpu().numpy().copy() for x in eng.retrieve_rerank_dev(*args, **kw)]
+    finally:
+        eng.close()
+    np.testing.assert_array_equal(got[0], np.where(base[0] >= 0, pk[np.maximum(base[0], 0)], -1))
+    np.testing.assert_array_equal(got[3], np.where(base[3] >= 0, pk[np.maximum(base[3], 0)], -1))
+    np.testing.assert_array_equal(got[1], base[1])
+    np.testing.assert_array_equal(got[2], base[2])
