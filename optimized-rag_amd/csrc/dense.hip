@@ -289,14 +289,21 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
             const int q = q0 + wn * 64 + j * 16 + fr;
             if (q >= q_valid) continue;
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i) {
+                // every dense slot is written (0 = empty for padded / filtered rows): no memset needed beforehand; the lane's
+                // 4 consecutive rows go out as two 16-byte stores
+                const int rbase = row0 + wm * 128 + i * 16 + fq * 4;
+                uint64_t kk[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    // every dense slot is written (0 = empty for padded / filtered rows): no memset needed beforehand
-                    const int row = row0 + wm * 128 + i * 16 + fq * 4 + r;
+                    const int row = rbase + r;
                     const bool ok = row < n_rows_valid && (tenants == nullptr || tenants[row] == tenant);
-                    cand[(size_t)q * RAG_CAND_CAP + row] = ok ? make_key(acc[i][j][r] * scale, (uint32_t)row) : 0ull;
+                    kk[r] = ok ? make_key(acc[i][j][r] * scale, (uint32_t)row) : 0ull;
                 }
+                ulonglong2* dst = reinterpret_cast<ulonglong2*>(cand + (size_t)q * RAG_CAND_CAP + rbase);
+                dst[0] = make_ulonglong2(kk[0], kk[1]);
+                dst[1] = make_ulonglong2(kk[2], kk[3]);
+            }
         }
         return;
     }
