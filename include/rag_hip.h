@@ -14,8 +14,10 @@
  *     hipStream_t passed as void*. NULL means the DEFAULT (null) stream, exactly as in HIP itself — frameworks
  *     whose current stream is the default stream (PyTorch) pass 0 and get correct ordering with their own work.
  *     The handle's private stream is only used by the synchronous *_host entry points.
- *   - one handle = one GPU = one process rank. Concurrent calls on one handle must be serialised by
- *     the caller (the reference graph is single-threaded, agent/rag_graph.py:506).
+ *   - one handle = one GPU = one process rank. Every entry point takes the handle's internal lock: the synchronous
+ *     *_host calls may be issued from several threads at once (the reference graph is single-threaded,
+ *     agent/rag_graph.py:506, but its DB pool allows 10 concurrent searches, database/connection.py:38-42); they
+ *     run one after another. *_dev calls share the handle's device workspaces: issue them on ONE stream.
  *   - doc ids are int64 (SQL BIGSERIAL ids, database/migrations/001_initial_schema.sql); scores are
  *     float64 because the reference computes every score as a Python float.
  */
@@ -132,8 +134,8 @@ int rag_rrf_fuse_host(rag_handle_t h, const int64_t* lists_host, int n_queries, 
 int rag_rrf_fuse_dev(rag_handle_t h, const int64_t* lists_dev, int n_queries, int n_lists, int list_len, int rrf_k,
                      int top_k, int64_t* keys_out_dev, double* scores_out_dev, int32_t* ranks_out_dev, void* stream);
 int rag_bm25_topk_dev(rag_handle_t h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int n_queries, int k,
-                      int64_t* ids_out_dev, int32_t* rows_out_dev, double* scores_out_dev, double* raw_max_out_dev,
-                      void* stream);
+                      int tenant, int64_t* ids_out_dev, int32_t* rows_out_dev, double* scores_out_dev,
+                      double* raw_max_out_dev, void* stream);
 int rag_hybrid_rrf_dev(rag_handle_t h, const float* q_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev,
                        int n_queries, int pool, int k, int rrf_k, int tenant, int64_t* lists_ws_dev,
                        double* scores_ws_dev, int64_t* keys_out_dev, double* rrf_out_dev, int32_t* ranks_out_dev,
@@ -167,9 +169,13 @@ int rag_bm25_load_host(rag_handle_t h, const int64_t* indptr_host /*V+1*/, const
                        const double* idf_host /*V*/, int64_t n_docs, int64_t n_terms, double avgdl,
                        double k1, double b);
 /* term_ptr[Q+1], terms[term_ptr[Q]] (query tokens WITH repeats; -1 = out-of-vocabulary).
- * scores_out are max-normalised as the reference does; raw_max_out[Q] (may be NULL) is the divisor. */
+ * scores_out are max-normalised as the reference does; raw_max_out[Q] (may be NULL) is the divisor.
+ * tenant >= 0 (needs rag_index_set_tenants_host and postings row-aligned with the index): only that tenant's documents
+ * can be returned - the `WHERE agent_id = %s` every reference query carries (rag/document_store.py:457); idf / avgdl stay
+ * the statistics of the whole loaded corpus, the max-normalisation uses the tenant's own best score. tenant < 0: no filter.
+ * The same filter applies to the BM25 leg of rag_hybrid_rrf_dev and rag_retrieve_rerank_dev (mode 1). */
 int rag_bm25_topk_host(rag_handle_t h, const int32_t* term_ptr_host, const int32_t* terms_host, int n_queries,
-                       int k, int64_t* ids_out_host, int32_t* rows_out_host, double* scores_out_host,
+                       int k, int tenant, int64_t* ids_out_host, int32_t* rows_out_host, double* scores_out_host,
                        double* raw_max_out_host);
 /* on = 1 (default): top-k scores are divided by the per-query max as rag/retrieval.py:343-345 does. on = 0: top-k
  * scores stay raw; a row-sharded index merges the shards' raw lists first and divides by the
@@ -178,6 +184,13 @@ int rag_bm25_set_normalize(rag_handle_t h, int on);
 /* dense scores for a (small) corpus: out[Q][N] raw (un-normalised) BM25, for hybrid_search semantics */
 int rag_bm25_scores_host(rag_handle_t h, const int32_t* term_ptr_host, const int32_t* terms_host, int n_queries,
                          double* out_host);
+/* The same for an AD-HOC corpus, stateless: HybridRetriever.hybrid_search builds a fresh BM25Okapi over the corpus it is
+ * handed on every call (rag/retrieval.py:333-341). The postings (arguments as rag_bm25_load_host) are uploaded, scored
+ * and dropped inside the call; the resident postings of the index are not touched. out[Q][n_docs] raw scores. */
+int rag_bm25_scores_adhoc_host(rag_handle_t h, const int64_t* indptr_host, const int32_t* doc_host, const int32_t* tf_host,
+                               const int32_t* doc_len_host, const double* idf_host, int64_t n_docs, int64_t n_terms,
+                               double avgdl, double k1, double b, const int32_t* term_ptr_host,
+                               const int32_t* terms_host, int n_queries, double* out_host);
 
 /* ---- weighted linear fusion + top-k: replaces rag/retrieval.py:294-322
  *      hybrid = alpha*semantic + beta*keyword + gamma*temporal, stable sort desc, [:top_k]. */
@@ -204,7 +217,8 @@ int rag_ce_score_dev(rag_handle_t h, const int32_t* input_ids_dev, const int32_t
  *      pairs [query, passage], raw logits, sigmoid, sort desc, [:top_k]) with the passages' token ids resident in HBM.
  *      rag_tokens_load_host: tokens[n_rows][L] passage WordPiece ids (no [CLS]/[SEP]) + lens[n_rows], row-aligned with the
  *      index. rag_retrieve_rerank_dev: mode 0 = dense top-pool candidates, mode 1 = dense + BM25 + RRF(rrf_k) top-pool;
- *      pairs are [CLS] query [SEP] passage [SEP] padded to L_pair (only the passage is truncated); outputs per query:
+ *      pairs are [CLS] query [SEP] passage [SEP] truncated 'longest_first' to max_length L_pair (what CrossEncoder.predict's
+ *      tokenizer call does; the reference's max_length is 512, rag/reranker.py:290-294) and padded to it; outputs per query:
  *      ids_out[k] doc ids (-1 padded), scores_out[k] = sigmoid(logit) as float64, logits_out[k] raw logits,
  *      cand_out[pool] (may be NULL) the candidate list that was reranked. */
 int rag_tokens_load_host(rag_handle_t h, const int32_t* tokens_host, const int32_t* lens_host, int64_t n_rows, int L);

@@ -62,14 +62,16 @@ _SIGS = {
     "rag_pairwise_cosine_host": ([_P, _P, C.c_int, _P, C.c_int, C.c_int, _P], C.c_int),
     "rag_rrf_fuse_host": ([_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P], C.c_int),
     "rag_bm25_load_host": ([_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double], C.c_int),
-    "rag_bm25_topk_host": ([_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
+    "rag_bm25_topk_host": ([_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
     "rag_bm25_scores_host": ([_P, _P, _P, C.c_int, _P], C.c_int),
+    "rag_bm25_scores_adhoc_host": ([_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double, _P, _P,
+                                   C.c_int, _P], C.c_int),
     "rag_bm25_set_normalize": ([_P, C.c_int], C.c_int),
     "rag_chunk_chain_host": ([_P, _P, _P, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _P], C.c_int),
     "rag_mmr_select_host": ([_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _P, _P], C.c_int),
     "rag_mmr_select_dev": ([_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _P, _P, _P], C.c_int),
     "rag_rrf_fuse_dev": ([_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
-    "rag_bm25_topk_dev": ([_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P], C.c_int),
+    "rag_bm25_topk_dev": ([_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P], C.c_int),
     "rag_hybrid_rrf_dev": ([_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P], C.c_int),
     "rag_linear_fuse_topk_host": ([_P, _P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _P, _P], C.c_int),
     "rag_ce_load_host": ([_P, C.POINTER(CeConfig), C.POINTER(_P), C.c_int], C.c_int),
@@ -365,7 +367,7 @@ class RagEngine:
                     "rag_bm25_load_host")
         self.bm25_docs = int(doc_len.shape[0])
 
-    def bm25_topk(self, term_ptr, terms, k):
+    def bm25_topk(self, term_ptr, terms, k, tenant=-1):
         term_ptr = _np(term_ptr, np.int32)
         terms = _np(terms, np.int32)
         Q = term_ptr.shape[0] - 1
@@ -373,21 +375,21 @@ class RagEngine:
         rows = np.empty((Q, k), dtype=np.int32)
         sc = np.empty((Q, k), dtype=np.float64)
         mx = np.empty((Q,), dtype=np.float64)
-        self._check(self.lib.rag_bm25_topk_host(self.h, _ptr(term_ptr), _ptr(terms), Q, int(k), _ptr(ids), _ptr(rows),
-                                                _ptr(sc), _ptr(mx)), "rag_bm25_topk_host")
+        self._check(self.lib.rag_bm25_topk_host(self.h, _ptr(term_ptr), _ptr(terms), Q, int(k), int(tenant), _ptr(ids),
+                                                _ptr(rows), _ptr(sc), _ptr(mx)), "rag_bm25_topk_host")
         return ids, rows, sc, mx
 
     def bm25_set_normalize(self, on):
         """on=False: bm25_topk* return RAW scores (a row-sharded index divides by the global max after its merge)."""
         self._check(self.lib.rag_bm25_set_normalize(self.h, 1 if on else 0), "rag_bm25_set_normalize")
 
-    def bm25_topk_dev(self, term_ptr, terms, k, ids_out, rows_out, scores_out, raw_max_out=None, stream=None):
+    def bm25_topk_dev(self, term_ptr, terms, k, ids_out, rows_out, scores_out, raw_max_out=None, stream=None, tenant=-1):
         """Device tensors in / out (int32 term arrays; int64 ids, float64 scores [Q, k]); asynchronous on `stream`."""
         import torch
         Q = term_ptr.shape[0] - 1
         st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
         self._check(self.lib.rag_bm25_topk_dev(self.h, C.c_void_p(term_ptr.data_ptr()), C.c_void_p(terms.data_ptr()), Q, int(k),
-                                               C.c_void_p(ids_out.data_ptr()),
+                                               int(tenant), C.c_void_p(ids_out.data_ptr()),
                                                C.c_void_p(rows_out.data_ptr() if rows_out is not None else 0),
                                                C.c_void_p(scores_out.data_ptr()),
                                                C.c_void_p(raw_max_out.data_ptr() if raw_max_out is not None else 0), st),
@@ -434,6 +436,18 @@ class RagEngine:
         self._check(self.lib.rag_bm25_scores_host(self.h, _ptr(term_ptr), _ptr(terms), Q, _ptr(out)), "rag_bm25_scores_host")
         return out
 
+    def bm25_scores_adhoc(self, indptr, doc, tf, doc_len, idf, avgdl, term_ptr, terms, k1=1.5, b=0.75):
+        """Raw BM25 scores [Q, n_docs] of an ad-hoc corpus (CSR as bm25_load); the resident postings are not touched."""
+        indptr, doc, tf = _np(indptr, np.int64), _np(doc, np.int32), _np(tf, np.int32)
+        doc_len, idf = _np(doc_len, np.int32), _np(idf, np.float64)
+        term_ptr, terms = _np(term_ptr, np.int32), _np(terms, np.int32)
+        Q = term_ptr.shape[0] - 1
+        out = np.zeros((Q, doc_len.shape[0]), dtype=np.float64)
+        self._check(self.lib.rag_bm25_scores_adhoc_host(self.h, _ptr(indptr), _ptr(doc), _ptr(tf), _ptr(doc_len), _ptr(idf),
+                                                        doc_len.shape[0], idf.shape[0], float(avgdl), float(k1), float(b),
+                                                        _ptr(term_ptr), _ptr(terms), Q, _ptr(out)), "rag_bm25_scores_adhoc_host")
+        return out
+
     # ---- cross-encoder ----------------------------------------------------------------------------
     def ce_load(self, cfg, tensors):
         c = CeConfig(cfg["vocab_size"], cfg["hidden"], cfg["layers"], cfg["heads"], cfg["ffn"], cfg["max_pos"],
@@ -449,7 +463,7 @@ class RagEngine:
         self._check(self.lib.rag_tokens_load_host(self.h, _ptr(tokens), _ptr(lens), tokens.shape[0], tokens.shape[1]),
                     "rag_tokens_load_host")
 
-    def retrieve_rerank_dev(self, q_emb, q_tok, q_len, pool, k, term_ptr=None, terms=None, rrf_k=60, tenant=-1, L_pair=256,
+    def retrieve_rerank_dev(self, q_emb, q_tok, q_len, pool, k, term_ptr=None, terms=None, rrf_k=60, tenant=-1, L_pair=512,
                             cls_id=101, sep_id=102, stream=None):
         """Dense (term_ptr None) or hybrid candidates -> cross-encoder -> top-k, all on the device (CUDA tensors).
         Returns (ids [Q,k] int64, scores [Q,k] float64 sigmoid, logits [Q,k] float32, candidates [Q,pool] int64)."""

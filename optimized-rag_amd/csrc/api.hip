@@ -12,10 +12,14 @@ int linear_fuse_topk_host(rag_ctx* h, const double* sem, const double* kw, const
                           double g, int top_k, int32_t* idx_out, double* hyb_out);
 int bm25_load_host(rag_ctx* h, const int64_t* indptr, const int32_t* doc, const int32_t* tf, const int32_t* doc_len,
                    const double* idf, int64_t n_docs, int64_t n_terms, double avgdl, double k1, double b);
-int bm25_topk_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, int k, int64_t* ids_out,
+int bm25_topk_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, int k, int tenant, int64_t* ids_out,
                    int32_t* rows_out, double* scores_out, double* raw_max_out);
+int bm25_scores_adhoc_host(rag_ctx* h, const int64_t* indptr, const int32_t* doc, const int32_t* tf, const int32_t* doc_len,
+                           const double* idf, int64_t n_docs, int64_t n_terms, double avgdl, double k1, double b,
+                           const int32_t* term_ptr, const int32_t* terms, int Q, double* out);
+int64_t bm25_n_docs(const rag_ctx* h);
 int bm25_scores_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, double* out);
-int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int64_t* ids_dev,
+int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int tenant, int64_t* ids_dev,
                   int32_t* rows_dev, double* scores_dev, double* raw_max_dev, hipStream_t st);
 int rrf_fuse_dev(rag_ctx* h, const int64_t* lists_dev, int Q, int L, int len, int64_t list_stride, int64_t query_stride, int rrf_k,
                  int top_k, int64_t* keys_dev, double* scores_dev, int32_t* ranks_dev, hipStream_t st);
@@ -44,10 +48,11 @@ int retrieve_rerank_dev(rag_ctx* h, const float* q_emb_dev, const int32_t* term_
                         int64_t* cand_out, hipStream_t st);
 
 static thread_local std::string g_null_err = "null handle";
+#define LOCK(h) std::lock_guard<std::mutex> lock_((h)->mu)
 
 extern "C" {
 
-int rag_version(void) { return 100; }
+int rag_version(void) { return 200; }
 
 int rag_device_count(int* n_out) {
     if (!n_out) return RAG_ERR_ARG;
@@ -79,6 +84,7 @@ int rag_create(int device_id, int dim, rag_handle_t* out) {
 
 int rag_destroy(rag_handle_t h) {
     if (!h) return RAG_ERR_ARG;
+    { LOCK(h); }                        // wait for a call in flight on another thread; the caller must not start new ones
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     dense_free(h);
@@ -86,8 +92,7 @@ int rag_destroy(rag_handle_t h) {
     ce_free(h);
     pipeline_free(h);
     hipFree(h->q32); hipFree(h->q16); hipFree(h->cand); hipFree(h->cnt); hipFree(h->tau); hipFree(h->bound);
-    hipFree(h->n_sorted); hipFree(h->exact); hipFree(h->flag); hipFree(h->stats); hipFree(h->out_ids);
-    hipFree(h->out_rows); hipFree(h->out_scores);
+    hipFree(h->n_sorted); hipFree(h->exact); hipFree(h->flag); hipFree(h->stats); hipFree(h->stage);
     for (auto& e : h->gemm_events) {
         hipEventDestroy(e.first);
         hipEventDestroy(e.second);
@@ -101,12 +106,14 @@ const char* rag_last_error(rag_handle_t h) { return h ? h->err.c_str() : g_null_
 
 int rag_synchronize(rag_handle_t h) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return RAG_OK;
 }
 
 int rag_set_profiling(rag_handle_t h, int enable) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     h->profiling = enable != 0;
     h->gemm_events_used = 0;      // (re)start collecting per-launch events of the dominant kernel
     return RAG_OK;
@@ -138,18 +145,21 @@ static int index_load_common(rag_ctx* h, const float* emb, const int64_t* ids, i
 
 int rag_index_load_host(rag_handle_t h, const float* emb_host, const int64_t* ids_host, int64_t id_base, int64_t n_rows) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     return index_load_common(h, emb_host, ids_host, id_base, n_rows, h->stream, true);
 }
 
 int rag_index_load_dev(rag_handle_t h, const float* emb_dev, const int64_t* ids_dev, int64_t id_base, int64_t n_rows,
                        void* stream) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     return index_load_common(h, emb_dev, ids_dev, id_base, n_rows, (hipStream_t)stream, false);
 }
 
 // ---- chunked bulk load (export of document_chunks / archival_memory in pieces) -------------------
 int rag_index_reserve(rag_handle_t h, int64_t n_rows_total, int64_t id_base) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     ARG_CHECK(h, n_rows_total > 0 && n_rows_total < (int64_t)0x7fffff00, "n_rows must fit int32 per GPU");
     HIP_TRY(h, hipSetDevice(h->device));
     dense_free(h);
@@ -183,21 +193,24 @@ static int index_append(rag_ctx* h, const float* emb, int64_t n, hipStream_t st,
 
 int rag_index_append_host(rag_handle_t h, const float* emb_host, int64_t n_rows) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     return index_append(h, emb_host, n_rows, h->stream, true);
 }
 
 int rag_index_append_dev(rag_handle_t h, const float* emb_dev, int64_t n_rows, void* stream) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     return index_append(h, emb_dev, n_rows, (hipStream_t)stream, false);
 }
 
 int rag_index_set_tenants_host(rag_handle_t h, const int32_t* t, int64_t n_rows) {
     if (!h) return RAG_ERR_ARG;
-    ARG_CHECK(h, n_rows == h->n_rows, "tenant array length must equal the index row count");
+    LOCK(h);
+    ARG_CHECK(h, t == nullptr || n_rows == h->n_rows, "tenant array length must equal the index row count");
     HIP_TRY(h, hipSetDevice(h->device));
     hipFree(h->tenants);
     h->tenants = nullptr;
-    if (t == nullptr || n_rows == 0) return RAG_OK;
+    if (t == nullptr || n_rows == 0) return RAG_OK;                    // NULL clears the filter table
     HIP_TRY(h, hipMalloc(&h->tenants, (size_t)n_rows * sizeof(int32_t)));
     HIP_TRY(h, hipMemcpy(h->tenants, t, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice));
     return RAG_OK;
@@ -205,6 +218,7 @@ int rag_index_set_tenants_host(rag_handle_t h, const int32_t* t, int64_t n_rows)
 
 int rag_index_set_ids_host(rag_handle_t h, const int64_t* ids, int64_t n_rows) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     ARG_CHECK(h, n_rows == h->n_rows, "id array length must equal the index row count");
     HIP_TRY(h, hipSetDevice(h->device));
     hipFree(h->ids);
@@ -217,12 +231,14 @@ int rag_index_set_ids_host(rag_handle_t h, const int64_t* ids, int64_t n_rows) {
 
 int rag_index_rows(rag_handle_t h, int64_t* n_rows_out) {
     if (!h || !n_rows_out) return RAG_ERR_ARG;
+    LOCK(h);
     *n_rows_out = h->n_rows;
     return RAG_OK;
 }
 
 int rag_index_fetch_rows_host(rag_handle_t h, const int64_t* rows, int n, float* out) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     ARG_CHECK(h, n >= 0 && (n == 0 || (rows && out)), "null rows/out");
     HIP_TRY(h, hipSetDevice(h->device));
     for (int i = 0; i < n; ++i) {
@@ -238,6 +254,7 @@ int rag_index_fetch_rows_host(rag_handle_t h, const int64_t* rows, int n, float*
 int rag_dense_topk_dev(rag_handle_t h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev,
                        double* scores_dev, void* stream) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     ARG_CHECK(h, q_dev && ids_dev && scores_dev, "null pointer");
     ARG_CHECK(h, Q > 0 && Q <= 65535, "1 <= n_queries <= 65535");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -247,47 +264,33 @@ int rag_dense_topk_dev(rag_handle_t h, const float* q_dev, int Q, int k, int ten
 int rag_dense_topk_host(rag_handle_t h, const float* q_host, int Q, int k, int tenant, int64_t* ids_out, int32_t* rows_out,
                         double* scores_out) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     ARG_CHECK(h, q_host && ids_out && scores_out, "null pointer");
     ARG_CHECK(h, Q > 0 && Q <= 65535, "1 <= n_queries <= 65535");
     ARG_CHECK(h, k > 0 && k <= RAG_MAX_K, "0 < k <= 256");
     HIP_TRY(h, hipSetDevice(h->device));
-    // workspace first (q32 staging lives there)
-    if (Q > h->ws_q) {
-        // dense_search re-checks; allocate via a dry call path: copy after ensure
-    }
     hipStream_t st = h->stream;
-    // stage queries: allocate a temporary if the workspace is not there yet
-    float* qd = nullptr;
-    HIP_TRY(h, hipMalloc(&qd, (size_t)Q * h->dim * sizeof(float)));
-    hipError_t e = hipMemcpyAsync(qd, q_host, (size_t)Q * h->dim * sizeof(float), hipMemcpyHostToDevice, st);
-    int rc = RAG_OK;
-    int64_t* ids_d = nullptr;
-    int32_t* rows_d = nullptr;
-    double* sc_d = nullptr;
-    if (e == hipSuccess) e = hipMalloc(&ids_d, (size_t)Q * k * sizeof(int64_t));
-    if (e == hipSuccess) e = hipMalloc(&rows_d, (size_t)Q * k * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&sc_d, (size_t)Q * k * sizeof(double));
-    if (e == hipSuccess) {
-        rc = dense_search(h, qd, Q, k, tenant, ids_d, rows_d, sc_d, st);
-        if (rc == RAG_OK) {
-            e = hipMemcpyAsync(ids_out, ids_d, (size_t)Q * k * sizeof(int64_t), hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess && rows_out)
-                e = hipMemcpyAsync(rows_out, rows_d, (size_t)Q * k * sizeof(int32_t), hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(scores_out, sc_d, (size_t)Q * k * sizeof(double), hipMemcpyDeviceToHost, st);
-        }
-    }
-    hipError_t e2 = hipStreamSynchronize(st);
-    hipFree(qd); hipFree(ids_d); hipFree(rows_d); hipFree(sc_d);
+    const size_t n_out = (size_t)Q * k;
+    int rc = stage_reserve(h, stage_size((size_t)Q * h->dim, 4) + 2 * stage_size(n_out, 8) + stage_size(n_out, 4));
     if (rc) return rc;
-    if (e != hipSuccess || e2 != hipSuccess) {
-        h->err = std::string("dense_topk_host: ") + hipGetErrorString(e != hipSuccess ? e : e2);
-        return RAG_ERR_HIP;
-    }
+    char* p = (char*)h->stage;
+    float* qd = stage_take<float>(p, (size_t)Q * h->dim);
+    int64_t* ids_d = stage_take<int64_t>(p, n_out);
+    double* sc_d = stage_take<double>(p, n_out);
+    int32_t* rows_d = stage_take<int32_t>(p, n_out);
+    HIP_TRY(h, hipMemcpyAsync(qd, q_host, (size_t)Q * h->dim * sizeof(float), hipMemcpyHostToDevice, st));
+    rc = dense_search(h, qd, Q, k, tenant, ids_d, rows_d, sc_d, st);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(ids_out, ids_d, n_out * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    if (rows_out) HIP_TRY(h, hipMemcpyAsync(rows_out, rows_d, n_out * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(scores_out, sc_d, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
     return RAG_OK;
 }
 
 int rag_dense_last_stats(rag_handle_t h, rag_dense_stats* out) {
     if (!h || !out) return RAG_ERR_ARG;
+    LOCK(h);
     ARG_CHECK(h, h->last_stats_valid && h->stats, "no dense search has run");
     int s[8];
     HIP_TRY(h, hipSetDevice(h->device));
@@ -307,6 +310,7 @@ int rag_dense_last_stats(rag_handle_t h, rag_dense_stats* out) {
 
 int rag_dense_kernel_ms(rag_handle_t h, float* gemm_ms_out, int* launches_out) {
     if (!h || !gemm_ms_out || !launches_out) return RAG_ERR_ARG;
+    LOCK(h);
     ARG_CHECK(h, h->profiling && h->gemm_events_used > 0, "profiling not enabled or no search ran");
     HIP_TRY(h, hipSetDevice(h->device));
     float total = 0.f;
@@ -324,6 +328,7 @@ int rag_dense_kernel_ms(rag_handle_t h, float* gemm_ms_out, int* launches_out) {
 int rag_merge_topk_dev(rag_handle_t h, const int64_t* ids_dev, const double* scores_dev, int n_lists, int64_t list_stride,
                        int Q, int k, int64_t* ids_out_dev, double* scores_out_dev, void* stream) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     ARG_CHECK(h, ids_dev && scores_dev && ids_out_dev && scores_out_dev, "null pointer");
     HIP_TRY(h, hipSetDevice(h->device));
     return merge_topk(h, ids_dev, scores_dev, n_lists, list_stride, Q, k, ids_out_dev, scores_out_dev,
@@ -332,36 +337,32 @@ int rag_merge_topk_dev(rag_handle_t h, const int64_t* ids_dev, const double* sco
 
 int rag_pairwise_cosine_host(rag_handle_t h, const float* a, int m, const float* b, int n, int dim, double* out) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     ARG_CHECK(h, m >= 0 && n >= 0 && dim > 0, "bad sizes");
     if (m == 0 || n == 0) return RAG_OK;
     ARG_CHECK(h, a && b && out, "null pointer");
     HIP_TRY(h, hipSetDevice(h->device));
-    float *ad = nullptr, *bd = nullptr;
-    double* od = nullptr;
     const bool same = (a == b && m == n);
-    HIP_TRY(h, hipMalloc(&ad, (size_t)m * dim * sizeof(float)));
-    hipError_t e = hipSuccess;
-    if (!same) e = hipMalloc(&bd, (size_t)n * dim * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&od, (size_t)m * n * sizeof(double));
-    if (e == hipSuccess) e = hipMemcpyAsync(ad, a, (size_t)m * dim * sizeof(float), hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess && !same) e = hipMemcpyAsync(bd, b, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, h->stream);
-    int rc = RAG_OK;
-    if (e == hipSuccess) rc = pairwise_cosine(h, ad, m, same ? ad : bd, n, dim, od, h->stream);
-    if (e == hipSuccess && rc == RAG_OK)
-        e = hipMemcpyAsync(out, od, (size_t)m * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-    hipError_t e2 = hipStreamSynchronize(h->stream);
-    hipFree(ad); hipFree(bd); hipFree(od);
+    hipStream_t st = h->stream;
+    int rc = stage_reserve(h, stage_size((size_t)m * dim, 4) + stage_size(same ? 0 : (size_t)n * dim, 4) + stage_size((size_t)m * n, 8));
     if (rc) return rc;
-    if (e != hipSuccess || e2 != hipSuccess) {
-        h->err = std::string("pairwise_cosine_host: ") + hipGetErrorString(e != hipSuccess ? e : e2);
-        return RAG_ERR_HIP;
-    }
+    char* p = (char*)h->stage;
+    float* ad = stage_take<float>(p, (size_t)m * dim);
+    float* bd = same ? ad : stage_take<float>(p, (size_t)n * dim);
+    double* od = stage_take<double>(p, (size_t)m * n);
+    HIP_TRY(h, hipMemcpyAsync(ad, a, (size_t)m * dim * sizeof(float), hipMemcpyHostToDevice, st));
+    if (!same) HIP_TRY(h, hipMemcpyAsync(bd, b, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, st));
+    rc = pairwise_cosine(h, ad, m, bd, n, dim, od, st);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(out, od, (size_t)m * n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
     return RAG_OK;
 }
 
 int rag_rrf_fuse_host(rag_handle_t h, const int64_t* lists, int Q, int L, int len, int rrf_k, int top_k, int64_t* keys_out,
                       double* scores_out, int32_t* ranks_out) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return rrf_fuse_host(h, lists, Q, L, len, rrf_k, top_k, keys_out, scores_out, ranks_out);
 }
@@ -369,6 +370,7 @@ int rag_rrf_fuse_host(rag_handle_t h, const int64_t* lists, int Q, int L, int le
 int rag_linear_fuse_topk_host(rag_handle_t h, const double* sem, const double* kw, const double* tmp, int n, double a,
                               double b, double g, int top_k, int32_t* idx_out, double* hyb_out) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return linear_fuse_topk_host(h, sem, kw, tmp, n, a, b, g, top_k, idx_out, hyb_out);
 }
@@ -376,28 +378,32 @@ int rag_linear_fuse_topk_host(rag_handle_t h, const double* sem, const double* k
 int rag_bm25_load_host(rag_handle_t h, const int64_t* indptr, const int32_t* doc, const int32_t* tf, const int32_t* doc_len,
                        const double* idf, int64_t n_docs, int64_t n_terms, double avgdl, double k1, double b) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return bm25_load_host(h, indptr, doc, tf, doc_len, idf, n_docs, n_terms, avgdl, k1, b);
 }
 
-int rag_bm25_topk_host(rag_handle_t h, const int32_t* term_ptr, const int32_t* terms, int Q, int k, int64_t* ids_out,
+int rag_bm25_topk_host(rag_handle_t h, const int32_t* term_ptr, const int32_t* terms, int Q, int k, int tenant, int64_t* ids_out,
                        int32_t* rows_out, double* scores_out, double* raw_max_out) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
-    return bm25_topk_host(h, term_ptr, terms, Q, k, ids_out, rows_out, scores_out, raw_max_out);
+    return bm25_topk_host(h, term_ptr, terms, Q, k, tenant, ids_out, rows_out, scores_out, raw_max_out);
 }
 
-int rag_bm25_topk_dev(rag_handle_t h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int64_t* ids_dev,
+int rag_bm25_topk_dev(rag_handle_t h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int tenant, int64_t* ids_dev,
                       int32_t* rows_dev, double* scores_dev, double* raw_max_dev, void* stream) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
-    return bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, k, ids_dev, rows_dev, scores_dev, raw_max_dev,
+    return bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, k, tenant, ids_dev, rows_dev, scores_dev, raw_max_dev,
                          (hipStream_t)stream);
 }
 
 int rag_rrf_fuse_dev(rag_handle_t h, const int64_t* lists_dev, int Q, int L, int len, int rrf_k, int top_k, int64_t* keys_dev,
                      double* scores_dev, int32_t* ranks_dev, void* stream) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return rrf_fuse_dev(h, lists_dev, Q, L, len, len, (int64_t)L * len, rrf_k, top_k, keys_dev, scores_dev, ranks_dev,
                         (hipStream_t)stream);
@@ -410,36 +416,51 @@ int rag_hybrid_rrf_dev(rag_handle_t h, const float* q_dev, const int32_t* term_p
                        int k, int rrf_k, int tenant, int64_t* lists_ws_dev, double* scores_ws_dev, int64_t* keys_out_dev,
                        double* rrf_out_dev, int32_t* ranks_out_dev, void* stream) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     ARG_CHECK(h, q_dev && term_ptr_dev && lists_ws_dev && scores_ws_dev && keys_out_dev && rrf_out_dev, "hybrid: null pointer");
     ARG_CHECK(h, pool > 0 && pool <= RAG_MAX_K && k > 0, "hybrid: 0 < pool <= 256");
+    ARG_CHECK(h, bm25_n_docs(h) == h->n_rows, "hybrid: the BM25 postings must be row-aligned with the index (same number of documents)");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     int rc = dense_search(h, q_dev, Q, pool, tenant, lists_ws_dev, nullptr, scores_ws_dev, st);
     if (rc) return rc;
-    rc = bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, lists_ws_dev + (size_t)Q * pool, nullptr, scores_ws_dev, nullptr, st);
+    rc = bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, tenant, lists_ws_dev + (size_t)Q * pool, nullptr, scores_ws_dev, nullptr, st);
     if (rc) return rc;
     return rrf_fuse_dev(h, lists_ws_dev, Q, 2, pool, (int64_t)Q * pool, pool, rrf_k, k, keys_out_dev, rrf_out_dev, ranks_out_dev, st);
 }
 
 int rag_bm25_set_normalize(rag_handle_t h, int on) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     return bm25_set_normalize(h, on);
 }
 
 int rag_bm25_scores_host(rag_handle_t h, const int32_t* term_ptr, const int32_t* terms, int Q, double* out) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return bm25_scores_host(h, term_ptr, terms, Q, out);
 }
 
+int rag_bm25_scores_adhoc_host(rag_handle_t h, const int64_t* indptr, const int32_t* doc, const int32_t* tf, const int32_t* doc_len,
+                               const double* idf, int64_t n_docs, int64_t n_terms, double avgdl, double k1, double b,
+                               const int32_t* term_ptr, const int32_t* terms, int Q, double* out) {
+    if (!h) return RAG_ERR_ARG;
+    LOCK(h);
+    HIP_TRY(h, hipSetDevice(h->device));
+    return bm25_scores_adhoc_host(h, indptr, doc, tf, doc_len, idf, n_docs, n_terms, avgdl, k1, b, term_ptr, terms, Q, out);
+}
+
 int rag_ce_load_host(rag_handle_t h, const rag_ce_config* cfg, const float* const* tensors, int n) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return ce_load_host(h, cfg, tensors, n);
 }
 
 int rag_ce_score_host(rag_handle_t h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L, float* out) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return ce_score(h, ids, tt, lens, P, L, out, h->stream, true);
 }
@@ -447,6 +468,7 @@ int rag_ce_score_host(rag_handle_t h, const int32_t* ids, const int32_t* tt, con
 int rag_ce_score_dev(rag_handle_t h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L, float* out,
                      void* stream) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return ce_score(h, ids, tt, lens, P, L, out, (hipStream_t)stream, false);
 }
@@ -454,6 +476,7 @@ int rag_ce_score_dev(rag_handle_t h, const int32_t* ids, const int32_t* tt, cons
 int rag_mmr_select_host(rag_handle_t h, const float* query, const float* emb, int n, int dim, int top_k, double lambda,
                         int variant, int32_t* sel_out, double* score_out) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return mmr_select_host(h, query, emb, n, dim, top_k, lambda, variant, sel_out, score_out);
 }
@@ -462,6 +485,7 @@ int rag_mmr_select_host(rag_handle_t h, const float* query, const float* emb, in
 int rag_mmr_select_dev(rag_handle_t h, const float* q_dev, const int32_t* rows_dev, int Q, int pool, int top_k, double lambda,
                        int variant, int32_t* sel_dev, double* score_dev, void* stream) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     ARG_CHECK(h, h->emb32 != nullptr && rows_dev, "mmr_select_dev: no index loaded / null rows");
     HIP_TRY(h, hipSetDevice(h->device));
     return mmr_select_dev(h, q_dev, h->emb32, rows_dev, Q, pool, h->dim, top_k, lambda, variant, sel_dev, score_dev,
@@ -471,12 +495,14 @@ int rag_mmr_select_dev(rag_handle_t h, const float* q_dev, const int32_t* rows_d
 int rag_chunk_chain_host(rag_handle_t h, const float* emb, const int32_t* sent_len, int n, int dim, double threshold,
                          int max_chunk, int min_chunk, int32_t* group_out) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return chunk_chain_host(h, emb, sent_len, n, dim, threshold, max_chunk, min_chunk, group_out);
 }
 
 int rag_tokens_load_host(rag_handle_t h, const int32_t* tokens, const int32_t* lens, int64_t n_rows, int L) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return tokens_load_host(h, tokens, lens, n_rows, L);
 }
@@ -486,6 +512,7 @@ int rag_retrieve_rerank_dev(rag_handle_t h, const float* q_emb_dev, const int32_
                             int tenant, int mode, int cls_id, int sep_id, int L_pair, int64_t* ids_out_dev,
                             double* scores_out_dev, float* logits_out_dev, int64_t* cand_out_dev, void* stream) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return retrieve_rerank_dev(h, q_emb_dev, term_ptr_dev, terms_dev, q_tok_dev, q_len_dev, Lq, Q, pool, k, rrf_k, tenant, mode,
                                cls_id, sep_id, L_pair, ids_out_dev, scores_out_dev, logits_out_dev, cand_out_dev,
@@ -496,6 +523,7 @@ int rag_ce_build_pairs_dev(rag_handle_t h, const int32_t* q_tok_dev, const int32
                            int pool, int64_t token_id_base, int L_pair, int cls_id, int sep_id, int32_t* ids_out_dev,
                            int32_t* tt_out_dev, int32_t* lens_out_dev, void* stream) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return ce_build_pairs_dev(h, q_tok_dev, q_len_dev, Lq, cand_dev, Q, pool, token_id_base, L_pair, cls_id, sep_id, ids_out_dev,
                               tt_out_dev, lens_out_dev, (hipStream_t)stream);
@@ -504,6 +532,7 @@ int rag_ce_build_pairs_dev(rag_handle_t h, const int32_t* q_tok_dev, const int32
 int rag_rerank_topk_dev(rag_handle_t h, const float* logits_dev, const int64_t* cand_dev, int Q, int pool, int k, int64_t* ids_out_dev,
                         double* scores_out_dev, float* logits_out_dev, void* stream) {
     if (!h) return RAG_ERR_ARG;
+    LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return rerank_topk_dev(h, logits_dev, cand_dev, Q, pool, k, ids_out_dev, scores_out_dev, logits_out_dev, (hipStream_t)stream);
 }

@@ -44,6 +44,9 @@ struct rag_bm25_index {
     int ws_tau_q = 0;
     int* ws_cnt = nullptr;             // [ws_cnt_n] valid entries per (query, range) partial list
     size_t ws_cnt_n = 0;
+    uint64_t* ws_run_key = nullptr;    // [ws_run_n] running top-k of every query across the threshold stages
+    uint32_t* ws_run_row = nullptr;
+    size_t ws_run_n = 0;
     double avgdl = 0, k1 = 1.5, b = 0.75;
     int normalize = 1;                 // 0: top-k scores stay raw (row-sharded search divides by the GLOBAL max after the merge)
 };
@@ -100,7 +103,8 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
                                                                  int64_t n_docs, int64_t n_terms, int k, int mode,
                                                                  double* __restrict__ dense_out, uint64_t* __restrict__ part_key,
                                                                  uint32_t* __restrict__ part_row, int range_begin,
-                                                                 const uint64_t* __restrict__ tau_key, int* __restrict__ part_cnt) {
+                                                                 const uint64_t* __restrict__ tau_key, int* __restrict__ part_cnt,
+                                                                 const int32_t* __restrict__ tenants, int tenant) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sc = reinterpret_cast<double*>(smem);                       // [BM_RANGE]
     int* hist = reinterpret_cast<int*>(smem + BM_SC_DOUBLES * 8);       // [256]
@@ -212,9 +216,12 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
     // ---- exact top-k of sc[0..lim): radix select of the k-th largest key, ties by lower doc ------------
     const size_t po = ((size_t)q * n_ranges + r) * k;
     // part_cnt[q][r] = number of valid entries at the front of this (query, range) slot group; the merge only reads those
+    // Tenant filter (`WHERE agent_id = %s`, rag/document_store.py:457): a document of another tenant is an EMPTY slot
+    // (key 0, below every real score) from here on, so it can neither enter a partial list nor move the threshold.
     if (lim <= k) {
         for (int i = tid; i < k; i += BM_THREADS) {
-            part_key[po + i] = i < lim ? f64_orderable(sc[SC_IDX(i)]) : 0ull;
+            const bool mine = i < lim && (tenants == nullptr || tenants[base + i] == tenant);
+            part_key[po + i] = mine ? f64_orderable(sc[SC_IDX(i)]) : 0ull;
             part_row[po + i] = (uint32_t)(base + i);
         }
         if (tid == 0) part_cnt[(size_t)q * n_ranges + r] = lim;
@@ -224,6 +231,11 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
     uint64_t keys[BM_SEG];           // this thread's 32 docs, read once (conflict-free thanks to the padding)
 #pragma unroll
     for (int j = 0; j < BM_SEG; ++j) keys[j] = (seg0 + j) < lim ? f64_orderable(sc[SC_IDX(seg0 + j)]) : 0ull;
+    if (tenants != nullptr) {
+#pragma unroll
+        for (int j = 0; j < BM_SEG; ++j)
+            if ((seg0 + j) < lim && tenants[base + seg0 + j] != tenant) keys[j] = 0ull;
+    }
     // Thresholded ranges (second stage, see bm25_launch_topk): tau_key[q] is the k-th best key over the first-stage
     // ranges, a lower bound of the global k-th. Only keys >= tau can reach the global top-k; a later range holds
     // about k * 16384 / (docs of stage one) of them, so they are compacted in doc order (the merge sorts anyway) and the
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
     if (tau_key != nullptr) {
         int n_in = 0;
 #pragma unroll
-        for (int j = 0; j < BM_SEG; ++j) n_in += (seg0 + j) < lim && keys[j] >= tk;
+        for (int j = 0; j < BM_SEG; ++j) n_in += keys[j] != 0ull && keys[j] >= tk;
         int sc_in = n_in;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
         if (total_in <= k) {
 #pragma unroll
             for (int j = 0; j < BM_SEG; ++j)
-                if ((seg0 + j) < lim && keys[j] >= tk) {
+                if (keys[j] != 0ull && keys[j] >= tk) {
                     part_key[po + off] = keys[j];
                     part_row[po + off] = (uint32_t)(base + seg0 + j);
                     ++off;
@@ -370,71 +382,40 @@ __device__ __forceinline__ void bm_sort_pairs(uint64_t* k1, uint32_t* k2, int P,
     }
 }
 
-// k-th best key of the first-stage partial lists of a query (n_first ranges x k slots, 0 = empty) -> tau_key[q];
-// 0 (everything passes) when the first stage found fewer than k docs. One workgroup per query, bitonic sort in LDS.
-__global__ __launch_bounds__(256) void bm25_tau_kernel(const uint64_t* __restrict__ part_key, int n_ranges, int n_first, int k,
-                                                        uint64_t* __restrict__ tau_key) {
-    extern __shared__ uint64_t tk_s[];
-    const int q = blockIdx.x, tid = threadIdx.x;
-    const int n = n_first * k;
-    int P = 1;
-    while (P < n) P <<= 1;
-    const uint64_t* pk = part_key + (size_t)q * n_ranges * k;          // the first-stage ranges are ranges 0..n_first-1
-    for (int i = tid; i < P; i += 256) tk_s[i] = i < n ? pk[i] : 0ull;
-    __syncthreads();
-    for (int kk = 2; kk <= P; kk <<= 1)
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const bool desc = (i & kk) == 0;
-                    const uint64_t a = tk_s[i], b = tk_s[ixj];
-                    if (desc ? a < b : a > b) { tk_s[i] = b; tk_s[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    if (tid == 0) tau_key[q] = tk_s[k - 1];                             // 0 if fewer than k real keys
-}
-
 #define BM_FIRST_RANGES 2      // exact per-range top-k for these (32768 docs), thresholded compaction for the rest (measured: 1 -> 7.5 ms, 2 -> 4.87, 4 -> 5.08)
+#define BM_STAGE_GROWTH 8      // every thresholded stage covers up to 8x the ranges seen before it
 
-// all ranges -> per-range partial lists part_key/part_row [Q][n_ranges][k]; tau_dev: scratch [Q]
-static void bm25_launch_topk(const rag_bm25_index* ix, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k,
-                             uint64_t* part_key, uint32_t* part_row, uint64_t* tau_dev, int* part_cnt, hipStream_t st) {
-    const int nr = ix->n_ranges;
-    static const int first_cfg = [] { const char* e = getenv("RAG_BM25_FIRST_RANGES"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? v : BM_FIRST_RANGES; }();
-    const bool staged = nr > 2 * first_cfg && tau_dev != nullptr && !getenv("RAG_BM25_NO_STAGING");
-    const int first = staged ? first_cfg : nr;
-    hipLaunchKernelGGL(bm25_range_kernel, dim3(first, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc, ix->w, ix->idf,
-                       ix->range_off, nr, term_ptr_dev, terms_dev, ix->n_docs, ix->n_terms, k, 0, (double*)nullptr, part_key,
-                       part_row, 0, (const uint64_t*)nullptr, part_cnt);
-    if (!staged) return;
-    int P = 1;
-    while (P < first * k) P <<= 1;
-    hipLaunchKernelGGL(bm25_tau_kernel, dim3(Q), dim3(256), (size_t)P * sizeof(uint64_t), st, part_key, nr, first, k, tau_dev);
-    hipLaunchKernelGGL(bm25_range_kernel, dim3(nr - first, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc, ix->w,
-                       ix->idf, ix->range_off, nr, term_ptr_dev, terms_dev, ix->n_docs, ix->n_terms, k, 0, (double*)nullptr,
-                       part_key, part_row, first, (const uint64_t*)tau_dev, part_cnt);
-}
-
-__global__ __launch_bounds__(256) void bm25_merge_kernel(const uint64_t* __restrict__ part_key, const uint32_t* __restrict__ part_row,
-                                                          int n_ranges, int k, const int64_t* __restrict__ idmap,
-                                                          int64_t id_base, int64_t* __restrict__ ids_out,
-                                                          int32_t* __restrict__ rows_out, double* __restrict__ scores_out,
-                                                          double* __restrict__ raw_max_out, int normalize,
-                                                          const int* __restrict__ part_cnt) {
+// Folds the partial lists of the doc ranges [r_begin, r_end) into the query's RUNNING top-k (run_key / run_row [Q][k], key 0 =
+// empty) and publishes tau_key[q] = its k-th key: a lower bound of the global k-th best, 0 ("everything passes") while fewer
+// than k documents have been seen. One workgroup per query; windows of BM_MERGE - k new entries, bitonic sort in LDS.
+// A thresholded range fills only the first part_cnt[q][r] of its k slots and the rest of the slot group holds whatever an
+// earlier batch left there, so ONLY the counted fronts are read, for any number of ranges: they are walked in groups of 256
+// (one prefix scan per group; a 12.5M-document shard has 763 ranges).
+// last != 0: the running list is final -> ids / rows / scores (divided by max if > 0 else 1.0, rag/retrieval.py:343-345).
+__global__ __launch_bounds__(256) void bm25_merge_stage_kernel(const uint64_t* __restrict__ part_key, const uint32_t* __restrict__ part_row,
+                                                                const int* __restrict__ part_cnt, int n_ranges, int r_begin, int r_end,
+                                                                int k, uint64_t* __restrict__ run_key, uint32_t* __restrict__ run_row,
+                                                                int first, uint64_t* __restrict__ tau_key, int last,
+                                                                const int64_t* __restrict__ idmap, int64_t id_base,
+                                                                int64_t* __restrict__ ids_out, int32_t* __restrict__ rows_out,
+                                                                double* __restrict__ scores_out, double* __restrict__ raw_max_out,
+                                                                int normalize) {
     __shared__ uint64_t sk[BM_MERGE];
     __shared__ uint32_t sr[BM_MERGE];
-    __shared__ int pre[257];                        // exclusive prefix of the per-range entry counts (n_ranges <= 256)
+    __shared__ int pre[257];                        // exclusive prefix of the entry counts of the current group of <= 256 ranges
     __shared__ int wtot[4];
     const int q = blockIdx.x, tid = threadIdx.x;
     const uint64_t* pk = part_key + (size_t)q * n_ranges * k;
     const uint32_t* pr = part_row + (size_t)q * n_ranges * k;
-    const bool compact = part_cnt != nullptr && n_ranges <= 256;      // thresholded ranges fill only a part of their k slots
-    int total = n_ranges * k;
-    if (compact) {
-        const int c = tid < n_ranges ? part_cnt[(size_t)q * n_ranges + tid] : 0;
+    for (int i = tid; i < BM_MERGE; i += 256) {
+        const bool keep = !first && i < k;
+        sk[i] = keep ? run_key[(size_t)q * k + i] : 0ull;
+        sr[i] = keep ? run_row[(size_t)q * k + i] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (int r0 = r_begin; r0 < r_end; r0 += 256) {
+        const int nr = min(256, r_end - r0);
+        const int c = tid < nr ? min(part_cnt[(size_t)q * n_ranges + r0 + tid], k) : 0;
         int incl = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -448,37 +429,40 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(const uint64_t* __restr
         pre[tid + 1] = off + incl;
         if (tid == 0) pre[0] = 0;
         __syncthreads();
-        total = pre[n_ranges];
-    }
-    for (int i = tid; i < BM_MERGE; i += 256) { sk[i] = 0ull; sr[i] = 0xFFFFFFFFu; }
-    __syncthreads();
-    int pos = 0;
-    while (pos < total) {
-        const int room = BM_MERGE - k;
-        const int take = min(room, total - pos);
-        for (int i = tid; i < room; i += 256) {
-            uint64_t key = 0ull;
-            uint32_t row = 0xFFFFFFFFu;
-            if (i < take) {
-                int slot = pos + i;
-                if (compact) {                      // entry e -> range r with pre[r] <= e < pre[r+1] -> slot r*k + (e - pre[r])
-                    int lo = 0, hi = n_ranges;
+        const int total = pre[nr];
+        int pos = 0;
+        while (pos < total) {
+            const int room = BM_MERGE - k;
+            const int take = min(room, total - pos);
+            for (int i = tid; i < room; i += 256) {
+                uint64_t key = 0ull;
+                uint32_t row = 0xFFFFFFFFu;
+                if (i < take) {                     // entry e -> range r with pre[r] <= e < pre[r+1] -> slot r*k + (e - pre[r])
+                    const int e = pos + i;
+                    int lo = 0, hi = nr;
                     while (hi - lo > 1) {
                         const int mid = (lo + hi) >> 1;
-                        if (pre[mid] <= slot) lo = mid; else hi = mid;
+                        if (pre[mid] <= e) lo = mid; else hi = mid;
                     }
-                    slot = lo * k + (slot - pre[lo]);
+                    const size_t slot = (size_t)(r0 + lo) * k + (e - pre[lo]);
+                    key = pk[slot];
+                    row = pr[slot];
                 }
-                key = pk[slot];
-                row = pr[slot];
+                sk[k + i] = key;
+                sr[k + i] = row;
             }
-            sk[k + i] = key;
-            sr[k + i] = row;
+            __syncthreads();
+            bm_sort_pairs(sk, sr, BM_MERGE, tid, 256);
+            pos += take;
         }
-        __syncthreads();
-        bm_sort_pairs(sk, sr, BM_MERGE, tid, 256);
-        pos += take;
+        __syncthreads();                            // every thread is done with pre[] / wtot[] before the next group's scan
     }
+    for (int i = tid; i < k; i += 256) {
+        run_key[(size_t)q * k + i] = sk[i];
+        run_row[(size_t)q * k + i] = sr[i];
+    }
+    if (tid == 0 && tau_key != nullptr) tau_key[q] = sk[k - 1];        // 0 if fewer than k real keys so far
+    if (!last) return;
     // top-1 raw score -> divisor (max if > 0 else 1.0), retrieval.py:344
     uint64_t u0 = sk[0];
     double mx = 1.0;
@@ -499,145 +483,201 @@ __global__ __launch_bounds__(256) void bm25_merge_kernel(const uint64_t* __restr
     }
 }
 
+// per-call device buffers of a top-k search: partial lists [Q][n_ranges][k], counts [Q][n_ranges], running list, threshold
+struct bm25_topk_ws {
+    uint64_t* part_key; uint32_t* part_row; int* part_cnt; uint64_t* run_key; uint32_t* run_row; uint64_t* tau;
+};
+struct bm25_topk_out {
+    const int64_t* idmap; int64_t id_base; int64_t* ids; int32_t* rows; double* scores; double* raw_max; int normalize;
+};
+
+// STAGED top-k over all doc ranges: ranges [0, first) get the exact per-range top-k; after every stage the running top-k
+// of the query gives tau (k-th best so far), and the next stage - up to BM_STAGE_GROWTH x the ranges seen so far - only
+// compacts keys >= tau. Expected survivors per stage ~ k * growth per query however large the shard is (a single
+// threshold from 32768 docs left ~k/2 per range: 38 k entries per query to merge on a 12.5M-doc shard).
+static void bm25_launch_topk(const rag_bm25_index* ix, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k,
+                             const bm25_topk_ws& w, const bm25_topk_out& o, const int32_t* tenants, int tenant, hipStream_t st) {
+    const int nr = ix->n_ranges;
+    static const int first_cfg = [] { const char* e = getenv("RAG_BM25_FIRST_RANGES"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? v : BM_FIRST_RANGES; }();
+    const bool staged = nr > 2 * first_cfg && !getenv("RAG_BM25_NO_STAGING");
+    int begin = 0, stage = 0;
+    while (begin < nr) {
+        int end = !staged ? nr : (stage == 0 ? first_cfg : (int)std::min<int64_t>(nr, (int64_t)begin * BM_STAGE_GROWTH));
+        if (staged && nr - end < end / 4) end = nr;                   // no tiny trailing stage
+        hipLaunchKernelGGL(bm25_range_kernel, dim3(end - begin, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc, ix->w,
+                           ix->idf, ix->range_off, nr, term_ptr_dev, terms_dev, ix->n_docs, ix->n_terms, k, 0, (double*)nullptr,
+                           w.part_key, w.part_row, begin, stage == 0 ? (const uint64_t*)nullptr : (const uint64_t*)w.tau, w.part_cnt,
+                           tenants, tenant);
+        const int last = end == nr;
+        hipLaunchKernelGGL(bm25_merge_stage_kernel, dim3(Q), dim3(256), 0, st, w.part_key, w.part_row, w.part_cnt, nr, begin, end, k,
+                           w.run_key, w.run_row, stage == 0 ? 1 : 0, w.tau, last, o.idmap, o.id_base, o.ids, o.rows, o.scores,
+                           o.raw_max, o.normalize);
+        begin = end;
+        ++stage;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
+static void bm25_index_free(rag_bm25_index* ix) {
+    if (!ix) return;
+    hipFree(ix->indptr); hipFree(ix->doc); hipFree(ix->w); hipFree(ix->idf); hipFree(ix->range_off);
+    hipFree(ix->ws_key); hipFree(ix->ws_row); hipFree(ix->ws_tau); hipFree(ix->ws_cnt); hipFree(ix->ws_run_key); hipFree(ix->ws_run_row);
+    delete ix;
+}
+
 void bm25_free(rag_ctx* h) {
-    if (!h->bm25) return;
-    hipFree(h->bm25->indptr); hipFree(h->bm25->doc); hipFree(h->bm25->w); hipFree(h->bm25->idf); hipFree(h->bm25->range_off);
-    hipFree(h->bm25->ws_key); hipFree(h->bm25->ws_row); hipFree(h->bm25->ws_tau); hipFree(h->bm25->ws_cnt);
-    delete h->bm25;
+    bm25_index_free(h->bm25);
     h->bm25 = nullptr;
 }
 
-int bm25_load_host(rag_ctx* h, const int64_t* indptr, const int32_t* doc, const int32_t* tf, const int32_t* doc_len,
-                   const double* idf, int64_t n_docs, int64_t n_terms, double avgdl, double k1, double b) {
+// host CSR -> device index (impacts + range table). Synchronous. On failure *out is freed and left null.
+static int bm25_build(rag_ctx* h, const int64_t* indptr, const int32_t* doc, const int32_t* tf, const int32_t* doc_len,
+                      const double* idf, int64_t n_docs, int64_t n_terms, double avgdl, double k1, double b, rag_bm25_index** out) {
+    *out = nullptr;
     ARG_CHECK(h, n_docs > 0 && n_terms >= 0 && n_docs < 0x7fffffff, "bm25_load: bad sizes");
     ARG_CHECK(h, indptr && doc_len && (n_terms == 0 || idf), "bm25_load: null pointer");
     const int64_t nnz = n_terms ? indptr[n_terms] : 0;
     ARG_CHECK(h, nnz == 0 || (doc && tf), "bm25_load: null postings");
-    bm25_free(h);
     rag_bm25_index* ix = new rag_bm25_index();
-    h->bm25 = ix;
     ix->n_docs = n_docs; ix->n_terms = n_terms; ix->nnz = nnz; ix->avgdl = avgdl; ix->k1 = k1; ix->b = b;
     hipStream_t st = h->stream;
     int32_t *tfd = nullptr, *dld = nullptr;
-    HIP_TRY(h, hipMalloc(&ix->indptr, (size_t)(n_terms + 1) * sizeof(int64_t)));
-    // + 4 postings of padding: the scoring kernel reads 4 consecutive postings per thread without a bounds branch
-    HIP_TRY(h, hipMalloc(&ix->doc, (size_t)(nnz + 4) * sizeof(int32_t)));
-    HIP_TRY(h, hipMalloc(&ix->w, (size_t)(nnz + 4) * sizeof(double)));
-    HIP_TRY(h, hipMemsetAsync(ix->doc + nnz, 0, 4 * sizeof(int32_t), h->stream));
-    HIP_TRY(h, hipMemsetAsync(ix->w + nnz, 0, 4 * sizeof(double), h->stream));
-    HIP_TRY(h, hipMalloc(&ix->idf, std::max<size_t>(1, n_terms) * sizeof(double)));
-    HIP_TRY(h, hipMalloc(&tfd, std::max<size_t>(1, nnz) * sizeof(int32_t)));
-    HIP_TRY(h, hipMalloc(&dld, (size_t)n_docs * sizeof(int32_t)));
-    HIP_TRY(h, hipMemcpyAsync(ix->indptr, indptr, (size_t)(n_terms + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    if (nnz) {
-        HIP_TRY(h, hipMemcpyAsync(ix->doc, doc, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(h, hipMemcpyAsync(tfd, tf, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    }
-    if (n_terms) HIP_TRY(h, hipMemcpyAsync(ix->idf, idf, (size_t)n_terms * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(h, hipMemcpyAsync(dld, doc_len, (size_t)n_docs * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    if (nnz) {
-        hipLaunchKernelGGL(bm25_weights_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, ix->indptr, ix->doc, tfd,
-                           dld, nnz, avgdl, k1, b, ix->idf, n_terms, ix->w);
-        HIP_TRY(h, hipGetLastError());
-    }
     ix->n_ranges = (int)((n_docs + BM_RANGE - 1) / BM_RANGE);
     const int64_t n_tab = n_terms * (int64_t)(ix->n_ranges + 1);
-    HIP_TRY(h, hipMalloc(&ix->range_off, std::max<size_t>(1, (size_t)n_tab) * sizeof(int32_t)));
-    if (n_tab) {
+    // + 4 postings of padding: the scoring kernel reads 4 consecutive postings per thread without a bounds branch
+    hipError_t e = hipMalloc(&ix->indptr, (size_t)(n_terms + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(&ix->doc, (size_t)(nnz + 4) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&ix->w, (size_t)(nnz + 4) * sizeof(double));
+    if (e == hipSuccess) e = hipMemsetAsync(ix->doc + nnz, 0, 4 * sizeof(int32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(ix->w + nnz, 0, 4 * sizeof(double), st);
+    if (e == hipSuccess) e = hipMalloc(&ix->idf, std::max<size_t>(1, n_terms) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&tfd, std::max<size_t>(1, nnz) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&dld, (size_t)n_docs * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&ix->range_off, std::max<size_t>(1, (size_t)n_tab) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(ix->indptr, indptr, (size_t)(n_terms + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && nnz) e = hipMemcpyAsync(ix->doc, doc, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && nnz) e = hipMemcpyAsync(tfd, tf, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_terms) e = hipMemcpyAsync(ix->idf, idf, (size_t)n_terms * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(dld, doc_len, (size_t)n_docs * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && nnz) {
+        hipLaunchKernelGGL(bm25_weights_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, ix->indptr, ix->doc, tfd,
+                           dld, nnz, avgdl, k1, b, ix->idf, n_terms, ix->w);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && n_tab) {
         hipLaunchKernelGGL(bm25_range_table_kernel, dim3((unsigned)((n_tab + 255) / 256)), dim3(256), 0, st, ix->indptr, ix->doc,
                            n_terms, ix->n_ranges, ix->range_off);
-        HIP_TRY(h, hipGetLastError());
+        e = hipGetLastError();
     }
-    HIP_TRY(h, hipStreamSynchronize(st));
+    const hipError_t e2 = hipStreamSynchronize(st);
     hipFree(tfd); hipFree(dld);
+    if (e != hipSuccess || e2 != hipSuccess) {
+        bm25_index_free(ix);
+        h->err = std::string("bm25_load: ") + hipGetErrorString(e != hipSuccess ? e : e2);
+        return RAG_ERR_HIP;
+    }
+    *out = ix;
     return RAG_OK;
 }
 
-static int bm25_run(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, int k, int mode, int64_t* ids_out,
-                    int32_t* rows_out, double* scores_out, double* raw_max_out, double* dense_out) {
-    ARG_CHECK(h, h->bm25 != nullptr, "no BM25 index loaded");
+int bm25_load_host(rag_ctx* h, const int64_t* indptr, const int32_t* doc, const int32_t* tf, const int32_t* doc_len,
+                   const double* idf, int64_t n_docs, int64_t n_terms, double avgdl, double k1, double b) {
+    rag_bm25_index* ix = nullptr;
+    const int rc = bm25_build(h, indptr, doc, tf, doc_len, idf, n_docs, n_terms, avgdl, k1, b, &ix);
+    if (rc) return rc;
+    bm25_free(h);
+    h->bm25 = ix;
+    return RAG_OK;
+}
+
+static int bm25_set_attr(rag_ctx* h) {
+    if (!h->attr_bm25) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bm25_range_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, BM_LDS_BYTES));
+        h->attr_bm25 = true;
+    }
+    return RAG_OK;
+}
+
+static int bm25_tenant_args(rag_ctx* h, const rag_bm25_index* ix, int tenant, const int32_t** tenants_out) {
+    *tenants_out = nullptr;
+    if (tenant < 0) return RAG_OK;
+    ARG_CHECK(h, h->tenants != nullptr && h->n_rows == ix->n_docs,
+              "bm25: a tenant filter needs rag_index_set_tenants_host and postings row-aligned with the index");
+    *tenants_out = h->tenants;
+    return RAG_OK;
+}
+
+// host-pointer search against `ix` (the resident index or an ad-hoc one). Device staging comes from the handle's
+// grow-only arena: no hipMalloc / hipFree per call.
+static int bm25_run(rag_ctx* h, rag_bm25_index* ix, const int32_t* term_ptr, const int32_t* terms, int Q, int k, int mode, int tenant,
+                    int64_t* ids_out, int32_t* rows_out, double* scores_out, double* raw_max_out, double* dense_out) {
+    ARG_CHECK(h, ix != nullptr, "no BM25 index loaded");
     ARG_CHECK(h, Q > 0 && Q <= 65535 && term_ptr, "bm25: 1 <= n_queries <= 65535");
-    rag_bm25_index* ix = h->bm25;
     const int n_terms_q = term_ptr[Q];
     ARG_CHECK(h, n_terms_q >= 0 && (n_terms_q == 0 || terms), "bm25: bad term arrays");
     if (mode == 0) ARG_CHECK(h, k > 0 && k <= BM_MERGE / 2 && k <= BM_RANGE, "bm25: 0 < k <= 1024");
+    const int32_t* tenants = nullptr;
+    int rc = bm25_tenant_args(h, ix, mode == 0 ? tenant : -1, &tenants);
+    if (rc) return rc;
+    if ((rc = bm25_set_attr(h))) return rc;
     hipStream_t st = h->stream;
-    const int n_ranges = (int)((ix->n_docs + BM_RANGE - 1) / BM_RANGE);
-    bool& attr = h->attr_bm25;
-    if (!attr) {
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bm25_range_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, BM_LDS_BYTES));
-        attr = true;
-    }
-    int32_t *tp = nullptr, *tm = nullptr;
-    uint64_t* pk = nullptr;
-    uint32_t* pr = nullptr;
-    int64_t* idd = nullptr;
-    int32_t* rwd = nullptr;
-    double *scd = nullptr, *mxd = nullptr, *dd = nullptr;
-    hipError_t e = hipMalloc(&tp, (size_t)(Q + 1) * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&tm, std::max<size_t>(1, n_terms_q) * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMemcpyAsync(tp, term_ptr, (size_t)(Q + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && n_terms_q) e = hipMemcpyAsync(tm, terms, (size_t)n_terms_q * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    const int nr = ix->n_ranges;
+    const size_t n_part = mode == 0 ? (size_t)Q * nr * k : 0, n_out = mode == 0 ? (size_t)Q * k : 0;
+    const size_t n_dense = mode == 1 ? (size_t)Q * ix->n_docs : 0;
+    size_t total = stage_size(Q + 1, 4) + stage_size(std::max(1, n_terms_q), 4) + stage_size(n_part, 8) + stage_size(n_part, 4) +
+                   stage_size((size_t)Q * nr, 4) + 2 * stage_size(n_out, 8) + 2 * stage_size(n_out, 4) + 2 * stage_size(Q, 8) +
+                   stage_size(n_out, 8) + stage_size(n_dense, 8);
+    if ((rc = stage_reserve(h, total))) return rc;
+    char* p = (char*)h->stage;
+    int32_t* tp = stage_take<int32_t>(p, Q + 1);
+    int32_t* tm = stage_take<int32_t>(p, std::max(1, n_terms_q));
+    bm25_topk_ws w;
+    w.part_key = stage_take<uint64_t>(p, n_part);
+    w.part_row = stage_take<uint32_t>(p, n_part);
+    w.part_cnt = stage_take<int>(p, (size_t)Q * nr);
+    w.run_key = stage_take<uint64_t>(p, n_out);
+    w.run_row = stage_take<uint32_t>(p, n_out);
+    w.tau = stage_take<uint64_t>(p, Q);
+    int64_t* idd = stage_take<int64_t>(p, n_out);
+    int32_t* rwd = stage_take<int32_t>(p, n_out);
+    double* mxd = stage_take<double>(p, Q);
+    double* scd = stage_take<double>(p, n_out);
+    double* dd = stage_take<double>(p, n_dense);
+    HIP_TRY(h, hipMemcpyAsync(tp, term_ptr, (size_t)(Q + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (n_terms_q) HIP_TRY(h, hipMemcpyAsync(tm, terms, (size_t)n_terms_q * sizeof(int32_t), hipMemcpyHostToDevice, st));
     if (mode == 0) {
-        if (e == hipSuccess) e = hipMalloc(&pk, (size_t)Q * n_ranges * k * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipMalloc(&pr, (size_t)Q * n_ranges * k * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&idd, (size_t)Q * k * sizeof(int64_t));
-        if (e == hipSuccess) e = hipMalloc(&rwd, (size_t)Q * k * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc(&scd, (size_t)Q * k * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc(&mxd, (size_t)Q * sizeof(double));
+        const bool aligned = ix == h->bm25 && h->n_rows == ix->n_docs;
+        const bm25_topk_out o = {aligned ? h->ids : (const int64_t*)nullptr, aligned ? h->id_base : (int64_t)0, idd, rwd, scd, mxd,
+                                 ix->normalize};
+        bm25_launch_topk(ix, tp, tm, Q, k, w, o, tenants, tenant, st);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(ids_out, idd, n_out * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        if (rows_out) HIP_TRY(h, hipMemcpyAsync(rows_out, rwd, n_out * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipMemcpyAsync(scores_out, scd, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (raw_max_out) HIP_TRY(h, hipMemcpyAsync(raw_max_out, mxd, (size_t)Q * sizeof(double), hipMemcpyDeviceToHost, st));
     } else {
-        if (e == hipSuccess) e = hipMalloc(&dd, (size_t)Q * ix->n_docs * sizeof(double));
+        hipLaunchKernelGGL(bm25_range_kernel, dim3(nr, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc, ix->w, ix->idf,
+                           ix->range_off, nr, tp, tm, ix->n_docs, ix->n_terms, k, 1, dd, (uint64_t*)nullptr, (uint32_t*)nullptr, 0,
+                           (const uint64_t*)nullptr, (int*)nullptr, (const int32_t*)nullptr, -1);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(dense_out, dd, n_dense * sizeof(double), hipMemcpyDeviceToHost, st));
     }
-    uint64_t* taud = nullptr;
-    int* cntd = nullptr;
-    if (e == hipSuccess && mode == 0) e = hipMalloc(&taud, (size_t)Q * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMalloc(&cntd, (size_t)Q * n_ranges * sizeof(int));
-    if (e == hipSuccess) {
-        if (mode == 0) {
-            bm25_launch_topk(ix, tp, tm, Q, k, pk, pr, taud, cntd, st);
-            hipLaunchKernelGGL(bm25_merge_kernel, dim3(Q), dim3(256), 0, st, pk, pr, n_ranges, k,
-                               h->n_rows == ix->n_docs ? h->ids : (const int64_t*)nullptr,
-                               h->n_rows == ix->n_docs ? h->id_base : (int64_t)0, idd, rwd, scd, mxd, ix->normalize, cntd);
-        } else {
-            hipLaunchKernelGGL(bm25_range_kernel, dim3(n_ranges, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc,
-                               ix->w, ix->idf, ix->range_off, ix->n_ranges, tp, tm, ix->n_docs, ix->n_terms, k, mode, dd, pk, pr,
-                               0, (const uint64_t*)nullptr, cntd);
-        }
-        e = hipGetLastError();
-    }
-    if (mode == 0) {
-        if (e == hipSuccess) e = hipMemcpyAsync(ids_out, idd, (size_t)Q * k * sizeof(int64_t), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && rows_out) e = hipMemcpyAsync(rows_out, rwd, (size_t)Q * k * sizeof(int32_t), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(scores_out, scd, (size_t)Q * k * sizeof(double), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && raw_max_out) e = hipMemcpyAsync(raw_max_out, mxd, (size_t)Q * sizeof(double), hipMemcpyDeviceToHost, st);
-    } else if (e == hipSuccess) {
-        e = hipMemcpyAsync(dense_out, dd, (size_t)Q * ix->n_docs * sizeof(double), hipMemcpyDeviceToHost, st);
-    }
-    hipError_t e2 = hipStreamSynchronize(st);
-    hipFree(tp); hipFree(tm); hipFree(pk); hipFree(pr); hipFree(idd); hipFree(rwd); hipFree(scd); hipFree(mxd); hipFree(dd);
-    hipFree(taud); hipFree(cntd);
-    if (e != hipSuccess || e2 != hipSuccess) {
-        h->err = std::string("bm25: ") + hipGetErrorString(e != hipSuccess ? e : e2);
-        return RAG_ERR_HIP;
-    }
+    HIP_TRY(h, hipStreamSynchronize(st));
     return RAG_OK;
 }
 
 // device-pointer entry: everything stays in HBM, asynchronous on `st` (workspace grows on first use / larger Q)
-int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int64_t* ids_dev,
+int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int tenant, int64_t* ids_dev,
                   int32_t* rows_dev, double* scores_dev, double* raw_max_dev, hipStream_t st) {
     ARG_CHECK(h, h->bm25 != nullptr, "no BM25 index loaded");
     ARG_CHECK(h, Q > 0 && Q <= 65535 && term_ptr_dev && ids_dev && scores_dev, "bm25_topk_dev: bad arguments");
     ARG_CHECK(h, k > 0 && k <= BM_MERGE / 2 && k <= BM_RANGE, "bm25: 0 < k <= 1024");
     rag_bm25_index* ix = h->bm25;
-    bool& attr = h->attr_bm25;
-    if (!attr) {
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bm25_range_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, BM_LDS_BYTES));
-        attr = true;
-    }
+    const int32_t* tenants = nullptr;
+    int rc = bm25_tenant_args(h, ix, tenant, &tenants);
+    if (rc) return rc;
+    if ((rc = bm25_set_attr(h))) return rc;
     const size_t need = (size_t)Q * ix->n_ranges * k;
     if (need > ix->ws_entries) {
         hipFree(ix->ws_key); hipFree(ix->ws_row);
@@ -661,12 +701,20 @@ int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_
         HIP_TRY(h, hipMalloc(&ix->ws_cnt, need_cnt * sizeof(int)));
         ix->ws_cnt_n = need_cnt;
     }
-    bm25_launch_topk(ix, term_ptr_dev, terms_dev, Q, k, ix->ws_key, ix->ws_row, ix->ws_tau, ix->ws_cnt, st);
+    const size_t need_run = (size_t)Q * k;
+    if (need_run > ix->ws_run_n) {
+        hipFree(ix->ws_run_key); hipFree(ix->ws_run_row);
+        ix->ws_run_key = nullptr; ix->ws_run_row = nullptr; ix->ws_run_n = 0;
+        HIP_TRY(h, hipMalloc(&ix->ws_run_key, need_run * sizeof(uint64_t)));
+        HIP_TRY(h, hipMalloc(&ix->ws_run_row, need_run * sizeof(uint32_t)));
+        ix->ws_run_n = need_run;
+    }
     // doc ids follow the dense index's mapping when both indexes cover the same rows (hybrid fusion needs one id space)
     const bool aligned = h->n_rows == ix->n_docs;
-    hipLaunchKernelGGL(bm25_merge_kernel, dim3(Q), dim3(256), 0, st, ix->ws_key, ix->ws_row, ix->n_ranges, k,
-                       aligned ? h->ids : (const int64_t*)nullptr, aligned ? h->id_base : (int64_t)0, ids_dev, rows_dev, scores_dev,
-                       raw_max_dev, ix->normalize, ix->ws_cnt);
+    const bm25_topk_ws w = {ix->ws_key, ix->ws_row, ix->ws_cnt, ix->ws_run_key, ix->ws_run_row, ix->ws_tau};
+    const bm25_topk_out o = {aligned ? h->ids : (const int64_t*)nullptr, aligned ? h->id_base : (int64_t)0, ids_dev, rows_dev, scores_dev,
+                             raw_max_dev, ix->normalize};
+    bm25_launch_topk(ix, term_ptr_dev, terms_dev, Q, k, w, o, tenants, tenant, st);
     HIP_TRY(h, hipGetLastError());
     return RAG_OK;
 }
@@ -677,13 +725,30 @@ int bm25_set_normalize(rag_ctx* h, int on) {
     return RAG_OK;
 }
 
-int bm25_topk_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, int k, int64_t* ids_out,
+int64_t bm25_n_docs(const rag_ctx* h) { return h->bm25 ? h->bm25->n_docs : -1; }
+
+int bm25_topk_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, int k, int tenant, int64_t* ids_out,
                    int32_t* rows_out, double* scores_out, double* raw_max_out) {
     ARG_CHECK(h, ids_out && scores_out, "bm25_topk: null output");
-    return bm25_run(h, term_ptr, terms, Q, k, 0, ids_out, rows_out, scores_out, raw_max_out, nullptr);
+    return bm25_run(h, h->bm25, term_ptr, terms, Q, k, 0, tenant, ids_out, rows_out, scores_out, raw_max_out, nullptr);
 }
 
 int bm25_scores_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, double* out) {
     ARG_CHECK(h, out, "bm25_scores: null output");
-    return bm25_run(h, term_ptr, terms, Q, 1, 1, nullptr, nullptr, nullptr, nullptr, out);
+    return bm25_run(h, h->bm25, term_ptr, terms, Q, 1, 1, -1, nullptr, nullptr, nullptr, nullptr, out);
+}
+
+// Stateless scoring of an AD-HOC corpus (HybridRetriever.hybrid_search builds a fresh BM25Okapi over the corpus it is handed on
+// every call, rag/retrieval.py:333-341): the postings are uploaded, scored and dropped inside the call; the resident
+// postings of the index (rag_bm25_load_host) are not touched.
+int bm25_scores_adhoc_host(rag_ctx* h, const int64_t* indptr, const int32_t* doc, const int32_t* tf, const int32_t* doc_len,
+                           const double* idf, int64_t n_docs, int64_t n_terms, double avgdl, double k1, double b,
+                           const int32_t* term_ptr, const int32_t* terms, int Q, double* out) {
+    ARG_CHECK(h, out, "bm25_scores_adhoc: null output");
+    rag_bm25_index* ix = nullptr;
+    int rc = bm25_build(h, indptr, doc, tf, doc_len, idf, n_docs, n_terms, avgdl, k1, b, &ix);
+    if (rc) return rc;
+    rc = bm25_run(h, ix, term_ptr, terms, Q, 1, 1, -1, nullptr, nullptr, nullptr, nullptr, out);
+    bm25_index_free(ix);
+    return rc;
 }

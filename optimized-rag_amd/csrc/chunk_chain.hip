@@ -62,24 +62,18 @@ int chunk_chain_host(rag_ctx* h, const float* emb, const int32_t* sent_len, int 
                      int min_chunk, int32_t* group_out) {
     ARG_CHECK(h, n > 0 && dim > 0 && dim <= 8192 && emb && sent_len && group_out, "chunk_chain: bad arguments (dim <= 8192)");
     hipStream_t st = h->stream;
-    float* ed = nullptr;
-    int32_t *ld = nullptr, *gd = nullptr;
-    hipError_t e = hipMalloc(&ed, (size_t)n * dim * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&ld, (size_t)n * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&gd, (size_t)n * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMemcpyAsync(ed, emb, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(ld, sent_len, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(chunk_chain_kernel, dim3(1), dim3(256), (size_t)dim * sizeof(double), st, ed, ld, n, dim, threshold,
-                           max_chunk, min_chunk, gd);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(group_out, gd, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st);
-    hipError_t e2 = hipStreamSynchronize(st);
-    hipFree(ed); hipFree(ld); hipFree(gd);
-    if (e != hipSuccess || e2 != hipSuccess) {
-        h->err = std::string("chunk_chain_host: ") + hipGetErrorString(e != hipSuccess ? e : e2);
-        return RAG_ERR_HIP;
-    }
+    const int rc = stage_reserve(h, stage_size((size_t)n * dim, 4) + 2 * stage_size(n, 4));
+    if (rc) return rc;
+    char* p = (char*)h->stage;
+    float* ed = stage_take<float>(p, (size_t)n * dim);
+    int32_t* ld = stage_take<int32_t>(p, n);
+    int32_t* gd = stage_take<int32_t>(p, n);
+    HIP_TRY(h, hipMemcpyAsync(ed, emb, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(ld, sent_len, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(chunk_chain_kernel, dim3(1), dim3(256), (size_t)dim * sizeof(double), st, ed, ld, n, dim, threshold,
+                       max_chunk, min_chunk, gd);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(group_out, gd, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
     return RAG_OK;
 }

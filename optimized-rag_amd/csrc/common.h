@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -56,10 +57,14 @@ struct rag_ctx {
     // exact-scan fallback workspace
     double* scan_scores = nullptr;   // [n_rows] (allocated on first use)
     int64_t scan_rows = 0;
-    int64_t* out_ids = nullptr;      // (unused staging, kept for ABI-stable struct layout inside the library)
-    int32_t* out_rows = nullptr;
-    double* out_scores = nullptr;
-    int out_k = 0;
+    // grow-only device arena of the synchronous *_host entry points: their per-call staging (queries in, results out, partial
+    // lists) is carved from it, so an agent-facing call pays no hipMalloc / hipFree
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+    // one lock per handle, taken by every entry point: the reference's DocumentStore.search may be called from up to 10
+    // threads (database/connection.py:38-42). *_host calls are then fully thread-safe (they are synchronous inside the
+    // lock); *_dev calls are serialised while they enqueue and share the handle's workspaces, so they must target ONE stream.
+    std::mutex mu;
 
     // profiling of the dominant kernel
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -102,6 +107,28 @@ struct rag_ctx {
     } while (0)
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- staging arena (see rag_ctx::stage): sum stage_size() of every piece, stage_reserve() once, stage_take() in the same order
+static inline size_t stage_size(size_t n, size_t elt) { return (size_t)round_up((int64_t)(n * elt), 256); }
+static inline int stage_reserve(rag_ctx* h, size_t bytes) {
+    if (bytes <= h->stage_bytes) return RAG_OK;
+    if (h->stage) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        hipFree(h->stage);
+        h->stage = nullptr;
+        h->stage_bytes = 0;
+    }
+    bytes = (size_t)round_up((int64_t)(bytes + bytes / 4), 1 << 20);          // headroom: slightly larger batches do not reallocate
+    HIP_TRY(h, hipMalloc(&h->stage, bytes));
+    h->stage_bytes = bytes;
+    return RAG_OK;
+}
+template <class T>
+static inline T* stage_take(char*& p, size_t n) {
+    T* r = reinterpret_cast<T*>(p);
+    p += stage_size(n, sizeof(T));
+    return r;
+}
 
 // ---- sortable keys: larger key = higher score, then lower row ---------------------------------
 __host__ __device__ static inline uint32_t f32_orderable(float s) {

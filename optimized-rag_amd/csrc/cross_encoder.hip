@@ -25,6 +25,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 struct rag_ce_model {
@@ -860,7 +861,11 @@ int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* l
     ARG_CHECK(h, L_in <= m->cfg.max_pos && L_in <= 512, "ce_score: sequence longer than max_position_embeddings/512");
     int L = 0;
     for (int c : kAttnL) if (c >= L_in) { L = c; break; }
-    const int chunk = std::max(1, std::min(P, (int)(2'000'000 / L)));        // ~2M tokens of activations per chunk (~30 GB)
+    // ~2M tokens of activations per chunk (~30 GB). RAG_CE_CHUNK_TOKENS (diagnostic) shrinks it so that parity tests can run
+    // the multi-chunk loop on small inputs.
+    const char* ct = getenv("RAG_CE_CHUNK_TOKENS");
+    const int64_t chunk_tokens = ct && atoll(ct) >= 32 ? atoll(ct) : 2'000'000;
+    const int chunk = std::max(1, std::min(P, (int)(chunk_tokens / L)));
     int rc = ce_ensure_ws(h, m, chunk, L);
     if (rc) return rc;
     const hipMemcpyKind kin = host_ptrs ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;

@@ -705,8 +705,7 @@ __global__ void search_init_kernel(float* __restrict__ tau, float* __restrict__ 
 static int ensure_workspace(rag_ctx* h, int Q) {
     if (Q <= h->ws_q) return RAG_OK;
     hipFree(h->q32); hipFree(h->q16); hipFree(h->cand); hipFree(h->cnt); hipFree(h->tau); hipFree(h->bound);
-    hipFree(h->n_sorted); hipFree(h->exact); hipFree(h->flag); hipFree(h->out_ids); hipFree(h->out_rows);
-    hipFree(h->out_scores);
+    hipFree(h->n_sorted); hipFree(h->exact); hipFree(h->flag);
     h->ws_q = 0;
     const int64_t qpad = round_up(Q, RAG_TILE);
     HIP_TRY(h, hipMalloc(&h->q32, (size_t)Q * h->dim * sizeof(float)));
@@ -718,9 +717,6 @@ static int ensure_workspace(rag_ctx* h, int Q) {
     HIP_TRY(h, hipMalloc(&h->n_sorted, (size_t)qpad * sizeof(int)));
     HIP_TRY(h, hipMalloc(&h->exact, (size_t)qpad * RAG_CAND_CAP * sizeof(double)));
     HIP_TRY(h, hipMalloc(&h->flag, (size_t)qpad * sizeof(int)));
-    HIP_TRY(h, hipMalloc(&h->out_ids, (size_t)Q * RAG_MAX_K * sizeof(int64_t)));
-    HIP_TRY(h, hipMalloc(&h->out_rows, (size_t)Q * RAG_MAX_K * sizeof(int32_t)));
-    HIP_TRY(h, hipMalloc(&h->out_scores, (size_t)Q * RAG_MAX_K * sizeof(double)));
     if (!h->stats) HIP_TRY(h, hipMalloc(&h->stats, 8 * sizeof(int)));
     HIP_TRY(h, hipMemset(h->q16, 0, (size_t)qpad * h->dim_pad * sizeof(half_t)));
     h->ws_q = Q;

@@ -114,30 +114,22 @@ int rrf_fuse_host(rag_ctx* h, const int64_t* lists, int Q, int L, int len, int r
     ARG_CHECK(h, (int64_t)L * len <= RRF_MAX_ITEMS, "rrf: n_lists*list_len must be <= 1024");
     ARG_CHECK(h, lists && keys_out && scores_out, "rrf: null pointer");
     hipStream_t st = h->stream;
-    const size_t T = (size_t)L * len;
-    int64_t *ld = nullptr, *kd = nullptr;
-    double* sd = nullptr;
-    int32_t* rd = nullptr;
-    HIP_TRY(h, hipMalloc(&ld, std::max<size_t>(1, (size_t)Q * T) * sizeof(int64_t)));
-    hipError_t e = hipMalloc(&kd, (size_t)Q * top_k * sizeof(int64_t));
-    if (e == hipSuccess) e = hipMalloc(&sd, (size_t)Q * top_k * sizeof(double));
-    if (e == hipSuccess && ranks_out) e = hipMalloc(&rd, (size_t)Q * top_k * L * sizeof(int32_t));
-    if (e == hipSuccess && T) e = hipMemcpyAsync(ld, lists, (size_t)Q * T * sizeof(int64_t), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(rrf_fuse_kernel, dim3(Q), dim3(256), 0, st, ld, L, std::max(len, 1), (int64_t)len, (int64_t)T, rrf_k, top_k,
-                           kd, sd, rd);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(keys_out, kd, (size_t)Q * top_k * sizeof(int64_t), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(scores_out, sd, (size_t)Q * top_k * sizeof(double), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && ranks_out)
-        e = hipMemcpyAsync(ranks_out, rd, (size_t)Q * top_k * L * sizeof(int32_t), hipMemcpyDeviceToHost, st);
-    hipError_t e2 = hipStreamSynchronize(st);
-    hipFree(ld); hipFree(kd); hipFree(sd); hipFree(rd);
-    if (e != hipSuccess || e2 != hipSuccess) {
-        h->err = std::string("rrf_fuse: ") + hipGetErrorString(e != hipSuccess ? e : e2);
-        return RAG_ERR_HIP;
-    }
+    const size_t T = (size_t)L * len, n_out = (size_t)Q * top_k;
+    const int rc = stage_reserve(h, stage_size(std::max<size_t>(1, (size_t)Q * T), 8) + 2 * stage_size(n_out, 8) + stage_size(n_out * L, 4));
+    if (rc) return rc;
+    char* p = (char*)h->stage;
+    int64_t* ld = stage_take<int64_t>(p, std::max<size_t>(1, (size_t)Q * T));
+    int64_t* kd = stage_take<int64_t>(p, n_out);
+    double* sd = stage_take<double>(p, n_out);
+    int32_t* rd = ranks_out ? stage_take<int32_t>(p, n_out * L) : nullptr;
+    if (T) HIP_TRY(h, hipMemcpyAsync(ld, lists, (size_t)Q * T * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rrf_fuse_kernel, dim3(Q), dim3(256), 0, st, ld, L, std::max(len, 1), (int64_t)len, (int64_t)T, rrf_k, top_k,
+                       kd, sd, rd);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(keys_out, kd, n_out * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(scores_out, sd, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (ranks_out) HIP_TRY(h, hipMemcpyAsync(ranks_out, rd, n_out * L * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
     return RAG_OK;
 }
 
@@ -225,33 +217,26 @@ int linear_fuse_topk_host(rag_ctx* h, const double* sem, const double* kw, const
     ARG_CHECK(h, sem && kw && idx_out && hyb_out, "linear_fuse: null pointer");
     hipStream_t st = h->stream;
     const int n_chunks = (n + TK_CHUNK - 1) / TK_CHUNK;
-    double *sd = nullptr, *kd = nullptr, *td = nullptr, *hd = nullptr;
-    uint64_t* pk = nullptr;
-    uint32_t* pi = nullptr;
-    int32_t* od = nullptr;
-    const size_t nb = (size_t)n * sizeof(double);
-    HIP_TRY(h, hipMalloc(&sd, nb));
-    hipError_t e = hipMalloc(&kd, nb);
-    if (e == hipSuccess && tmp) e = hipMalloc(&td, nb);
-    if (e == hipSuccess) e = hipMalloc(&hd, nb);
-    if (e == hipSuccess) e = hipMalloc(&pk, (size_t)n_chunks * top_k * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMalloc(&pi, (size_t)n_chunks * top_k * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&od, (size_t)top_k * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMemcpyAsync(sd, sem, nb, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(kd, kw, nb, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && tmp) e = hipMemcpyAsync(td, tmp, nb, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(linear_fuse_chunk_kernel, dim3(n_chunks), dim3(256), 0, st, sd, kd, td, n, a, b, g, top_k, hd, pk, pi);
-        hipLaunchKernelGGL(topk_merge_kernel, dim3(1), dim3(256), 0, st, pk, pi, n_chunks * top_k, top_k, od);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(idx_out, od, (size_t)top_k * sizeof(int32_t), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(hyb_out, hd, nb, hipMemcpyDeviceToHost, st);
-    hipError_t e2 = hipStreamSynchronize(st);
-    hipFree(sd); hipFree(kd); hipFree(td); hipFree(hd); hipFree(pk); hipFree(pi); hipFree(od);
-    if (e != hipSuccess || e2 != hipSuccess) {
-        h->err = std::string("linear_fuse: ") + hipGetErrorString(e != hipSuccess ? e : e2);
-        return RAG_ERR_HIP;
-    }
+    const size_t nb = (size_t)n * sizeof(double), n_part = (size_t)n_chunks * top_k;
+    const int rc = stage_reserve(h, 4 * stage_size(n, 8) + stage_size(n_part, 8) + stage_size(n_part, 4) + stage_size(top_k, 4));
+    if (rc) return rc;
+    char* p = (char*)h->stage;
+    double* sd = stage_take<double>(p, n);
+    double* kd = stage_take<double>(p, n);
+    double* td = stage_take<double>(p, n);
+    double* hd = stage_take<double>(p, n);
+    uint64_t* pk = stage_take<uint64_t>(p, n_part);
+    uint32_t* pi = stage_take<uint32_t>(p, n_part);
+    int32_t* od = stage_take<int32_t>(p, top_k);
+    if (!tmp) td = nullptr;
+    HIP_TRY(h, hipMemcpyAsync(sd, sem, nb, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(kd, kw, nb, hipMemcpyHostToDevice, st));
+    if (tmp) HIP_TRY(h, hipMemcpyAsync(td, tmp, nb, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(linear_fuse_chunk_kernel, dim3(n_chunks), dim3(256), 0, st, sd, kd, td, n, a, b, g, top_k, hd, pk, pi);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(1), dim3(256), 0, st, pk, pi, n_chunks * top_k, top_k, od);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(idx_out, od, (size_t)top_k * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(hyb_out, hd, nb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
     return RAG_OK;
 }

@@ -141,25 +141,19 @@ int mmr_select_host(rag_ctx* h, const float* query, const float* emb, int n, int
     ARG_CHECK(h, query && emb && sel_out && score_out, "mmr: null pointer");
     ARG_CHECK(h, n > 0 && n <= MMR_MAX_N && dim > 0 && top_k > 0, "mmr: 1 <= n <= 256 candidates, top_k >= 1");
     hipStream_t st = h->stream;
-    float *qd = nullptr, *ed = nullptr;
-    int32_t* sd = nullptr;
-    double* cd = nullptr;
-    hipError_t e = hipMalloc(&qd, (size_t)dim * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&ed, (size_t)n * dim * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&sd, (size_t)top_k * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&cd, (size_t)top_k * sizeof(double));
-    if (e == hipSuccess) e = hipMemcpyAsync(qd, query, (size_t)dim * sizeof(float), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(ed, emb, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, st);
-    int rc = RAG_OK;
-    if (e == hipSuccess) rc = mmr_select_dev(h, qd, ed, nullptr, 1, n, dim, top_k, lam, variant, sd, cd, st);
-    if (e == hipSuccess && rc == RAG_OK) e = hipMemcpyAsync(sel_out, sd, (size_t)top_k * sizeof(int32_t), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && rc == RAG_OK) e = hipMemcpyAsync(score_out, cd, (size_t)top_k * sizeof(double), hipMemcpyDeviceToHost, st);
-    hipError_t e2 = hipStreamSynchronize(st);
-    hipFree(qd); hipFree(ed); hipFree(sd); hipFree(cd);
+    int rc = stage_reserve(h, stage_size(dim, 4) + stage_size((size_t)n * dim, 4) + stage_size(top_k, 4) + stage_size(top_k, 8));
     if (rc) return rc;
-    if (e != hipSuccess || e2 != hipSuccess) {
-        h->err = std::string("mmr_select_host: ") + hipGetErrorString(e != hipSuccess ? e : e2);
-        return RAG_ERR_HIP;
-    }
+    char* p = (char*)h->stage;
+    float* qd = stage_take<float>(p, dim);
+    float* ed = stage_take<float>(p, (size_t)n * dim);
+    int32_t* sd = stage_take<int32_t>(p, top_k);
+    double* cd = stage_take<double>(p, top_k);
+    HIP_TRY(h, hipMemcpyAsync(qd, query, (size_t)dim * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(ed, emb, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, st));
+    rc = mmr_select_dev(h, qd, ed, nullptr, 1, n, dim, top_k, lam, variant, sd, cd, st);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(sel_out, sd, (size_t)top_k * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(score_out, cd, (size_t)top_k * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
     return RAG_OK;
 }

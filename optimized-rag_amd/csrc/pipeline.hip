@@ -6,15 +6,16 @@
 // with the passages' token ids resident in HBM next to their embeddings ("token store"), so
 // between the query arriving and the top-k leaving nothing crosses PCIe.
 //   1. candidates: dense top-pool (mode 0) or dense + BM25 + RRF -> top-pool (mode 1)
-//   2. ce_build_pairs_kernel: [CLS] query [SEP] passage [SEP], token_type 0 | 1, passage truncated to fit L_pair
+//   2. ce_build_pairs_kernel: [CLS] query [SEP] passage [SEP], token_type 0 | 1, truncated 'longest_first' to L_pair
 //   3. ce_score (cross_encoder.hip)
 //   4. rerank_topk_kernel: sigmoid in float64, stable order (score desc, candidate order on ties), top-k
 #include "common.h"
 
 int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev, double* scores_dev,
                  hipStream_t st);
-int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int64_t* ids_dev,
+int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int tenant, int64_t* ids_dev,
                   int32_t* rows_dev, double* scores_dev, double* raw_max_dev, hipStream_t st);
+int64_t bm25_n_docs(const rag_ctx* h);
 int rrf_fuse_dev(rag_ctx* h, const int64_t* lists_dev, int Q, int L, int len, int64_t list_stride, int64_t query_stride, int rrf_k,
                  int top_k, int64_t* keys_dev, double* scores_dev, int32_t* ranks_dev, hipStream_t st);
 int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L, float* out, hipStream_t st,
@@ -50,9 +51,21 @@ __global__ __launch_bounds__(256) void ce_build_pairs_kernel(const int32_t* __re
     if (p >= n_pairs) return;
     const int q = p / pool;
     const int64_t row = cand[p] < 0 ? -1 : cand[p] - id_base;
-    const int ql = max(0, min(q_len[q], min(Lq, L - 3)));
-    int dl = 0;
-    if (row >= 0 && row < n_rows) dl = max(0, min(min(tok_len[row], Ld), L - 3 - ql));   // only the passage is truncated
+    // truncation = 'longest_first' to max_length L, as CrossEncoder.predict tokenises its pairs (SURVEY.md section 8c;
+    // the fast tokenizer's rule, pinned against the `tokenizers` package by tests/test_pair_truncation.py): with
+    // M = L - 3 content tokens and n1 <= n2 the two lengths, the shorter side is kept whole while it fits
+    // (n2 = max(n1, M - n1)); if both exceed their share, n1 = M / 2 and n2 = n1 + M % 2.
+    int ql = max(0, min(q_len[q], Lq));
+    int dl = (row >= 0 && row < n_rows) ? max(0, min(tok_len[row], Ld)) : 0;
+    const int M = L - 3;
+    if (ql + dl > M) {
+        const bool swap = ql > dl;
+        int n1 = swap ? dl : ql, n2 = swap ? ql : dl;
+        n2 = n1 > M ? n1 : max(n1, M - n1);
+        if (n1 + n2 > M) { n1 = M / 2; n2 = n1 + M % 2; }
+        ql = swap ? n2 : n1;
+        dl = swap ? n1 : n2;
+    }
     const int total = ql + dl + 3;
     const int32_t* qt = q_tok + (size_t)q * Lq;
     const int32_t* dt = tok + (size_t)(row < 0 ? 0 : row) * Ld;
@@ -138,6 +151,7 @@ int retrieve_rerank_dev(rag_ctx* h, const float* q_emb_dev, const int32_t* term_
     ARG_CHECK(h, L_pair >= 8 && L_pair <= 512 && Lq > 0 && q_emb_dev && q_tok_dev && q_len_dev && ids_out && scores_out && logits_out,
               "retrieve_rerank: bad arguments");
     ARG_CHECK(h, mode == 0 || (mode == 1 && term_ptr_dev && h->bm25 != nullptr), "retrieve_rerank: mode 1 needs BM25 postings and query terms");
+    ARG_CHECK(h, mode == 0 || bm25_n_docs(h) == h->n_rows, "retrieve_rerank: the BM25 postings must be row-aligned with the index");
     const size_t P = (size_t)Q * pool;
     // workspace: lists [2][Q][pool] i64 | scores [Q][pool] f64 | cand [Q][pool] i64 | rrf [Q][pool] f64 | ranks [Q][pool][2] i32
     //            | pair ids [P][L] | pair tt [P][L] | lens [P] | logits [P]
@@ -171,7 +185,7 @@ int retrieve_rerank_dev(rag_ctx* h, const float* q_emb_dev, const int32_t* term_
         rc = dense_search(h, q_emb_dev, Q, pool, tenant, cand, nullptr, sc, st);
     } else {
         rc = dense_search(h, q_emb_dev, Q, pool, tenant, lists, nullptr, sc, st);
-        if (!rc) rc = bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, lists + P, nullptr, sc, nullptr, st);
+        if (!rc) rc = bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, tenant, lists + P, nullptr, sc, nullptr, st);
         if (!rc) rc = rrf_fuse_dev(h, lists, Q, 2, pool, (int64_t)P, pool, rrf_k, pool, cand, rrf, ranks, st);
     }
     h->ids = ids_saved;

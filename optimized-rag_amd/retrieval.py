@@ -2,7 +2,7 @@
 
 What runs where
   * cosine(query, every doc)      -> rag_pairwise_cosine_host (float64 kernel)   [reference :253-256, :362-371]
-  * BM25Okapi.get_scores + /max   -> rag_bm25_load_host + rag_bm25_scores_host   [reference :324-347]
+  * BM25Okapi.get_scores + /max   -> rag_bm25_scores_adhoc_host (stateless)      [reference :324-347]
   * alpha*s + beta*kw + gamma*t, stable sort, [:top_k] -> rag_linear_fuse_topk_host [reference :294-322]
   * tokenising, keyword-set overlap fallback, ISO timestamps, dict assembly stay in Python (text handling).
 `retrieve`/`_retrieve_*` are the reference's fan-out wrappers; with a GpuDocumentIndex as `document_store` the
@@ -164,9 +164,11 @@ class HybridRetriever:
         if not corpus or all(len(d.split()) == 0 for d in corpus):
             logger.warning("BM25: Empty or whitespace-only corpus, returning zeros")
             return [0.0] * len(corpus)
-        post = Bm25Postings.from_corpus(corpus).load(self.engine)
+        # stateless: a fresh BM25Okapi per call in the reference (:333-341); the index's resident postings stay loaded
+        post = Bm25Postings.from_corpus(corpus)
         ptr, terms = post.encode_queries([query])
-        scores = self.engine.bm25_scores(ptr, terms)[0]
+        scores = self.engine.bm25_scores_adhoc(post.indptr, post.doc, post.tf, post.doc_len, post.idf, post.avgdl, ptr, terms,
+                                               post.k1, post.b)[0]
         mx = float(scores.max()) if len(scores) > 0 and scores.max() > 0 else 1.0
         return [float(s / mx) for s in scores]
 

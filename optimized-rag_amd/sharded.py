@@ -107,7 +107,7 @@ class ShardedHybridIndex(ShardedDenseIndex):
         send = self._hyb_buffers(queries.shape[0], pool, k, queries.device)["send"]
         f64 = torch.float64
         self.engine.dense_topk_dev(queries, pool, send[0], None, send[1].view(f64), tenant=tenant)
-        self.engine.bm25_topk_dev(term_ptr, terms, pool, send[2], None, send[3].view(f64))
+        self.engine.bm25_topk_dev(term_ptr, terms, pool, send[2], None, send[3].view(f64), tenant=tenant)
         return send
 
     def fuse_gathered(self, recv, k, rrf_k=60):
@@ -179,10 +179,10 @@ class ShardedPipeline:
         self.token_id_base = token_id_base
         self._bufs = {}
 
-    def retrieve_rerank(self, queries, term_ptr, terms, q_tok, q_len, pool, k, L_pair=256, rrf_k=60, cls_id=101, sep_id=102):
+    def retrieve_rerank(self, queries, term_ptr, terms, q_tok, q_len, pool, k, L_pair=512, rrf_k=60, cls_id=101, sep_id=102, tenant=-1):
         """Returns (ids [Q,k] int64, scores [Q,k] float64 = sigmoid(logit), logits [Q,k] float32, candidates [Q,pool])."""
         Q, dev = queries.shape[0], queries.device
-        cand = self.index.search_hybrid(queries, term_ptr, terms, pool, pool, rrf_k=rrf_k)["keys"]
+        cand = self.index.search_hybrid(queries, term_ptr, terms, pool, pool, rrf_k=rrf_k, tenant=tenant)["keys"]
         key = (Q, pool, k, L_pair, str(dev))
         if key not in self._bufs:
             P = Q * pool

@@ -145,6 +145,23 @@ class BM25Okapi:
         return score
 
 
+def bm25_scores_csr(indptr, doc, tf, doc_len, idf, avgdl, query_terms, k1=1.5, b=0.75):
+    """BM25Okapi.get_scores from term-major CSR postings (the index-level form of the same arithmetic, for corpora too
+    large to hold as token dicts): for every query term IN ORDER, score[doc] += idf[t] * (tf*(k1+1) / (tf + k1*(1 - b +
+    b*dl/avgdl))) over the term's postings. Documents outside a posting list have tf = 0 and receive + 0.0, so the
+    sparse update is bit-identical to the dense one above (tests/test_oracle_bm25.py checks that). -1 = unknown term."""
+    score = np.zeros(len(doc_len))
+    dl = np.asarray(doc_len)
+    for t in query_terms:
+        if t < 0 or t >= len(idf):
+            continue
+        a, e = int(indptr[t]), int(indptr[t + 1])
+        d = np.asarray(doc[a:e])
+        f = np.asarray(tf[a:e])
+        score[d] += (idf[t] or 0) * (f * (k1 + 1) / (f + k1 * (1 - b + b * dl[d] / avgdl)))
+    return score
+
+
 def bm25_scores(query, corpus):
     """retrieval.py:324-347: zeros for an empty / all-whitespace corpus; else BM25Okapi scores divided
     by their max when that max is > 0 (else by 1.0)."""
@@ -390,6 +407,23 @@ def score_sentences_hybrid(query, sentences, q_emb, s_embs):      # context_comp
 # ---------------------------------------------------------------------------------------------
 # a6/a7 re-ranker post-processing   (rag/reranker.py:28-90, 320-384)
 # ---------------------------------------------------------------------------------------------
+
+
+def longest_first_lengths(n1, n2, max_content):
+    """Lengths the two sequences of a pair keep under truncation='longest_first' (what CrossEncoder.predict's tokenizer
+    call applies, /root/reference/rag/reranker.py:355 -> sentence-transformers -> fast tokenizer; third-party, absent from
+    the reference tree): max_content = max_length - special tokens. The shorter side is kept whole while it fits; if both
+    exceed their share the FIRST-or-shorter side gets floor(max/2), the other the rest. Pinned against the `tokenizers`
+    package shipped in this image by tests/test_pair_truncation.py."""
+    if n1 + n2 <= max_content:
+        return n1, n2
+    swap = n1 > n2
+    a, b = (n2, n1) if swap else (n1, n2)
+    b = a if a > max_content else max(a, max_content - a)
+    if a + b > max_content:
+        a = max_content // 2
+        b = a + max_content % 2
+    return (b, a) if swap else (a, b)
 
 
 def sigmoid(x):

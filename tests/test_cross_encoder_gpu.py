@@ -62,6 +62,67 @@ def test_minilm_shapes_vs_oracle(eng, P, L):
     assert np.abs(got[sel] - exp).max() < LOGIT_TOL, (got[sel], exp)
 
 
+def _random_pairs(rng, cfg, P, L, lens):
+    ids = rng.integers(1000, cfg["vocab_size"], (P, L)).astype(np.int32)
+    ids[np.arange(L)[None, :] >= lens[:, None]] = 0
+    tt = ((np.arange(L)[None, :] >= 18) & (np.arange(L)[None, :] < lens[:, None])).astype(np.int32)
+    return ids, tt
+
+
+def test_bench_path_persistent_handover_and_two_chunks(eng):
+    """The path the rerank throughput is measured on: 6-layer MiniLM shape, L = 256, 8192 pairs of mixed
+    length = ~1.5M packed rows, so every persistent GEMM workgroup walks several tiles (the cross-tile DMA hand-over in
+    all three epilogue variants) and the 2M-token chunk loop runs twice (7812 + 380 pairs). Pairs are independent, so the
+    float64 oracle is evaluated on a sample: first / last pair, both sides of the chunk boundary, short and full-length
+    pairs, pairs deep inside the first chunk."""
+    import torch
+    cfg = B.minilm_config()
+    w = B.seeded_weights(cfg, 99)
+    load_model(eng, cfg, w)
+    P, L = 8192, 256
+    rng = np.random.default_rng(8192)
+    lens = (18 + rng.integers(96, 225, P)).clip(max=L).astype(np.int32)             # the bench's length mix (SURVEY 8d)
+    lens[rng.integers(0, P, 400)] = rng.integers(2, 60, 400)                         # plus short pairs ...
+    lens[rng.integers(0, P, 200)] = L                                                # ... and full-length ones
+    sample = [0, 1, 40, 977, 3000, 5000, 7810, 7811, 7812, 7813, 8000, P - 1]
+    lens[[1, 7811]] = [5, L]
+    lens[[7812, 8000]] = [L, 33]
+    ids, tt = _random_pairs(rng, cfg, P, L, lens)
+    out = torch.empty((P,), dtype=torch.float32, device="cuda")
+    eng.ce_score_dev(torch.from_numpy(ids).cuda(), torch.from_numpy(tt).cuda(), torch.from_numpy(lens).cuda(), out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    exp = B.forward_logits(w, cfg, ids[sample].astype(np.int64), tt[sample].astype(np.int64), lens[sample], fast_erf=True)
+    assert np.abs(got[sample] - exp).max() < LOGIT_TOL, (got[sample], exp)
+    sg = np.array([O.sigmoid(float(x)) for x in got[sample]])
+    se = np.array([O.sigmoid(float(x)) for x in exp])
+    assert np.abs(sg - se).max() < SCORE_TOL
+    # the host-pointer entry walks the same chunk loop with H2D staging per chunk: same bits
+    np.testing.assert_array_equal(eng.ce_score(ids[7700:7900], tt[7700:7900], lens[7700:7900]), got[7700:7900])
+
+
+def test_small_multi_chunk_loop(eng, monkeypatch):
+    """RAG_CE_CHUNK_TOKENS shrinks the activation chunk: 300 pairs at L = 64 in chunks of 64 pairs (5 chunks, the last one
+    short) must give the same logits, bit for bit, as one chunk (pairs are independent; every output element sums its K
+    range in the same order whatever tile it lands in), and match the float64 oracle."""
+    cfg = dict(vocab_size=5000, hidden=384, layers=2, heads=12, ffn=1536, max_pos=64, type_vocab=2, eps=1e-12)
+    w = B.seeded_weights(cfg, 3)
+    load_model(eng, cfg, w)
+    rng = np.random.default_rng(64)
+    P, L = 300, 64
+    lens = rng.integers(2, L + 1, P).astype(np.int32)
+    ids, tt = _random_pairs(rng, cfg, P, L, lens)
+    one = eng.ce_score(ids, tt, lens)
+    monkeypatch.setenv("RAG_CE_CHUNK_TOKENS", "4096")
+    many = eng.ce_score(ids, tt, lens)
+    monkeypatch.delenv("RAG_CE_CHUNK_TOKENS")
+    np.testing.assert_array_equal(one, many)
+    sel = [0, 63, 64, 65, 255, 256, 299]
+    exp = B.forward_logits(w, cfg, ids[sel].astype(np.int64), tt[sel].astype(np.int64), lens[sel])
+    assert np.abs(many[sel] - exp).max() < LOGIT_TOL
+
+
 def test_reranker_from_local_dir(eng, tmp_path):
     """End to end through the mirror class: local checkpoint dir -> tokeniser -> HIP forward -> sigmoid -> sort."""
     from safetensors.numpy import save_file

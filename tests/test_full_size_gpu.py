@@ -90,28 +90,35 @@ def test_float64_spot_check_of_a_query_subset(world):
         np.testing.assert_allclose(got_s[qi], exact[order], atol=1e-9)
 
 
+def _postings(world):
+    """1M-doc synthetic postings + 1024 term queries, built once per module and loaded into world['whole']."""
+    if "post" not in world:
+        import bench_modes as BM
+        from optimized_rag_amd.bm25 import Bm25Postings
+        indptr, d, tf, dl, tok, doc_ptr = BM.synthetic_csr(N, 100_000, 120)
+        post = Bm25Postings(indptr, d, tf, dl, Bm25Postings.idf_table(np.diff(indptr).clip(min=0), N), float(dl.sum()) / N)
+        post.idf[np.diff(indptr) == 0] = 0.0
+        post.load(world["whole"])
+        rng = np.random.default_rng(7)
+        ptr, terms = [0], []
+        for i in range(Q):
+            di = int(rng.integers(0, N))
+            toks = tok[doc_ptr[di]:doc_ptr[di + 1]]
+            n = int(rng.integers(4, 13))
+            terms.extend(int(x) for x in (rng.choice(toks, n) if len(toks) else [0] * n))
+            ptr.append(len(terms))
+        world["post"] = (post, np.asarray(ptr, np.int32), np.asarray(terms, np.int32))
+    return world["post"]
+
+
 def test_bm25_full_size_staged_equals_exhaustive_select(world, monkeypatch):
     """BASELINE.json configs[2] at FULL size (1M docs, ~9.5e7 postings, 1024 queries, top-100): the staged-threshold BM25
     path must return bit-identical ids and scores to the path that runs the exact per-range select on every range, its
     scores are max-normalised and sorted, and the sharded pipeline property holds: scoring two doc partitions with the
     global statistics and merging == scoring the whole corpus."""
     import torch
-    import bench_modes as BM
-    from optimized_rag_amd.bm25 import Bm25Postings
     eng = world["whole"]
-    indptr, d, tf, dl, tok, doc_ptr = BM.synthetic_csr(N, 100_000, 120)
-    post = Bm25Postings(indptr, d, tf, dl, Bm25Postings.idf_table(np.diff(indptr).clip(min=0), N), float(dl.sum()) / N)
-    post.idf[np.diff(indptr) == 0] = 0.0
-    post.load(eng)
-    rng = np.random.default_rng(7)
-    ptr, terms = [0], []
-    for i in range(Q):
-        di = int(rng.integers(0, N))
-        toks = tok[doc_ptr[di]:doc_ptr[di + 1]]
-        n = int(rng.integers(4, 13))
-        terms.extend(int(x) for x in (rng.choice(toks, n) if len(toks) else [0] * n))
-        ptr.append(len(terms))
-    ptr, terms = np.asarray(ptr, np.int32), np.asarray(terms, np.int32)
+    post, ptr, terms = _postings(world)
     ptr_d, terms_d = torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda()
     pool = 100
 
@@ -151,3 +158,65 @@ def test_bm25_full_size_staged_equals_exhaustive_select(world, monkeypatch):
     merged = os_.cpu().numpy()
     np.testing.assert_array_equal(oi.cpu().numpy(), ids_s)
     np.testing.assert_array_equal(merged / np.where(merged[:, :1] > 0, merged[:, :1], 1.0), sc_s)
+
+
+def test_retrieve_rerank_full_size_vs_oracle_on_sampled_queries(world):
+    """BASELINE.json configs[3] at FULL size through the one-call entry: 1M rows + ~9.5e7 postings + a 224-token passage
+    store, 256 queries, hybrid top-100 -> MiniLM-L-6 cross-encoder (L = 256, 6 layers, 25,600 pairs = 3 activation
+    chunks) -> top-20. Every query: slots filled, scores sorted, ids drawn from its candidate list. Two sampled queries
+    get the whole oracle composition: float64 dense top-100, CSR BM25 top-100, RRF ranks (candidate list bit-exact),
+    'longest_first' pair assembly, float64 BERT forward of all 100 pairs, sigmoid, stable sort."""
+    import torch
+    from oracle import bert_oracle as B
+    from oracle import rag_oracle as O
+    from optimized_rag_amd.cross_encoder import flatten_state_dict
+    eng = world["whole"]
+    post, ptr, terms = _postings(world)
+    Qr, pool, k, L, Ld, Lq = 256, 100, 20, 256, 224, 16
+    cfg = B.minilm_config()
+    w = B.seeded_weights(cfg, 2024)
+    eng.ce_load(cfg, flatten_state_dict(w, cfg["layers"]))
+    tok = torch.randint(1000, cfg["vocab_size"], (N, Ld), generator=torch.Generator().manual_seed(5), dtype=torch.int32).numpy()
+    tok_len = torch.randint(96, Ld + 1, (N,), generator=torch.Generator().manual_seed(6), dtype=torch.int32).numpy()
+    eng.tokens_load(tok, tok_len)
+    q_tok = torch.randint(1000, cfg["vocab_size"], (Qr, Lq), generator=torch.Generator().manual_seed(8), dtype=torch.int32)
+    q_len = torch.full((Qr,), Lq, dtype=torch.int32)
+    q_emb = world["q"][:Qr].contiguous()
+    ids, sc, lg, cand = eng.retrieve_rerank_dev(q_emb, q_tok.cuda(), q_len.cuda(), pool, k, term_ptr=torch.from_numpy(ptr[:Qr + 1]).cuda(),
+                                                terms=torch.from_numpy(terms).cuda(), L_pair=L)
+    torch.cuda.synchronize()
+    ids, sc, lg, cand = ids.cpu().numpy(), sc.cpu().numpy(), lg.cpu().numpy(), cand.cpu().numpy()
+    assert (ids >= 0).all() and (cand >= 0).all() and (np.diff(sc, axis=1) <= 0).all()
+    assert all(set(ids[q]) <= set(cand[q]) and len(set(ids[q])) == k for q in range(Qr))
+    np.testing.assert_allclose(sc, 1.0 / (1.0 + np.exp(-lg.astype(np.float64))), atol=1e-15)
+    # ---- oracle composition for two queries --------------------------------------------------------------------
+    hc = world["corpus"].cpu().numpy()
+    unit = hc / np.linalg.norm(hc, axis=1, keepdims=True)
+    for qi in (3, 200):
+        hq = q_emb[qi:qi + 1].cpu().numpy()
+        s32 = ((hq / np.linalg.norm(hq)) @ unit.T)[0]
+        short = np.argpartition(-s32, 600)[:600]
+        exact = O.cosine_matrix(hq, hc[short])[0]
+        d_rows = short[np.lexsort((short, -exact))[:pool]]
+        qt = terms[ptr[qi]:ptr[qi + 1]].tolist()
+        raw = O.bm25_scores_csr(post.indptr, post.doc, post.tf, post.doc_len, post.idf, post.avgdl, qt)
+        b_rows = O.stable_topk_desc(raw, pool)
+        okeys, _, _ = O.rrf_fuse([[int(r) for r in d_rows], [int(r) for r in b_rows]], k=60, top_k=pool)
+        assert cand[qi].tolist() == okeys                                            # candidate list: bit-exact
+        pid = np.zeros((pool, L), dtype=np.int64)
+        ptt = np.zeros((pool, L), dtype=np.int64)
+        plen = np.zeros(pool, dtype=np.int64)
+        for j, r in enumerate(okeys):
+            ql, dl = O.longest_first_lengths(Lq, int(tok_len[r]), L - 3)
+            row = [101] + q_tok[qi, :ql].tolist() + [102] + tok[r, :dl].tolist() + [102]
+            pid[j, :len(row)] = row
+            ptt[j, ql + 2:len(row)] = 1
+            plen[j] = len(row)
+        ologit = B.forward_logits(w, cfg, pid, ptt, plen, fast_erf=True)
+        oscore = np.array([O.sigmoid(float(x)) for x in ologit])
+        order = sorted(range(pool), key=lambda j: -oscore[j])
+        np.testing.assert_allclose(sc[qi], oscore[order[:k]], atol=1e-3)
+        np.testing.assert_allclose(lg[qi], ologit[order[:k]], atol=4e-3)
+        gaps = np.abs(np.diff(oscore[order[:k + 1]]))
+        if gaps.min() > 2e-3:
+            assert ids[qi].tolist() == [okeys[j] for j in order[:k]]

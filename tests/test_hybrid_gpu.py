@@ -502,3 +502,128 @@ def test_bm25_staged_threshold_path_vs_oracle(eng, k):
         np.testing.assert_array_equal(rows[qi], top.astype(np.int32), err_msg=q)
         np.testing.assert_array_equal(scores[qi], raw[top] / m, err_msg=q)
         assert mx[qi] == m
+
+
+def _sparse_postings(rng, n_docs, n_terms, per_term):
+    """Term-major CSR with a few thousand postings per term spread over ALL doc ranges (cheap to build at millions of docs)."""
+    from optimized_rag_amd.bm25 import Bm25Postings
+    indptr, docs, tfs = [0], [], []
+    for t in range(n_terms):
+        d = np.unique(rng.integers(0, n_docs, per_term if t else 40 * per_term))       # term 0 is frequent
+        docs.append(d.astype(np.int32))
+        tfs.append(rng.integers(1, 4, d.shape[0]).astype(np.int32))
+        indptr.append(indptr[-1] + d.shape[0])
+    doc_len = rng.integers(5, 40, n_docs).astype(np.int32)
+    indptr = np.asarray(indptr, dtype=np.int64)
+    idf = Bm25Postings.idf_table(np.diff(indptr), n_docs)
+    return Bm25Postings(indptr, np.concatenate(docs), np.concatenate(tfs), doc_len, idf, float(doc_len.sum()) / n_docs)
+
+
+def test_bm25_more_than_256_ranges_reuses_workspace(eng):
+    """above 256 doc ranges (> 4,194,304 docs; a 12.5M-row shard has 763) the merge must still read only the
+    COUNTED front of every partial list. The same device workspace is used by two batches with different queries (so
+    stale slots of the first batch sit behind the second batch's fronts); both the host and the device entry must equal
+    the exact per-range select (RAG_BM25_NO_STAGING) and the CSR oracle, bit for bit."""
+    import torch
+    rng = np.random.default_rng(404)
+    n_docs, k = 4_500_000, 100                                   # 275 doc ranges
+    post = _sparse_postings(rng, n_docs, 48, 3000).load(eng)
+    batches = [[[0, 3, 7], [5], [1, 1, 2, 40], [47, 0], [-1], [9, 10, 11, 12, 13, 14]],
+               [[2, 0], [6, 7, 8], [30, 31], [0], [44, 45, 46, 47], [20]]]
+    for terms_of in batches:
+        ptr = np.cumsum([0] + [len(t) for t in terms_of]).astype(np.int32)
+        terms = np.asarray([x for t in terms_of for x in t], dtype=np.int32)
+        ids, rows, scores, mx = eng.bm25_topk(ptr, terms, k)
+        Q = len(terms_of)
+        di = torch.empty((Q, k), dtype=torch.int64, device="cuda")
+        dr = torch.empty((Q, k), dtype=torch.int32, device="cuda")
+        ds = torch.empty((Q, k), dtype=torch.float64, device="cuda")
+        eng.bm25_topk_dev(torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda(), k, di, dr, ds)
+        torch.cuda.synchronize()
+        os.environ["RAG_BM25_NO_STAGING"] = "1"
+        try:
+            _, rows_x, scores_x, mx_x = eng.bm25_topk(ptr, terms, k)
+        finally:
+            del os.environ["RAG_BM25_NO_STAGING"]
+        np.testing.assert_array_equal(rows, rows_x)
+        np.testing.assert_array_equal(scores, scores_x)
+        np.testing.assert_array_equal(dr.cpu().numpy(), rows_x)
+        np.testing.assert_array_equal(ds.cpu().numpy(), scores_x)
+        for qi, t in enumerate(terms_of):
+            raw = O.bm25_scores_csr(post.indptr, post.doc, post.tf, post.doc_len, post.idf, post.avgdl, t)
+            m = raw.max() if raw.max() > 0 else 1.0
+            top = O.stable_topk_desc(raw, k)
+            np.testing.assert_array_equal(rows[qi], top.astype(np.int32))
+            np.testing.assert_array_equal(scores[qi], raw[top] / m)
+            assert mx[qi] == m == mx_x[qi]
+
+
+def test_bm25_and_hybrid_tenant_filter(eng):
+    """the `WHERE agent_id = %s` of every reference query (rag/document_store.py:457) must hold for the BM25
+    leg too. Tenants: three interleaved ones plus one stored contiguously at the END of the table (the usual export
+    order). BM25 top-k under a tenant == oracle scores masked to the tenant's docs (global idf / avgdl), stable order,
+    divided by the tenant's own max; the hybrid call returns only that tenant's ids and equals the oracle composition."""
+    import torch
+    from optimized_rag_amd.bm25 import Bm25Postings
+    rng = np.random.default_rng(505)
+    N, D, Q, pool, k = 40_000, 1536, 10, 60, 20
+    docs = synthetic_postings(rng, N, 3000, 14)
+    corpus = [" ".join(f"t{t}" for t in d) for d in docs]
+    emb = rng.standard_normal((N, D)).astype(np.float32)
+    tenants = rng.integers(0, 3, N).astype(np.int32)
+    tenants[N - 700:] = 3                                                          # contiguous tenant, last doc range only
+    q = (emb[rng.integers(0, N, Q)] + 0.5 * rng.standard_normal((Q, D))).astype(np.float32)
+    queries = [" ".join(f"t{t}" for t in rng.choice(docs[int(rng.integers(0, N))] or [1], size=4)) for _ in range(Q)]
+    queries[2] = "nosuchtoken"
+    eng.index_load(emb, id_base=1000)
+    eng.set_tenants(tenants)
+    post = Bm25Postings.from_corpus(corpus).load(eng)
+    ptr, terms = post.encode_queries(queries)
+    obm = O.BM25Okapi([O.tokenize(c) for c in corpus])
+    qd, pd, td = torch.from_numpy(q).cuda(), torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda()
+    for tenant in (1, 3):
+        mine = np.nonzero(tenants == tenant)[0]
+        ids, rows, scores, mx = eng.bm25_topk(ptr, terms, pool, tenant=tenant)
+        keys, rrf, ranks = [t.cpu().numpy().copy() for t in eng.hybrid_rrf_dev(qd, pd, td, pool, k, tenant=tenant)]
+        d_ids, _ = O.dense_topk(emb, q, pool, tenant_of_row=tenants, tenant=tenant)
+        for qi in range(Q):
+            raw = obm.get_scores(O.tokenize(queries[qi]))[mine]
+            m = raw.max() if raw.max() > 0 else 1.0
+            top = O.stable_topk_desc(raw, pool)
+            np.testing.assert_array_equal(rows[qi], mine[top].astype(np.int32))
+            np.testing.assert_array_equal(scores[qi], raw[top] / m)
+            assert mx[qi] == m
+            okeys, oscores, oranks = O.rrf_fuse([[int(r) + 1000 for r in d_ids[qi] if r >= 0], [int(r) + 1000 for r in mine[top]]],
+                                                k=60, top_k=k)
+            assert keys[qi].tolist() == okeys and rrf[qi].tolist() == oscores and ranks[qi].tolist() == oranks
+            assert all(tenants[key - 1000] == tenant for key in keys[qi] if key >= 0)
+    eng.set_tenants(None)
+
+
+def test_adhoc_hybrid_search_keeps_resident_postings(eng):
+    """HybridRetriever.hybrid_search scores its ad-hoc corpus statelessly; the index's resident postings (and
+    their normalise flag) survive, and mis-aligned postings are refused by the hybrid call instead of read out of range."""
+    import torch
+    from optimized_rag_amd import RagError
+    from optimized_rag_amd.bm25 import Bm25Postings
+    from optimized_rag_amd.retrieval import HybridRetriever
+    rng = np.random.default_rng(606)
+    N, D = 3000, 1536
+    docs = synthetic_postings(rng, N, 500, 10)
+    corpus = [" ".join(f"t{t}" for t in d) for d in docs]
+    emb = rng.standard_normal((N, D)).astype(np.float32)
+    eng.index_load(emb)
+    post = Bm25Postings.from_corpus(corpus).load(eng)
+    ptr, terms = post.encode_queries(["t1 t2 t3", "t7"])
+    before = eng.bm25_topk(ptr, terms, 10)
+    hr = HybridRetriever(None, None, "a", engine=eng)
+    small = ["alpha beta", "beta gamma gamma", "delta"]
+    out = hr.hybrid_search("beta gamma", small, rng.standard_normal((3, 8)).tolist(), rng.standard_normal(8).tolist(), top_k=3)
+    assert sorted(r["content"] for r in out) == sorted(small)
+    after = eng.bm25_topk(ptr, terms, 10)
+    for a, b in zip(before, after):
+        np.testing.assert_array_equal(a, b)
+    Bm25Postings.from_corpus(small).load(eng)                                     # 3 docs vs 3000 rows: not row-aligned
+    qd = torch.from_numpy(emb[:2].copy()).cuda()
+    with pytest.raises(RagError, match="row-aligned"):
+        eng.hybrid_rrf_dev(qd, torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda(), 10, 5)

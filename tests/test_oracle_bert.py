@@ -39,3 +39,5 @@ def test_bert_oracle_matches_transformers_small():
                  attention_mask=torch.from_numpy(mask)).logits[:, 0].numpy()
     mine = B.forward_logits(w, cfg, ids, tt, lens)
     np.testing.assert_allclose(mine, ref, atol=1e-10)
+    # the vectorised-erf path the full-size GPU tests use is the same function
+    np.testing.assert_allclose(B.forward_logits(w, cfg, ids, tt, lens, fast_erf=True), mine, atol=1e-12)

@@ -45,3 +45,18 @@ def test_bm25_edge_cases():
     assert O.bm25_scores("q", []) == []
     assert O.bm25_scores("q", ["", "   "]) == [0.0, 0.0]        # retrieval.py:329-331
     assert O.bm25_scores("nothing", ["a b", "c d"]) == [0.0, 0.0]   # max <= 0 -> divide by 1.0
+
+
+def test_bm25_csr_form_is_bit_identical_to_the_dense_form():
+    """oracle.bm25_scores_csr (used by the GPU tests on corpora too large for token dicts) == BM25Okapi.get_scores."""
+    import tools_textgen as T
+    from optimized_rag_amd.bm25 import Bm25Postings
+    rng = np.random.default_rng(5)
+    corpus = [T.make_doc(rng, int(rng.integers(1, 5))) for _ in range(300)]
+    corpus[10] = ""
+    post = Bm25Postings.from_corpus(corpus)
+    bm = O.BM25Okapi([O.tokenize(c) for c in corpus])
+    for q in ["memory vector index", "paris paris london", "zzz unknown", "kernel"]:
+        _, terms = post.encode_queries([q])
+        got = O.bm25_scores_csr(post.indptr, post.doc, post.tf, post.doc_len, post.idf, post.avgdl, terms.tolist())
+        np.testing.assert_array_equal(got, bm.get_scores(O.tokenize(q)))

@@ -19,10 +19,9 @@ def build_pairs(q_tok, q_len, cand, tok, tok_len, L):
     tt = np.zeros((Q * pool, L), dtype=np.int64)
     lens = np.zeros(Q * pool, dtype=np.int64)
     for q in range(Q):
-        ql = int(min(q_len[q], q_tok.shape[1], L - 3))
         for j in range(pool):
             r = int(cand[q, j])
-            dl = 0 if r < 0 else int(min(tok_len[r], tok.shape[1], L - 3 - ql))
+            ql, dl = O.longest_first_lengths(int(min(q_len[q], q_tok.shape[1])), 0 if r < 0 else int(min(tok_len[r], tok.shape[1])), L - 3)
             row = [CLS] + list(q_tok[q, :ql]) + [SEP] + ([] if r < 0 else list(tok[r, :dl])) + [SEP]
             p = q * pool + j
             ids[p, :len(row)] = row
@@ -38,15 +37,17 @@ def test_retrieve_rerank_matches_oracle_composition(hybrid):
     from optimized_rag_amd.bm25 import Bm25Postings
     from optimized_rag_amd.cross_encoder import flatten_state_dict
     rng = np.random.default_rng(123 + hybrid)
-    N, D, Q, pool, k, Ld, Lq, L = 300, 1536, 3, 6, 4, 20, 8, 32
+    N, D, Q, pool, k, Ld, Lq, L = 300, 1536, 3, 6, 4, 20, 14, 24      # max_length 24: 21 content tokens per pair
     cfg = dict(vocab_size=2000, hidden=384, layers=2, heads=12, ffn=1536, max_pos=64, type_vocab=2, eps=1e-12)
     w = B.seeded_weights(cfg, 17)
     emb = rng.standard_normal((N, D)).astype(np.float32)
     q_emb = (emb[rng.integers(0, N, Q)] + 0.5 * rng.standard_normal((Q, D))).astype(np.float32)
     tok = rng.integers(200, cfg["vocab_size"], (N, Ld)).astype(np.int32)
     tok_len = rng.integers(3, Ld + 1, N).astype(np.int32)
-    tok_len[:5] = Ld                                                   # some passages need truncation (ql + dl + 3 > L)
+    tok_len[:5] = Ld
     q_tok = rng.integers(200, cfg["vocab_size"], (Q, Lq)).astype(np.int32)
+    # longest_first: a 14-token query against 20-token passages trims BOTH sides (10 | 11), against short passages only the
+    # query; the 3- and 5-token queries trim only long passages
     q_len = np.array([Lq, 3, 5], dtype=np.int32)
     corpus = [" ".join(f"t{t}" for t in tok[i, :tok_len[i]] % 40) for i in range(N)]
     queries = [" ".join(f"t{t}" for t in q_tok[i, :q_len[i]] % 40) for i in range(Q)]

@@ -54,7 +54,7 @@ class OracleEngine:
     def bm25_set_normalize(self, on):
         self.bm_norm = bool(on)
 
-    def bm25_topk_dev(self, term_ptr, terms, k, ids_out, rows_out, scores_out, raw_max_out=None, stream=None):
+    def bm25_topk_dev(self, term_ptr, terms, k, ids_out, rows_out, scores_out, raw_max_out=None, stream=None, tenant=-1):
         assert not self.bm_norm, "a row shard must hand out RAW scores"
         indptr, doc, tf, dl, idf, avgdl, k1, b = self.bm
         tp, tm = term_ptr.numpy(), terms.numpy()
