@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: dense cosine top-k=20 over a 1M x 1536-d synthetic corpus, batch = 1024 queries
-(BASELINE.json configs[1]), queries/sec with inputs resident in HBM.
+(BASELINE.json configs[1]), queries/sec with inputs resident in HBM. `value` / `roofline` / `cpu_baseline` of the JSON line
+are that configuration's. On one GPU the SAME line also carries the rest of BASELINE.json's metric ("queries/sec + p50
+retrieve+rerank latency"): a `hybrid` block (configs[2]: dense + BM25 + RRF), a `retrieve_rerank` block (configs[3]:
+hybrid top-100 -> MiniLM-L-6 cross-encoder -> top-20, batch 256, p50 single-query latency) and an `agent_latency`
+block (the calls the reference agent makes: DocumentStore.search, ConsistencyChecker, apply_mmr), each with its own
+roofline figures and a CPU baseline timed on this box's host cores (bench_modes.py; --dense-only skips them).
 
   python bench.py --gpus N --steps K --warmup W
   N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
@@ -68,6 +73,11 @@ def main():
     ap.add_argument("--mode", default="dense", choices=["dense", "hybrid", "rerank", "pipeline"],
                     help="dense = the headline metric (default); hybrid / rerank = BASELINE configs[2] / [3], single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense-only", action="store_true", help="skip the hybrid / retrieve_rerank / agent_latency blocks")
+    ap.add_argument("--corpus", default="iid", choices=["iid", "clustered", "sorted", "tenant-contiguous"],
+                    help="row order / structure of the synthetic corpus (default: i.i.d. unit Gaussians, BASELINE configs[1]); "
+                         "see bench_modes.structured_chunk")
+    ap.add_argument("--latency-batches", type=int, default=100, help="timed batches for the p50 (after 10 warm-ups)")
     ap.add_argument("--single-query-latency", action="store_true",
                     help="also time Q=1 searches (off by default so that every launch of the run has the bench shape and "
                          "rocprofv3's per-kernel averages match the reported ones)")
@@ -147,14 +157,16 @@ def main():
         dt = float(t.item())
     stats = eng.dense_stats()
 
-    # p50 latency of one batch, synchronised per step (not part of `value`)
+    # p50 latency of one batch, synchronised per step (not part of `value`): >= 100 timed batches after 10 warm-ups
+    # 
     lat = []
-    for _ in range(min(20, max(5, args.steps))):
+    for it in range(10 + max(1, args.latency_batches)):
         fence()
         a = time.perf_counter()
         step()
         torch.cuda.synchronize()
-        lat.append((time.perf_counter() - a) * 1e3)
+        if it >= 10:
+            lat.append((time.perf_counter() - a) * 1e3)
     p50 = float(np.median(lat))
 
     # single-query latency (what one agent turn sees): Q = 1 through the same entry point, synchronised
@@ -247,6 +259,21 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
     }
+    # ---- the rest of BASELINE.json's metric on the same resident index (one GPU only) ---------------------------------
+    if world == 1 and not args.dense_only and args.rows <= 2_000_000 and args.corpus == "iid":
+        import bench_modes as BM
+        del host_corpus
+        state = None
+        for name, fn in (("hybrid", lambda: BM.hybrid_block(eng, queries, args.rows, not args.no_cpu_baseline)),
+                         ("retrieve_rerank", lambda: BM.retrieve_rerank_block(eng, queries, args.rows, state, not args.no_cpu_baseline)),
+                         ("agent_latency", lambda: BM.agent_latency_block(eng, queries, args.rows, not args.no_cpu_baseline))):
+            try:
+                res = fn()
+                if name == "hybrid":
+                    res, state = res
+                out[name] = res
+            except Exception as e:                      # a secondary block must never cost the headline line
+                out[name] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

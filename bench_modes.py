@@ -254,3 +254,290 @@ def run_mode(args):
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+# =====================================================================================================================
+# Blocks of the DEFAULT bench line (python bench.py on one GPU): the rest of BASELINE.json's metric next to the dense
+# headline, on the same resident 1M x 1536 index. Each returns a dict that carries its own roofline figures and a
+# `cpu_baseline` timed on this box's host cores on a bounded sample (oracle/cpu_baseline.py).
+# =====================================================================================================================
+PEAK_MFMA_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0
+
+
+def _term_queries(tok, doc_ptr, N, Q, seed=7):
+    rng = np.random.default_rng(seed)
+    ptr, terms = [0], []
+    for i in range(Q):                                   # 4-12 tokens sampled from a random doc
+        di = int(rng.integers(0, N))
+        toks = tok[doc_ptr[di]:doc_ptr[di + 1]]
+        n = int(rng.integers(4, 13))
+        terms.extend(int(x) for x in (rng.choice(toks, n) if len(toks) else [0] * n))
+        ptr.append(len(terms))
+    return np.asarray(ptr, np.int32), np.asarray(terms, np.int32)
+
+
+def _p50_ms(fn, n, warm):
+    lat = []
+    for it in range(warm + n):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        if it >= warm:
+            lat.append((time.perf_counter() - a) * 1e3)
+    return float(np.median(lat))
+
+
+def hybrid_block(eng, q, N, cpu_baseline=True):
+    """BASELINE.json configs[2]: dense top-100 + BM25(CSR) top-100 + RRF(k=60) -> top-20, one rag_hybrid_rrf_dev call per
+    batch. Loads the postings into `eng` (they stay resident for the retrieve_rerank block). Returns (block, state)."""
+    from optimized_rag_amd.bm25 import Bm25Postings
+    device = q.device
+    Q, k, pool = q.shape[0], 20, 100
+    t0 = time.perf_counter()
+    indptr, d, tf, dl, tok, doc_ptr = synthetic_csr(N, 100_000, 120)
+    post = Bm25Postings(indptr, d, tf, dl, Bm25Postings.idf_table(np.diff(indptr).clip(min=0), N), float(dl.sum()) / N)
+    post.idf[np.diff(indptr) == 0] = 0.0
+    post.load(eng)
+    build_s = time.perf_counter() - t0
+    ptr, terms = _term_queries(tok, doc_ptr, N, Q)
+    ptr_d, terms_d = torch.from_numpy(ptr).to(device), torch.from_numpy(terms).to(device)
+    ids_d = torch.empty((Q, pool), dtype=torch.int64, device=device)
+    sc_d = torch.empty((Q, pool), dtype=torch.float64, device=device)
+
+    def hybrid(nq):
+        return eng.hybrid_rrf_dev(q[:nq], ptr_d[:nq + 1], terms_d, pool, k)
+
+    steps = 10
+    t_1024 = timed(lambda: hybrid(Q), steps, 2)
+    t_256 = timed(lambda: hybrid(256), steps, 2)
+    # BM25 leg alone, device time from HIP events on the launch stream (rag_stage_kernel_ms, stage 1)
+    eng.bm25_topk_dev(ptr_d, terms_d, pool, ids_d, None, sc_d)
+    torch.cuda.synchronize()
+    eng.set_profiling(True)
+    for _ in range(steps):
+        eng.bm25_topk_dev(ptr_d, terms_d, pool, ids_d, None, sc_d)
+    torch.cuda.synchronize()
+    bm_ms, bm_spans = eng.stage_kernel_ms(1)
+    eng.set_profiling(False)
+    counts = np.diff(indptr)
+    nnz_touched = float(counts[terms[terms >= 0]].sum())
+    bm_gbs = nnz_touched * 12.0 / (bm_ms / bm_spans * 1e-3) / 1e9
+    p50_1 = _p50_ms(lambda: hybrid(1), 100, 10)
+    block = {
+        "workload": f"{N} docs: dense top-{pool} + BM25(CSR, nnz={int(indptr[-1])}) top-{pool} + RRF(k=60) -> top-{k} "
+                    "(BASELINE.json configs[2]); one rag_hybrid_rrf_dev call per batch, everything resident in HBM",
+        "value": round(Q / t_1024, 1), "unit": "queries/sec", "batch_queries": Q, "ms_per_batch": round(t_1024 * 1e3, 3),
+        "queries_per_sec_batch256": round(256 / t_256, 1), "p50_single_query_latency_ms": round(p50_1, 4),
+        "roofline": {"bound": "hbm", "kernel": "bm25_range_kernel + bm25_merge_stage_kernel (BM25 top-100 of one batch)",
+                     "achieved": round(bm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(bm_gbs / PEAK_HBM_GBS, 4),
+                     "traffic": None, "avg_call_ms": round(bm_ms / bm_spans, 4),
+                     "algorithmic_bytes_per_call": nnz_touched * 12.0,
+                     "note": "algorithmic bytes = postings of the batch's query terms x 12 B (doc id + float64 impact), SURVEY 8d; "
+                             "most posting reads are L2 hits (frequent terms are shared by the batch), so the achieved figure can "
+                             "exceed what HBM alone would deliver"},
+        "index_build_s": round(build_s, 1),
+    }
+    if cpu_baseline:
+        from oracle.cpu_baseline import bm25_topk_numpy
+        ns = 24
+        rows, cdt = bm25_topk_numpy(indptr, d, tf, dl, post.idf, post.avgdl, ptr[:ns + 1], terms, pool)
+        ids_d2 = torch.empty((Q, pool), dtype=torch.int64, device=device)
+        rows_d2 = torch.empty((Q, pool), dtype=torch.int32, device=device)
+        eng.bm25_topk_dev(ptr_d, terms_d, pool, ids_d2, rows_d2, sc_d)
+        torch.cuda.synchronize()
+        same = float(np.mean([len(set(rows[i]) & set(rows_d2[i].cpu().numpy())) / pool for i in range(ns)]))
+        block["cpu_baseline"] = {"value": round(ns / cdt, 2), "unit": "queries/sec (BM25 top-100 leg only)", "cores": 1, "kind": "port",
+                                 "sample": f"{ns} of the {Q} term queries against the full {N}-doc postings: numpy BM25Okapi restatement "
+                                           f"over CSR (all-doc float64 scores, /max, top-{pool}), {cdt:.2f}s",
+                                 "topk_overlap_with_gpu": round(same, 5)}
+    return block, dict(ptr_d=ptr_d, terms_d=terms_d, indptr=indptr)
+
+
+def retrieve_rerank_block(eng, q, N, hyb_state, cpu_baseline=True):
+    """BASELINE.json configs[3]: hybrid top-100 -> ms-marco-MiniLM-L-6 shape cross-encoder -> top-20, batch = 256 queries,
+    ONE rag_retrieve_rerank_dev call per batch; p50 single-query retrieve+rerank latency over 100 calls."""
+    from optimized_rag_amd.cross_encoder import MINILM_L6_CONFIG, random_init_tensors
+    device = q.device
+    Q, k, pool, L, Ld, Lq = 256, 20, 100, 256, 224, 16
+    cfg = MINILM_L6_CONFIG
+    tensors = random_init_tensors(cfg, 2024)
+    eng.ce_load(cfg, tensors)
+    # passage token store: WordPiece ids ~U[1000, vocab), lengths ~U[96, 224] (SURVEY 8d), 16-token queries
+    tok_store = torch.randint(1000, cfg["vocab_size"], (N, Ld), generator=torch.Generator().manual_seed(5), dtype=torch.int32)
+    tok_len = torch.randint(96, Ld + 1, (N,), generator=torch.Generator().manual_seed(6), dtype=torch.int32)
+    eng.tokens_load(tok_store.numpy(), tok_len.numpy())
+    q_tok = torch.randint(1000, cfg["vocab_size"], (Q, Lq), generator=torch.Generator().manual_seed(8), dtype=torch.int32)
+    q_tok_d = q_tok.to(device)
+    q_len = torch.full((Q,), Lq, dtype=torch.int32, device=device)
+    ptr_d, terms_d = hyb_state["ptr_d"], hyb_state["terms_d"]
+
+    def run(nq):
+        return eng.retrieve_rerank_dev(q[:nq], q_tok_d[:nq], q_len[:nq], pool, k, term_ptr=ptr_d[:nq + 1], terms=terms_d, L_pair=L)
+
+    steps = 4
+    run(Q)
+    torch.cuda.synchronize()
+    eng.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run(Q)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / steps
+    ce_ms, ce_spans = eng.stage_kernel_ms(2)
+    eng.set_profiling(False)
+    lat_b = _p50_ms(lambda: run(Q), 5, 0)
+    lat_1 = _p50_ms(lambda: run(1), 100, 10)
+    ids, sc, lg, cand = run(Q)
+    torch.cuda.synchronize()
+    cand_h = cand.cpu().numpy()
+    ok = bool((ids >= 0).all().item() and (sc[:, :-1] >= sc[:, 1:]).all().item())
+    # algorithmic FLOPs of one batch: SURVEY 8d per-pair formula 6 * len * (3.539e6 + 1536 * len) on the REAL token counts
+    # of the pairs that were scored ([CLS] q [SEP] passage [SEP], longest_first to L); padding is neither computed nor counted
+    plen = np.minimum(Lq + tok_len.numpy()[cand_h.reshape(-1)].astype(np.float64) + 3, L)
+    flops = float((6.0 * plen * (3.539e6 + 1536.0 * plen)).sum())
+    ce_tf = flops / (ce_ms / ce_spans * 1e-3) / 1e12
+    block = {
+        "workload": f"{N} docs x {DIM}-d + BM25 CSR + {Ld}-token passage store; batch={Q} queries: dense top-{pool} + BM25 top-{pool} "
+                    f"+ RRF -> top-{pool} -> MiniLM-L-6 cross-encoder (L={L}, {Q * pool} pairs, mean {plen.mean():.0f} tokens) -> top-{k} "
+                    "(BASELINE.json configs[3]); one rag_retrieve_rerank_dev call per batch",
+        "value": round(Q / t, 2), "unit": "queries/sec", "batch_queries": Q, "ms_per_batch": round(t * 1e3, 2), "steps": steps,
+        "p50_batch_latency_ms": round(lat_b, 2), "p50_single_query_latency_ms": round(lat_1, 3),
+        "pairs_per_sec": round(Q * pool / t, 1),
+        "roofline": {"bound": "mfma", "kernel": "cross-encoder forward (ce_gemm_kernel<*> + ce_attention_kernel + epilogues), all chunks of a batch",
+                     "achieved": round(ce_tf, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ce_tf / PEAK_MFMA_TFLOPS, 4),
+                     "traffic": None, "avg_forward_ms": round(ce_ms / ce_spans, 3), "algorithmic_flops_per_forward": flops,
+                     "share_of_batch_time": round(ce_ms / ce_spans / (t * 1e3), 4),
+                     "note": "algorithmic FLOPs / device time of the forward (HIP events on the launch stream); operands are split-fp16 "
+                             "(hi + lo) to hold the 1e-3 score bar, so the matrix pipe issues up to 3 MFMAs per algorithmic product"},
+        "sanity": {"all_slots_filled_and_sorted": ok},
+    }
+    if cpu_baseline:
+        from oracle.cpu_baseline import bert_cpu_pairs
+        ns = 64                                              # 2 batches of 32 pairs = the first 64 pairs of query 0
+        pid = np.zeros((ns, L), dtype=np.int64)
+        ptt = np.zeros((ns, L), dtype=np.int64)
+        pl = np.zeros(ns, dtype=np.int64)
+        tok_np = tok_store.numpy()
+        for j in range(ns):
+            r = int(cand_h[0, j])
+            dlen = int(min(tok_len[r], L - 3 - Lq))
+            row = [101] + q_tok[0].tolist() + [102] + tok_np[r, :dlen].tolist() + [102]
+            pid[j, :len(row)] = row
+            ptt[j, Lq + 2:len(row)] = 1
+            pl[j] = len(row)
+        cl, cdt, threads = bert_cpu_pairs(cfg, tensors, pid, ptt, pl, batch=32)
+        block["cpu_baseline"] = {"value": round(ns / cdt / pool, 4), "unit": "queries/sec (rerank of 100 pairs per query)", "cores": threads,
+                                 "kind": "port", "pairs_per_sec": round(ns / cdt, 2),
+                                 "sample": f"{ns} of the batch's {Q * pool} pairs (the first {ns} candidates of query 0), torch-CPU "
+                                           f"BertForSequenceClassification fp32, batch 32 padded to the longest pair "
+                                           f"(what sentence-transformers' CrossEncoder.predict does on CPU), {cdt:.2f}s"}
+    del tok_store
+    return block
+
+
+class _Rows:
+    """list-like payload table of the 1M-row index: rows are synthesised on access (no 1M dicts in memory)."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return {"content": f"chunk {int(i)}", "filename": "bench.txt", "file_type": "txt", "metadata": {}, "id": int(i)}
+
+
+def agent_latency_block(eng, q, N, cpu_baseline=True):
+    """What ONE agent turn calls, through the Python mirror classes (host pointers, synchronous C-ABI entries, dict assembly):
+    GpuDocumentIndex.search (DocumentStore.search, rag/document_store.py:424-485, WHERE agent_id = ..., top_k 5),
+    ConsistencyChecker.check_consistency on C = 60 claims (rag/consistency_checker.py:148-191), apply_mmr 12 -> 5
+    (rag/nodes/helpers.py:183-260). p50 over 100 calls each, next to the reference's literal pure-Python loops."""
+    from optimized_rag_amd.consistency_checker import ConsistencyChecker
+    from optimized_rag_amd.document_store import GpuDocumentIndex
+    from optimized_rag_amd.nodes_helpers import apply_mmr
+    qh = q[:8].cpu().numpy()
+    qlist = [[float(x) for x in row] for row in qh]
+
+    class Svc:
+        def __init__(self):
+            self.i = 0
+
+        def generate_embedding(self, text):
+            self.i += 1
+            return qlist[self.i % len(qlist)]
+
+        def generate_embeddings_batch(self, texts):
+            return [claim_emb[t] for t in texts]
+
+    svc = Svc()
+    idx = GpuDocumentIndex(svc, dim=DIM, engine=eng)
+    idx.rows = _Rows(N)
+    idx._tenant_id = {"agent-0": 0}
+    eng.set_tenants(np.zeros(N, dtype=np.int32))
+
+    def search():
+        out = idx.search("agent-0", "what is in the corpus", top_k=5)
+        assert len(out) == 5
+
+    def wall_p50(fn, n=100, warm=10):
+        lat = []
+        for it in range(warm + n):
+            a = time.perf_counter()
+            fn()
+            if it >= warm:
+                lat.append((time.perf_counter() - a) * 1e3)
+        return float(np.median(lat))
+
+    p_search = wall_p50(search)
+    search_raw = wall_p50(lambda: eng.dense_topk(qh[:1], 5, tenant=0))
+    eng.set_tenants(None)
+    # consistency: 5 documents x 12 claims of >= 20 characters, seeded claim embeddings with a few near-duplicates
+    rng = np.random.default_rng(11)
+    words = "memory vector index query document retrieval ranking fusion agent graph node embedding cosine score".split()
+    docs, claim_emb, doc_of, texts = [], {}, [], []
+    base = rng.standard_normal((60, DIM))
+    base[7] = base[31] + 0.05 * rng.standard_normal(DIM)                          # one pair above the 0.85 threshold
+    c = 0
+    for di in range(5):
+        sents = []
+        for _ in range(12):
+            t = " ".join(rng.choice(words, 7)) + f" number {c}"
+            claim_emb[t] = [float(x) for x in base[c].astype(np.float32)]
+            sents.append(t)
+            texts.append(t)
+            doc_of.append(di)
+            c += 1
+        docs.append({"content": ". ".join(sents) + ".", "source": f"doc_{di}"})
+    chk = ConsistencyChecker(svc, similarity_threshold=0.85, engine=eng)
+    res = chk.check_consistency([dict(x) for x in docs], "query")
+    assert res.get("total_claims", 60) == 60, res
+    p_cons = wall_p50(lambda: chk.check_consistency([dict(x) for x in docs], "query"))
+    # apply_mmr: 12 retrieved documents carrying their embeddings -> 5
+    cand_emb = rng.standard_normal((12, DIM)).astype(np.float32)
+    mdocs = [{"content": f"d{i}", "embedding": [float(x) for x in cand_emb[i]]} for i in range(12)]
+    p_mmr = wall_p50(lambda: apply_mmr("the query", mdocs, 0.7, 5, svc, engine=eng))
+    block = {
+        "workload": f"single calls through the Python mirror classes on the resident {N}-row index (host pointers in, dicts out)",
+        "p50_ms": {"GpuDocumentIndex.search(agent_id, query, top_k=5) incl. 5 embedding fetches + dict assembly": round(p_search, 4),
+                   "rag_dense_topk_host alone (Q=1, k=5, tenant filter)": round(search_raw, 4),
+                   "ConsistencyChecker.check_consistency (5 docs, 60 claims, 1440 cross-document pairs)": round(p_cons, 4),
+                   "apply_mmr (12 candidates -> 5, embeddings attached)": round(p_mmr, 4)},
+        "calls_per_p50": 100,
+    }
+    if cpu_baseline:
+        from oracle.cpu_baseline import python_loop_consistency, python_loop_mmr, python_loop_semantic_scan
+        t_scan, _ = python_loop_semantic_scan(4096, DIM)
+        t_cons, _ = python_loop_consistency([claim_emb[t] for t in texts], doc_of)
+        t_mmr, _ = python_loop_mmr(qlist[1], cand_emb, 5, 0.7)
+        block["cpu_baseline"] = {
+            "kind": "port", "cores": 1, "unit": "ms per call",
+            "value": {"semantic scan of ONE query over 4096 documents (rag/retrieval.py:253-256 loop; the reference's search itself "
+                      "is a Postgres round trip, absent here)": round(t_scan * 1e3, 2),
+                      "consistency pair loop, 60 claims (rag/consistency_checker.py:169-189)": round(t_cons * 1e3, 2),
+                      "apply_mmr loop, 12 -> 5 (rag/nodes/helpers.py:229-252)": round(t_mmr * 1e3, 2)},
+            "sample": "the literal pure-Python generator-sum cosine loops of the reference, one core, same vectors as the GPU calls "
+                      "(N = 4096 for the scan: the full 1M-row loop would take minutes)"}
+    return block

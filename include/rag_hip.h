@@ -102,6 +102,11 @@ int rag_dense_last_stats(rag_handle_t h, rag_dense_stats* out);
 /* Names/launch geometry of the dominant kernel of the last dense search, for bench.py's roofline. */
 int rag_dense_kernel_ms(rag_handle_t h, float* gemm_ms_out, int* gemm_launches_out);
 int rag_set_profiling(rag_handle_t h, int enable);
+/* Measurement hook (bench.py's rooflines; the reference has nothing to mirror): with profiling on, HIP event pairs are
+ * recorded on the launch stream around stage 0 = every thresholded dense GEMM launch (== rag_dense_kernel_ms),
+ * 1 = the BM25 posting-range + merge launches of each top-k call, 2 = each cross-encoder forward. Returns the summed
+ * device time and the number of spans since profiling was (re)enabled; synchronises on the spans' end events. */
+int rag_stage_kernel_ms(rag_handle_t h, int stage, float* ms_out, int* spans_out);
 
 /* ---- merge of per-shard partial top-k lists (multi-GPU exchange step).
  * list l lives at ids_dev + l*list_stride / scores_dev + l*list_stride, each [Q][k] (ids int64, scores

@@ -58,6 +58,7 @@ _SIGS = {
     "rag_dense_topk_dev": ([_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
     "rag_dense_last_stats": ([_P, C.POINTER(DenseStats)], C.c_int),
     "rag_dense_kernel_ms": ([_P, C.POINTER(C.c_float), C.POINTER(C.c_int)], C.c_int),
+    "rag_stage_kernel_ms": ([_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)], C.c_int),
     "rag_merge_topk_dev": ([_P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P, _P], C.c_int),
     "rag_pairwise_cosine_host": ([_P, _P, C.c_int, _P, C.c_int, C.c_int, _P], C.c_int),
     "rag_rrf_fuse_host": ([_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P], C.c_int),
@@ -267,6 +268,12 @@ class RagEngine:
     def dense_kernel_ms(self):
         ms, n = C.c_float(), C.c_int()
         self._check(self.lib.rag_dense_kernel_ms(self.h, C.byref(ms), C.byref(n)), "rag_dense_kernel_ms")
+        return float(ms.value), int(n.value)
+
+    def stage_kernel_ms(self, stage):
+        """(summed device ms, spans) of profiling stage 0 dense emit / 1 BM25 top-k / 2 cross-encoder forward."""
+        ms, n = C.c_float(), C.c_int()
+        self._check(self.lib.rag_stage_kernel_ms(self.h, int(stage), C.byref(ms), C.byref(n)), "rag_stage_kernel_ms")
         return float(ms.value), int(n.value)
 
     def merge_topk_dev(self, ids, scores, ids_out, scores_out, n_lists=None, list_stride=None, stream=None):

@@ -93,10 +93,11 @@ int rag_destroy(rag_handle_t h) {
     pipeline_free(h);
     hipFree(h->q32); hipFree(h->q16); hipFree(h->cand); hipFree(h->cnt); hipFree(h->tau); hipFree(h->bound);
     hipFree(h->n_sorted); hipFree(h->exact); hipFree(h->flag); hipFree(h->stats); hipFree(h->stage);
-    for (auto& e : h->gemm_events) {
-        hipEventDestroy(e.first);
-        hipEventDestroy(e.second);
-    }
+    for (auto& p : h->prof)
+        for (auto& e : p.ev) {
+            hipEventDestroy(e.first);
+            hipEventDestroy(e.second);
+        }
     hipStreamDestroy(h->stream);
     delete h;
     return RAG_OK;
@@ -115,7 +116,7 @@ int rag_set_profiling(rag_handle_t h, int enable) {
     if (!h) return RAG_ERR_ARG;
     LOCK(h);
     h->profiling = enable != 0;
-    h->gemm_events_used = 0;      // (re)start collecting per-launch events of the dominant kernel
+    for (auto& p : h->prof) p.used = 0;      // (re)start collecting spans
     return RAG_OK;
 }
 
@@ -308,21 +309,27 @@ int rag_dense_last_stats(rag_handle_t h, rag_dense_stats* out) {
     return RAG_OK;
 }
 
-int rag_dense_kernel_ms(rag_handle_t h, float* gemm_ms_out, int* launches_out) {
-    if (!h || !gemm_ms_out || !launches_out) return RAG_ERR_ARG;
+int rag_stage_kernel_ms(rag_handle_t h, int stage, float* ms_out, int* spans_out) {
+    if (!h || !ms_out || !spans_out) return RAG_ERR_ARG;
     LOCK(h);
-    ARG_CHECK(h, h->profiling && h->gemm_events_used > 0, "profiling not enabled or no search ran");
+    ARG_CHECK(h, stage >= 0 && stage < RAG_PROF_STAGES, "stage must be 0 (dense emit), 1 (bm25) or 2 (cross-encoder)");
+    auto& p = h->prof[stage];
+    ARG_CHECK(h, p.used > 0, "no span recorded for this stage (rag_set_profiling(h, 1) before the calls)");
     HIP_TRY(h, hipSetDevice(h->device));
     float total = 0.f;
-    for (int i = 0; i < h->gemm_events_used; ++i) {
-        HIP_TRY(h, hipEventSynchronize(h->gemm_events[i].second));
+    for (int i = 0; i < p.used; ++i) {
+        HIP_TRY(h, hipEventSynchronize(p.ev[i].second));
         float ms = 0.f;
-        HIP_TRY(h, hipEventElapsedTime(&ms, h->gemm_events[i].first, h->gemm_events[i].second));
+        HIP_TRY(h, hipEventElapsedTime(&ms, p.ev[i].first, p.ev[i].second));
         total += ms;
     }
-    *gemm_ms_out = total;
-    *launches_out = h->gemm_events_used;
+    *ms_out = total;
+    *spans_out = p.used;
     return RAG_OK;
+}
+
+int rag_dense_kernel_ms(rag_handle_t h, float* gemm_ms_out, int* launches_out) {
+    return rag_stage_kernel_ms(h, 0, gemm_ms_out, launches_out);
 }
 
 int rag_merge_topk_dev(rag_handle_t h, const int64_t* ids_dev, const double* scores_dev, int n_lists, int64_t list_stride,

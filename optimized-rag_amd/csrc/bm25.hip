@@ -714,9 +714,10 @@ int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_
     const bm25_topk_ws w = {ix->ws_key, ix->ws_row, ix->ws_cnt, ix->ws_run_key, ix->ws_run_row, ix->ws_tau};
     const bm25_topk_out o = {aligned ? h->ids : (const int64_t*)nullptr, aligned ? h->id_base : (int64_t)0, ids_dev, rows_dev, scores_dev,
                              raw_max_dev, ix->normalize};
+    if ((rc = prof_begin(h, 1, st))) return rc;
     bm25_launch_topk(ix, term_ptr_dev, terms_dev, Q, k, w, o, tenants, tenant, st);
     HIP_TRY(h, hipGetLastError());
-    return RAG_OK;
+    return prof_end(h, 1, st);
 }
 
 int bm25_set_normalize(rag_ctx* h, int on) {

@@ -22,6 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define RAG_MAX_K 256            // largest k / shortlist supported by the select kernels
 #define RAG_SCALE_LOG2 7         // unit rows are stored as fp16(128 * x): keeps fp16 out of subnormals
 
+#define RAG_PROF_STAGES 3
 struct rag_ce_model;             // cross_encoder.hip
 struct rag_bm25_index;           // bm25.hip
 
@@ -66,10 +67,11 @@ struct rag_ctx {
     // lock); *_dev calls are serialised while they enqueue and share the handle's workspaces, so they must target ONE stream.
     std::mutex mu;
 
-    // profiling of the dominant kernel
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_events;
-    int gemm_events_used = 0;
+    // profiling (rag_set_profiling): HIP event pairs recorded on the launch stream around the spans bench.py prices against
+    // a roofline. Stage 0 = every dense_emit_kernel<false> launch, 1 = the BM25 range + merge launches of one top-k call,
+    // 2 = one cross-encoder forward (all chunks of a rag_ce_score_dev / rag_retrieve_rerank_dev call).
+    struct prof_spans { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; int used = 0; };
+    prof_spans prof[RAG_PROF_STAGES];
     rag_dense_stats last_stats = {};
     bool last_stats_valid = false;
     int last_q = 0, last_k = 0, last_stages = 0, last_shortlist = 0;
@@ -107,6 +109,27 @@ struct rag_ctx {
     } while (0)
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- profiling spans (no-ops unless rag_set_profiling(h, 1))
+static inline int prof_begin(rag_ctx* h, int stage, hipStream_t st) {
+    if (!h->profiling) return RAG_OK;
+    auto& p = h->prof[stage];
+    if ((int)p.ev.size() <= p.used) {
+        hipEvent_t a, b;
+        HIP_TRY(h, hipEventCreate(&a));
+        HIP_TRY(h, hipEventCreate(&b));
+        p.ev.push_back({a, b});
+    }
+    HIP_TRY(h, hipEventRecord(p.ev[p.used].first, st));
+    return RAG_OK;
+}
+static inline int prof_end(rag_ctx* h, int stage, hipStream_t st) {
+    if (!h->profiling) return RAG_OK;
+    auto& p = h->prof[stage];
+    HIP_TRY(h, hipEventRecord(p.ev[p.used].second, st));
+    p.used++;
+    return RAG_OK;
+}
 
 // ---- staging arena (see rag_ctx::stage): sum stage_size() of every piece, stage_reserve() once, stage_take() in the same order
 static inline size_t stage_size(size_t n, size_t elt) { return (size_t)round_up((int64_t)(n * elt), 256); }

@@ -871,6 +871,7 @@ int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* l
     const hipMemcpyKind kin = host_ptrs ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     const hipMemcpyKind kout = host_ptrs ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     int32_t *sid = m->sid, *stt = m->stt;
+    if ((rc = prof_begin(h, 2, st))) return rc;
     for (int p0 = 0; p0 < P; p0 += chunk) {
         const int pc = std::min(chunk, P - p0);
         HIP_TRY(h, hipMemcpyAsync(sid, ids + (size_t)p0 * L_in, (size_t)pc * L_in * 4, kin, st));
@@ -882,6 +883,7 @@ int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* l
         if (rc) break;
         HIP_TRY(h, hipMemcpyAsync(out + p0, m->logits, (size_t)pc * 4, kout, st));
     }
+    if (!rc) rc = prof_end(h, 2, st);
     // device-pointer calls stay asynchronous on the caller's stream (all buffers belong to the model workspace);
     // host-pointer calls return results, so they wait
     hipError_t e = host_ptrs ? hipStreamSynchronize(st) : hipGetLastError();

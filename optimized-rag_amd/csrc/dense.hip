@@ -824,14 +824,9 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
         if (total_tiles - end < end / 4) end = total_tiles;
         const int n_rt = end - begin;
         const int grid = (int)round_up(n_rt, 8) * n_qtiles;
-        if (h->profiling && stage > 0) {      // the thresholded kernel only (stage 0 is 0.2% of the rows)
-            if ((int)h->gemm_events.size() <= h->gemm_events_used) {
-                hipEvent_t a, b;
-                HIP_TRY(h, hipEventCreate(&a));
-                HIP_TRY(h, hipEventCreate(&b));
-                h->gemm_events.push_back({a, b});
-            }
-            HIP_TRY(h, hipEventRecord(h->gemm_events[h->gemm_events_used].first, st));
+        if (stage > 0) {                      // the thresholded kernel only (stage 0 is 0.2% of the rows)
+            const int prc = prof_begin(h, 0, st);
+            if (prc) return prc;
         }
         if (stage == 0)
             hipLaunchKernelGGL((dense_emit_kernel<true, false>), dim3(grid), dim3(512), DENSE_LDS_BYTES, st, h->emb16, h->q16,
@@ -843,9 +838,9 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
             hipLaunchKernelGGL((dense_emit_kernel<false, false>), dim3(grid), dim3(512), DENSE_LDS_BYTES, st, h->emb16, h->q16,
                                h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant STAMP_ARG);
         HIP_TRY(h, hipGetLastError());
-        if (h->profiling && stage > 0) {
-            HIP_TRY(h, hipEventRecord(h->gemm_events[h->gemm_events_used].second, st));
-            h->gemm_events_used++;
+        if (stage > 0) {
+            const int prc = prof_end(h, 0, st);
+            if (prc) return prc;
         }
         const bool last = end == total_tiles;
         hipLaunchKernelGGL(select_kernel, dim3((Q + 3) / 4), dim3(256), SELECT_LDS_BYTES, st, h->cand, h->cnt, tau, h->bound,
