@@ -35,18 +35,58 @@ PEAK_MFMA_TFLOPS = 2500.0       # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0           # HBM3E spec peak, MI355X_MICROARCH.md
 
 
-def gen_chunk(c, rows, device):
+N_CLUSTERS = 1000               # --corpus clustered: 1,000 clusters of rows/1000 rows each, stored cluster by cluster
+N_TENANTS = 100                 # --corpus tenant-contiguous: 100 tenants of rows/100 contiguous rows each
+BENCH_TENANT = 97               # ... and the whole query batch belongs to a tenant near the END of the table
+
+
+def gen_chunk(c, rows, device, kind="iid", total_rows=None):
+    """Chunk c (rows [c*rows, (c+1)*rows)) of the synthetic corpus, unit rows.
+    iid (BASELINE configs[1]): i.i.d. Gaussian directions - any row order is exchangeable.
+    clustered: row = unit(center + noise of norm ~1) (cosine ~0.71 to its centre), 1,000 rows per cluster, stored cluster
+      by cluster (a table inserted file by file): a query's whole neighbourhood sits in one ~1,000-row stretch.
+    sorted: an i.i.d. direction plus a drift along a fixed axis that grows with the row number from -1.5 to +1.5 (a
+      topic-sorted table): the rows most similar to a late query are all at the end of the table.
+    tenant-contiguous: i.i.d. rows; the tenant column (bench_tenants) is what is structured."""
     g = torch.Generator(device=device)
     g.manual_seed(1234 + c)
     x = torch.randn((rows, DIM), generator=g, device=device, dtype=torch.float32)
+    if kind == "clustered":
+        per = max(1, (total_rows or rows) // N_CLUSTERS)
+        cid = (torch.arange(rows, device=device) + c * rows) // per
+        cg = torch.Generator(device=device)
+        cg.manual_seed(99)
+        centers = torch.randn((N_CLUSTERS + 1, DIM), generator=cg, device=device)
+        centers /= centers.norm(dim=1, keepdim=True)
+        x = centers[cid.clamp(max=N_CLUSTERS)] + x / DIM ** 0.5
+    elif kind == "sorted":
+        ug = torch.Generator(device=device)
+        ug.manual_seed(98)
+        u = torch.randn((DIM,), generator=ug, device=device)
+        u /= u.norm()
+        pos = (torch.arange(rows, device=device, dtype=torch.float32) + c * rows) / float(total_rows or rows)
+        x = x / DIM ** 0.5 + (3.0 * pos - 1.5)[:, None] * u[None, :]
     return x / x.norm(dim=1, keepdim=True)
 
 
-def gen_queries(Q, total_rows, n_chunks, chunk_rows, device):
-    """query i = normalised(corpus[r_i] + 0.5 * unit-scale noise): one planted neighbour at cos ~0.89."""
+def bench_tenants(total_rows):
+    """tenant-contiguous: tenant t owns rows [t * total/100, (t+1) * total/100) - the order a per-agent export produces."""
+    return (np.arange(total_rows, dtype=np.int64) * N_TENANTS // total_rows).astype(np.int32)
+
+
+def gen_queries(Q, total_rows, n_chunks, chunk_rows, device, kind="iid"):
+    """query i = normalised(corpus[r_i] + 0.5 * unit-scale noise): one planted neighbour at cos ~0.89. For the structured
+    corpora the planted rows are drawn where the old contiguous schedule was weakest: the last fifth of the table
+    (clustered / sorted), the bench tenant's own rows (tenant-contiguous)."""
     g = torch.Generator(device="cpu")
     g.manual_seed(4321)
-    rows = torch.randint(0, total_rows, (Q,), generator=g)
+    if kind == "tenant-contiguous":
+        lo, hi = BENCH_TENANT * total_rows // N_TENANTS, (BENCH_TENANT + 1) * total_rows // N_TENANTS
+    elif kind in ("clustered", "sorted"):
+        lo, hi = total_rows * 4 // 5, total_rows
+    else:
+        lo, hi = 0, total_rows
+    rows = torch.randint(lo, hi, (Q,), generator=g)
     noise_g = torch.Generator(device=device)
     noise_g.manual_seed(4322)
     noise = torch.randn((Q, DIM), generator=noise_g, device=device) * (0.5 / DIM ** 0.5)
@@ -55,7 +95,7 @@ def gen_queries(Q, total_rows, n_chunks, chunk_rows, device):
         sel = ((rows // chunk_rows) == c).nonzero().flatten()
         if sel.numel() == 0:
             continue
-        chunk = gen_chunk(c, chunk_rows, device)
+        chunk = gen_chunk(c, chunk_rows, device, kind, total_rows)
         q[sel.to(device)] = chunk[(rows[sel] % chunk_rows).to(device)]
         del chunk
     q = q + noise
@@ -119,12 +159,17 @@ def main():
     eng.index_reserve(n_local, id_base=id_base)
     host_parts = [] if (rank == 0 and world == 1 and not args.no_cpu_baseline and args.rows <= 2_000_000) else None
     for c in my_chunks:
-        blk = gen_chunk(c, chunk_rows, device)
+        blk = gen_chunk(c, chunk_rows, device, args.corpus, args.rows)
         eng.index_append(blk)
         if host_parts is not None:
             host_parts.append(blk.cpu())
         del blk
-    queries, planted = gen_queries(Q, args.rows, n_chunks, chunk_rows, device)
+    queries, planted = gen_queries(Q, args.rows, n_chunks, chunk_rows, device, args.corpus)
+    tenant = -1
+    if args.corpus == "tenant-contiguous":
+        assert world == 1, "--corpus tenant-contiguous is a single-GPU robustness run"
+        eng.set_tenants(bench_tenants(args.rows))
+        tenant = BENCH_TENANT
     host_corpus = torch.cat(host_parts) if host_parts else None
     del host_parts
     torch.cuda.empty_cache()
@@ -133,7 +178,7 @@ def main():
     index = ShardedDenseIndex(eng, rank=rank, world=world)
 
     def step():
-        return index.search(queries, k)
+        return index.search(queries, k, tenant=tenant)
 
     def fence():
         if world > 1:
@@ -197,16 +242,19 @@ def main():
         return
 
     # ---- roofline of the dominant kernel: dense_emit_kernel<false> (the thresholded GEMM stages) -----------
-    stage0_rows = min(n_local, 2048)
+    # rows one search scores: the whole shard, or (tenant filter) the tenant's own tiles only
+    t_lo, t_hi = (BENCH_TENANT * args.rows // N_TENANTS, (BENCH_TENANT + 1) * args.rows // N_TENANTS) if tenant >= 0 else (0, n_local)
+    n_scan = ((t_hi + 255) // 256 - t_lo // 256) * 256 if tenant >= 0 else n_local
+    stage0_rows = min(n_scan, 2048)
     roof_bytes_note = None
     dim_pad = (DIM + 63) // 64 * 64
     # algorithmic work of the thresholded GEMM stages per step on this rank: every (query, row) dot product once, every
     # fp16 corpus row read once (+ the query tile once per launch). No padding counted.
-    flops_per_step = 2.0 * Q * (n_local - stage0_rows) * DIM
+    flops_per_step = 2.0 * Q * (n_scan - stage0_rows) * DIM
     launches_per_step = gemm_launches / args.steps
     avg_launch_ms = gemm_ms / gemm_launches
     achieved_tflops = flops_per_step * args.steps / (gemm_ms * 1e-3) / 1e12
-    bytes_per_step = (n_local - stage0_rows) * dim_pad * 2.0 + launches_per_step * Q * dim_pad * 2.0
+    bytes_per_step = (n_scan - stage0_rows) * dim_pad * 2.0 + launches_per_step * Q * dim_pad * 2.0
     achieved_gbs = bytes_per_step * args.steps / (gemm_ms * 1e-3) / 1e9
     # which roof binds this shape: time at MFMA peak vs time at HBM peak (crossover at ~300 queries per batch)
     mfma_bound = flops_per_step / (PEAK_MFMA_TFLOPS * 1e12) >= bytes_per_step / (PEAK_HBM_GBS * 1e9)
@@ -237,7 +285,8 @@ def main():
         from oracle.cpu_baseline import dense_topk_blas
         qs = min(args.cpu_sample_queries, Q)
         hq = queries[:qs].cpu()
-        idx, vals, cdt, threads = dense_topk_blas(host_corpus, hq, k)
+        idx, vals, cdt, threads = dense_topk_blas(host_corpus[t_lo:t_hi], hq, k)       # WHERE agent_id = ... : the tenant's rows
+        idx = idx + t_lo
         same = np.mean([len(set(idx[i]) & set(got_ids[i])) / k for i in range(qs)])
         cpu_baseline = {"value": round(qs / cdt, 2), "unit": "queries/sec", "cores": threads, "kind": "port",
                         "sample": f"{qs} of the {Q} queries against the full {args.rows}x{DIM} corpus, "
@@ -251,7 +300,9 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f16 MFMA pass (fp32 acc) + f64 rescore", "data": "synthetic",
         "config": {"workload": f"{args.rows} x {DIM}-d synthetic unit embeddings, dense cosine top-k={k}, "
-                               f"batch={Q} queries (BASELINE.json configs[1])",
+                               f"batch={Q} queries (BASELINE.json configs[1])" +
+                               ("" if args.corpus == "iid" else f"; ROW ORDER VARIANT --corpus {args.corpus} (not the headline config)"),
+                   "corpus": args.corpus,
                    "corpus_rows": args.rows, "rows_per_gpu": n_local, "batch_queries": Q, "k": k,
                    "parallelism": f"row-sharded x{world}" + (" + RCCL all-gather merge" if world > 1 else "")},
         "p50_batch_latency_ms": round(p50, 4), "p50_single_query_latency_ms": None if lat1 is None else round(lat1, 4),

@@ -90,11 +90,11 @@ typedef struct rag_dense_stats {
     int32_t n_queries;
     int32_t proven_fast;      /* <= 256 survivors above tau: ranked in the fast path (exact by construction) */
     int32_t proven_wide;      /* more survivors (clusters, duplicates): ranked by the wide kernel            */
-    int32_t exact_scan;       /* candidate buffer overflowed: float64 scan of every row                      */
-    int32_t overflowed;       /* overflow events (any stage)                                                 */
+    int32_t exact_scan;       /* buffer overflowed in the second pass too: float64 scan of every row         */
+    int32_t overflowed;       /* overflow events (any stage of the first pass)                               */
     int32_t shortlist;        /* k (the threshold is the k-th best score so far minus 2*eps)                 */
     int32_t stages;           /* threshold stages used                  */
-    int32_t reserved;
+    int32_t second_pass;      /* overflowed queries whose re-emission at the final threshold fitted the buffer */
     double eps;               /* rigorous |fp16 score - exact| bound    */
 } rag_dense_stats;
 int rag_dense_last_stats(rag_handle_t h, rag_dense_stats* out);

@@ -24,10 +24,10 @@ def lib_path():
 class DenseStats(C.Structure):
     _fields_ = [("n_queries", C.c_int32), ("proven_fast", C.c_int32), ("proven_wide", C.c_int32),
                 ("exact_scan", C.c_int32), ("overflowed", C.c_int32), ("shortlist", C.c_int32),
-                ("stages", C.c_int32), ("reserved", C.c_int32), ("eps", C.c_double)]
+                ("stages", C.c_int32), ("second_pass", C.c_int32), ("eps", C.c_double)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class CeConfig(C.Structure):

@@ -93,6 +93,7 @@ int rag_destroy(rag_handle_t h) {
     pipeline_free(h);
     hipFree(h->q32); hipFree(h->q16); hipFree(h->cand); hipFree(h->cnt); hipFree(h->tau); hipFree(h->bound);
     hipFree(h->n_sorted); hipFree(h->exact); hipFree(h->flag); hipFree(h->stats); hipFree(h->stage);
+    hipFree(h->q16b); hipFree(h->candb); hipFree(h->cntb); hipFree(h->taub); hipFree(h->boundb); hipFree(h->n_sortedb); hipFree(h->ovf_list);
     for (auto& p : h->prof)
         for (auto& e : p.ev) {
             hipEventDestroy(e.first);
@@ -211,10 +212,10 @@ int rag_index_set_tenants_host(rag_handle_t h, const int32_t* t, int64_t n_rows)
     HIP_TRY(h, hipSetDevice(h->device));
     hipFree(h->tenants);
     h->tenants = nullptr;
-    if (t == nullptr || n_rows == 0) return RAG_OK;                    // NULL clears the filter table
+    if (t == nullptr || n_rows == 0) return dense_build_tenant_tiles(h, nullptr, 0);      // NULL clears the filter table
     HIP_TRY(h, hipMalloc(&h->tenants, (size_t)n_rows * sizeof(int32_t)));
     HIP_TRY(h, hipMemcpy(h->tenants, t, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice));
-    return RAG_OK;
+    return dense_build_tenant_tiles(h, t, n_rows);
 }
 
 int rag_index_set_ids_host(rag_handle_t h, const int64_t* ids, int64_t n_rows) {
@@ -304,7 +305,7 @@ int rag_dense_last_stats(rag_handle_t h, rag_dense_stats* out) {
     out->overflowed = s[4];
     out->shortlist = h->last_shortlist;
     out->stages = h->last_stages;
-    out->reserved = 0;
+    out->second_pass = s[5];
     out->eps = h->last_eps;
     return RAG_OK;
 }

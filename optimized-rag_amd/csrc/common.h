@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/rag_hip.h"
@@ -41,6 +42,9 @@ struct rag_ctx {
     half_t* emb16 = nullptr;     // [n_rows_pad][dim_pad] fp16 (2^7 * unit rows), zero padded
     int64_t* ids = nullptr;      // [n_rows] or null
     int32_t* tenants = nullptr;  // [n_rows] or null
+    int32_t* tenant_tiles = nullptr;                                   // concatenated per-tenant lists of 256-row tiles
+    std::unordered_map<int32_t, std::pair<int64_t, int>> tenant_span;  // tenant -> (offset, count) into tenant_tiles
+    int64_t tenant_rows = 0;                                           // row count the tenant table was built for
     int* bad_rows = nullptr;     // device counter: rows with zero / non-finite norm
 
     // dense search workspace (sized for ws_q queries)
@@ -55,6 +59,12 @@ struct rag_ctx {
     double* exact = nullptr;         // [ws_qpad][RAG_CAND_CAP] float64 rescored cosines
     int* flag = nullptr;             // [ws_qpad]   0 done, 1 needs wide ranking, 2 needs exact scan, 3 scanned
     int* stats = nullptr;            // [8] device counters
+    // second pass for overflowed queries: one 256-query tile of its own (dense.hip)
+    half_t* q16b = nullptr;
+    uint64_t* candb = nullptr;
+    unsigned* cntb = nullptr;
+    float *taub = nullptr, *boundb = nullptr;
+    int *n_sortedb = nullptr, *ovf_list = nullptr;
     // exact-scan fallback workspace
     double* scan_scores = nullptr;   // [n_rows] (allocated on first use)
     int64_t scan_rows = 0;
@@ -178,6 +188,7 @@ int dense_index_normalize_range(rag_ctx* h, int64_t first_row, int64_t n_rows, h
 int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev,
                  double* scores_dev, hipStream_t st);
 int dense_free(rag_ctx* h);
+int dense_build_tenant_tiles(rag_ctx* h, const int32_t* tenants_host, int64_t n_rows);
 int merge_topk(rag_ctx* h, const int64_t* ids, const double* scores, int n_lists, int64_t list_stride, int Q, int k,
                int64_t* ids_out, double* scores_out, hipStream_t st);
 int pairwise_cosine(rag_ctx* h, const float* a_dev, int m, const float* b_dev, int n, int dim, double* out_dev,

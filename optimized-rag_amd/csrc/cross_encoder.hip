@@ -110,7 +110,10 @@ __device__ __forceinline__ void ce_dma(const half_t* __restrict__ g, char* lds, 
 // starts with both stages resident. The packed row count lives on the device (no host sync): the loop stops at the
 // first token tile past it.
 #define CE_EPI_WAVE_BYTES (CE_STAGE_BYTES / 8)            // 6 KiB of the free stage per wave
-template <int EPI>
+// TERMS: which correction products run beside hi*hi. bit 0 = W_lo * x_hi (undoes the fp16 rounding of the WEIGHTS), bit 1 =
+// W_hi * x_lo (undoes the rounding of the ACTIVATIONS). 3 = both (default everywhere); the other instances exist for the
+// per-site ablation of DESIGN.md section 4.5 (RAG_CE_TERMS) and for sites where a term is provably not needed.
+template <int EPI, int TERMS>
 __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__ W, size_t w_plane, const half_t* __restrict__ X,
                                                        size_t x_plane, int N, int K, const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ out32,
@@ -195,12 +198,12 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 ah[i] = *reinterpret_cast<const half8*>(st + a_base + i * 16 * 64 + off);
-                al[i] = *reinterpret_cast<const half8*>(st + CE_W_BYTES + a_base + i * 16 * 64 + off);
+                if (TERMS & 1) al[i] = *reinterpret_cast<const half8*>(st + CE_W_BYTES + a_base + i * 16 * 64 + off);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 bh[j] = *reinterpret_cast<const half8*>(st + 2 * CE_W_BYTES + b_base + j * 16 * 64 + off);
-                bl[j] = *reinterpret_cast<const half8*>(st + 2 * CE_W_BYTES + CE_X_BYTES + b_base + j * 16 * 64 + off);
+                if (TERMS & 2) bl[j] = *reinterpret_cast<const half8*>(st + 2 * CE_W_BYTES + CE_X_BYTES + b_base + j * 16 * 64 + off);
             }
             CE_ISSUE(t + 2)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -214,8 +217,8 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    if (TERMS & 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    if (TERMS & 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
             __builtin_amdgcn_s_setprio(0);
@@ -755,10 +758,21 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     bool& attr = h->attr_ce_gemm;
     const size_t lds = CE_GEMM_LDS;
     if (!attr) {
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_kernel<EPI_QKV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_kernel<EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_kernel<EPI_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#define CE_ATTR(E, T) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_kernel<E, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#define CE_ATTR4(E) CE_ATTR(E, 0) CE_ATTR(E, 1) CE_ATTR(E, 2) CE_ATTR(E, 3)
+        CE_ATTR4(EPI_QKV) CE_ATTR4(EPI_GELU) CE_ATTR4(EPI_RESID)
         attr = true;
+    }
+    // correction terms per GEMM site (qkv, out-proj, ffn-up, ffn-down), each 0..3; RAG_CE_TERMS="3333" is the default
+    int terms[4] = {3, 3, 3, 3};
+    if (const char* te = getenv("RAG_CE_TERMS"))
+        for (int i = 0; i < 4 && te[i] >= '0' && te[i] <= '3'; ++i) terms[i] = te[i] - '0';
+#define CE_GEMM(E, T, ...)                                                                                        \
+    switch (T) {                                                                                                  \
+        case 0: hipLaunchKernelGGL((ce_gemm_kernel<E, 0>), dim3(n_cu), blk, lds, st, __VA_ARGS__); break;        \
+        case 1: hipLaunchKernelGGL((ce_gemm_kernel<E, 1>), dim3(n_cu), blk, lds, st, __VA_ARGS__); break;        \
+        case 2: hipLaunchKernelGGL((ce_gemm_kernel<E, 2>), dim3(n_cu), blk, lds, st, __VA_ARGS__); break;        \
+        default: hipLaunchKernelGGL((ce_gemm_kernel<E, 3>), dim3(n_cu), blk, lds, st, __VA_ARGS__); break;       \
     }
 #define CE_PER_DISPATCH(CALL)                                                                 \
     switch (per) {                                                                            \
@@ -778,24 +792,24 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     const half_t* nullh = nullptr;
     for (int l = 0; l < m->cfg.layers; ++l) {
         auto& ly = m->layers[l];
-        hipLaunchKernelGGL(ce_gemm_kernel<EPI_QKV>, dim3(n_cu), blk, lds, st, ly.wqkv, (size_t)3 * H * H, m->x16, pp.x,
-                           3 * H, H, ly.bqkv, (const float*)nullptr, (float*)nullptr, m->q16, pp.q, m->kf16, m->vf16, pp.kv, H,
-                           m->cfg.heads, m->m_packed, m->row_pair, m->pair_off);
+        CE_GEMM(EPI_QKV, terms[0], ly.wqkv, (size_t)3 * H * H, m->x16, pp.x,
+                3 * H, H, ly.bqkv, (const float*)nullptr, (float*)nullptr, m->q16, pp.q, m->kf16, m->vf16, pp.kv, H,
+                m->cfg.heads, m->m_packed, m->row_pair, m->pair_off)
         {
             const int rc = L == 32 ? launch_attention<1>(h, m, P, L, pp, st) : launch_attention<2>(h, m, P, L, pp, st);
             if (rc != RAG_OK) return rc;
         }
-        hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(n_cu), blk, lds, st, ly.wo, (size_t)H * H, m->ctx16, pp.ctx, H, H,
-                           ly.bo, m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
-                           m->row_pair, m->pair_off);
+        CE_GEMM(EPI_RESID, terms[1], ly.wo, (size_t)H * H, m->ctx16, pp.ctx, H, H,
+                ly.bo, (const float*)m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
+                m->row_pair, m->pair_off)
 #define LN1(PER) launch_ln<PER>(m, m->y32, ly.ln1_g, ly.ln1_b, M, pp.x, st)
         CE_PER_DISPATCH(LN1)
-        hipLaunchKernelGGL(ce_gemm_kernel<EPI_GELU>, dim3(n_cu), blk, lds, st, ly.w1, (size_t)F * H, m->x16, pp.x, F, H,
-                           ly.b1, (const float*)nullptr, (float*)nullptr, m->h16, pp.h, (half_t*)nullptr, (half_t*)nullptr, (size_t)0,
-                           H, m->cfg.heads, m->m_packed, m->row_pair, m->pair_off);
-        hipLaunchKernelGGL(ce_gemm_kernel<EPI_RESID>, dim3(n_cu), blk, lds, st, ly.w2, (size_t)H * F, m->h16, pp.h, H, F,
-                           ly.b2, m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
-                           m->row_pair, m->pair_off);
+        CE_GEMM(EPI_GELU, terms[2], ly.w1, (size_t)F * H, m->x16, pp.x, F, H,
+                ly.b1, (const float*)nullptr, (float*)nullptr, m->h16, pp.h, (half_t*)nullptr, (half_t*)nullptr, (size_t)0,
+                H, m->cfg.heads, m->m_packed, m->row_pair, m->pair_off)
+        CE_GEMM(EPI_RESID, terms[3], ly.w2, (size_t)H * F, m->h16, pp.h, H, F,
+                ly.b2, (const float*)m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
+                m->row_pair, m->pair_off)
 #define LN2(PER) launch_ln<PER>(m, m->y32, ly.ln2_g, ly.ln2_b, M, pp.x, st)
         CE_PER_DISPATCH(LN2)
     }
@@ -805,7 +819,10 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     return RAG_OK;
 }
 
-static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L) {
+// (re)allocates the activation workspace; the zero fills are enqueued on `st`, the stream the forward runs on (a
+// synchronous hipMemset on the null stream is NOT ordered against a non-blocking stream: the first forward after a
+// reallocation could otherwise start before its buffers were cleared)
+static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t st) {
     if (P <= m->ws_pairs && L == m->ws_L) return RAG_OK;
     ce_free_ws(m);
     const int H = m->cfg.hidden;
@@ -830,13 +847,13 @@ static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L) {
     HIP_TRY(h, hipMalloc(&m->stt, (size_t)P * L * 4));
     HIP_TRY(h, hipMalloc(&m->logits, (size_t)P * 4));
     // padded token rows are read by the GEMM tiles: keep them finite
-    HIP_TRY(h, hipMemset(m->x16, 0, 2 * pp.x * 2));
-    HIP_TRY(h, hipMemset(m->ctx16, 0, 2 * pp.ctx * 2));
-    HIP_TRY(h, hipMemset(m->h16, 0, 2 * pp.h * 2));
-    HIP_TRY(h, hipMemset(m->q16, 0, 2 * pp.q * 2));
-    HIP_TRY(h, hipMemset(m->kf16, 0, 2 * pp.kv * 2));
-    HIP_TRY(h, hipMemset(m->vf16, 0, 2 * pp.kv * 2));
-    HIP_TRY(h, hipMemset(m->x32, 0, (size_t)Mp * H * 4));
+    HIP_TRY(h, hipMemsetAsync(m->x16, 0, 2 * pp.x * 2, st));
+    HIP_TRY(h, hipMemsetAsync(m->ctx16, 0, 2 * pp.ctx * 2, st));
+    HIP_TRY(h, hipMemsetAsync(m->h16, 0, 2 * pp.h * 2, st));
+    HIP_TRY(h, hipMemsetAsync(m->q16, 0, 2 * pp.q * 2, st));
+    HIP_TRY(h, hipMemsetAsync(m->kf16, 0, 2 * pp.kv * 2, st));
+    HIP_TRY(h, hipMemsetAsync(m->vf16, 0, 2 * pp.kv * 2, st));
+    HIP_TRY(h, hipMemsetAsync(m->x32, 0, (size_t)Mp * H * 4, st));
     m->ws_pairs = P;
     m->ws_L = L;
     m->ws_tokens = Mp;
@@ -866,7 +883,7 @@ int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* l
     const char* ct = getenv("RAG_CE_CHUNK_TOKENS");
     const int64_t chunk_tokens = ct && atoll(ct) >= 32 ? atoll(ct) : 2'000'000;
     const int chunk = std::max(1, std::min(P, (int)(chunk_tokens / L)));
-    int rc = ce_ensure_ws(h, m, chunk, L);
+    int rc = ce_ensure_ws(h, m, chunk, L, st);
     if (rc) return rc;
     const hipMemcpyKind kin = host_ptrs ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     const hipMemcpyKind kout = host_ptrs ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;

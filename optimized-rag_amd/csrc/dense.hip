@@ -19,6 +19,9 @@
 //   scan             the 4096-entry buffer overflowed: float64 exact scan of every row for that query.
 #include "common.h"
 
+#include <algorithm>
+#include <unordered_map>
+
 #define WAVE 64
 
 // ------------------------------------------------------------------------------------------------
@@ -181,7 +184,9 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
                                                           int Dp, int rtile_begin, int n_rtiles, int n_qtiles,
                                                           int n_rows_valid, int q_valid, const float* __restrict__ tau,
                                                           unsigned* __restrict__ cnt, uint64_t* __restrict__ cand,
-                                                          const int32_t* __restrict__ tenants, int tenant
+                                                          const int32_t* __restrict__ tenants, int tenant,
+                                                          const int32_t* __restrict__ tile_list, int tile_mul, int tile_mod,
+                                                          const int* __restrict__ active_count
 #ifdef DENSE_STAMP
                                                           , unsigned long long* __restrict__ stamp_out
 #endif
@@ -200,13 +205,24 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
     unsigned long long stamp_acc[4] = {0ull, 0ull, 0ull, 0ull}, stamp_prev = 0ull;
 #endif
 
+    // second-pass launches (re-emission for queries whose buffer overflowed) cover the whole corpus but usually have
+    // nothing to do: the device-side count of such queries decides, no host round trip
+    if (active_count != nullptr && *active_count == 0) return;
     // XCD-aware tile assignment (speed only; any placement is correct)
     const int b = blockIdx.x;
     const int xcd = b & 7, seq = b >> 3;
     const int rt = (seq / n_qtiles) * 8 + xcd;
     const int qt = seq % n_qtiles;
     if (rt >= n_rtiles) return;
-    const int row0 = (rtile_begin + rt) * RAG_TILE;
+    // ROW ORDER. The threshold stages must each see a REPRESENTATIVE sample of the rows, whatever order the table was
+    // exported in (file by file, tenant by tenant, topic-sorted): position p of the schedule maps to corpus tile
+    // (p * tile_mul) mod tile_mod - a multiplicative low-discrepancy permutation (tile_mul ~ 0.618 * tile_mod, coprime), so
+    // every prefix of positions is spread evenly over the table - and, under a tenant filter, through tile_list: the
+    // tiles that hold at least one row of that tenant (other tiles are never read).
+    const int pos = rtile_begin + rt;
+    int tile = (int)(((int64_t)pos * tile_mul) % tile_mod);
+    if (tile_list != nullptr) tile = tile_list[tile];
+    const int row0 = tile * RAG_TILE;
     const int q0 = qt * RAG_TILE;
 
     // per-thread DMA source inside a half-tile: linear chunk i = j*512 + tid -> row j*64 + (tid>>3), position tid&7
@@ -300,7 +316,7 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
                     const bool ok = row < n_rows_valid && (tenants == nullptr || tenants[row] == tenant);
                     kk[r] = ok ? make_key(acc[i][j][r] * scale, (uint32_t)row) : 0ull;
                 }
-                ulonglong2* dst = reinterpret_cast<ulonglong2*>(cand + (size_t)q * RAG_CAND_CAP + rbase);
+                ulonglong2* dst = reinterpret_cast<ulonglong2*>(cand + (size_t)q * RAG_CAND_CAP + (rbase - row0) + pos * RAG_TILE);
                 dst[0] = make_ulonglong2(kk[0], kk[1]);
                 dst[1] = make_ulonglong2(kk[2], kk[3]);
             }
@@ -386,17 +402,19 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
 __global__ __launch_bounds__(256) void select_kernel(uint64_t* __restrict__ cand, unsigned* __restrict__ cnt,
                                                       float* __restrict__ tau, float* __restrict__ bound,
                                                       int* __restrict__ n_sorted, int* __restrict__ stats, int n_queries,
-                                                      int dense0_rows, int k, float two_eps, int final_stage) {
+                                                      int dense0_rows, int k, float two_eps, int final_stage,
+                                                      const int* __restrict__ active_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wv;
     if (q >= n_queries) return;                              // whole wave exits; no block-level sync is used
+    if (active_count != nullptr && q >= *active_count) return;   // second pass: only the re-emitted queries
     uint64_t* spill = reinterpret_cast<uint64_t*>(smem) + (size_t)wv * (RAG_CAND_CAP - SEL_REG * 64);
     uint64_t* c = cand + (size_t)q * RAG_CAND_CAP;
     const unsigned emitted = cnt[q];
     const bool overflow = dense0_rows == 0 && emitted > RAG_CAND_CAP;
     const int n_in = dense0_rows > 0 ? dense0_rows : (int)min(emitted, (unsigned)RAG_CAND_CAP);
-    if (overflow && lane == 0) atomicAdd(&stats[4], 1);
+    if (overflow && lane == 0 && stats != nullptr) atomicAdd(&stats[4], 1);
     // keys: first SEL_REG*64 in registers (element e*64 + lane), the rest (rare) in this wave's LDS slice
     uint64_t kreg[SEL_REG];
 #pragma unroll
@@ -574,8 +592,13 @@ __global__ __launch_bounds__(512) void wide_kernel(const uint64_t* __restrict__ 
     }
 }
 
-// L3: exact float64 scan of every row for queries with flag == 2.
+// L3: exact float64 scan of every row for queries with flag == 2 (last resort: more than RAG_CAND_CAP rows within 2 eps
+// of the k-th best even after the second pass, e.g. thousands of duplicates).
+// Scratch is BOUNDED: flagged queries are handled in rounds of SCAN_ROUND ordinals, and the corpus is cut into at most
+// ~1024 row blocks whatever its size (each workgroup walks its block in windows, keeping a running top-k), so a search that
+// flags nothing never needs more than SCAN_ROUND x 1024 x k partial entries (r1: Q x chunks x k = 7.5 GB on a 12.5M-row shard).
 #define SCAN_CHUNK 2048
+#define SCAN_ROUND 256
 __device__ __forceinline__ bool pair_before(uint64_t ka, uint32_t ra, uint64_t kb, uint32_t rb) {
     return ka > kb || (ka == kb && ra < rb);      // score desc, row asc
 }
@@ -598,46 +621,55 @@ __device__ __forceinline__ void bitonic_sort_pairs(uint64_t* k1, uint32_t* k2, i
     }
 }
 
-// flagged queries are rare: a 1-block kernel compacts them into a list so the scan launches a corpus-sized grid
-// (one block per 2048-row chunk, looping over the list) instead of Q x chunks early-exit blocks.
-__global__ __launch_bounds__(256) void scan_list_kernel(const int* __restrict__ flag, int Q, int* __restrict__ list,
-                                                         int* __restrict__ count) {
+// queries with flag == want -> list (in query order is not required), count. One workgroup.
+__global__ __launch_bounds__(256) void flag_list_kernel(const int* __restrict__ flag, const float* __restrict__ bound, int Q,
+                                                         int want, int cap, int* __restrict__ list, int* __restrict__ count) {
     __shared__ int n;
     if (threadIdx.x == 0) n = 0;
     __syncthreads();
-    for (int q = threadIdx.x; q < Q; q += 256)
-        if (flag[q] == 2) list[atomicAdd(&n, 1)] = q;
+    for (int q = threadIdx.x; q < Q; q += 256) {
+        const bool hit = flag != nullptr ? flag[q] == want : bound[q] == INFINITY;
+        if (hit) {
+            const int o = atomicAdd(&n, 1);
+            if (o < cap) list[o] = q;
+        }
+    }
     __syncthreads();
-    if (threadIdx.x == 0) *count = n;
+    if (threadIdx.x == 0) *count = min(n, cap);
 }
 
 __global__ __launch_bounds__(256) void scan_chunk_kernel(const float* __restrict__ q32, const float* __restrict__ emb32,
                                                           const int32_t* __restrict__ tenants, int tenant, int64_t n_rows,
-                                                          int dim, int k, const int* __restrict__ list,
-                                                          const int* __restrict__ count, uint64_t* __restrict__ part_key,
+                                                          int64_t rows_per_block, int dim, int k, const int* __restrict__ list,
+                                                          const int* __restrict__ count, int f0, uint64_t* __restrict__ part_key,
                                                           uint32_t* __restrict__ part_row) {
     __shared__ uint64_t sk[SCAN_CHUNK];
     __shared__ uint32_t sr[SCAN_CHUNK];
-    const int chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n_flagged = *count;
-    const int64_t base = (int64_t)chunk * SCAN_CHUNK;
-    for (int f = 0; f < n_flagged; ++f) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int f_end = min(*count, f0 + SCAN_ROUND);
+    const int64_t base = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t base_end = min(n_rows, base + rows_per_block);
+    const int window = SCAN_CHUNK - k;
+    for (int f = f0; f < f_end; ++f) {
         const int q = list[f];
-        for (int i = wv; i < SCAN_CHUNK; i += 4) {
-            const int64_t row = base + i;
-            uint64_t key = 0ull;          // 0 = empty (below every real score: orderable(-inf) > 0)
-            if (row < n_rows && (tenants == nullptr || tenants[row] == tenant)) {
-                const double v = exact_cosine_wave(q32 + (size_t)q * dim, emb32 + (size_t)row * dim, dim, lane);
-                key = f64_orderable(v);
+        for (int i = tid; i < k; i += 256) { sk[i] = 0ull; sr[i] = 0xFFFFFFFFu; }      // running top-k of this row block
+        for (int64_t w0 = base; w0 < base_end; w0 += window) {
+            for (int i = wv; i < window; i += 4) {
+                const int64_t row = w0 + i;
+                uint64_t key = 0ull;          // 0 = empty (below every real score: orderable(-inf) > 0)
+                if (row < base_end && (tenants == nullptr || tenants[row] == tenant)) {
+                    const double v = exact_cosine_wave(q32 + (size_t)q * dim, emb32 + (size_t)row * dim, dim, lane);
+                    key = f64_orderable(v);
+                }
+                if (lane == 0) {
+                    sk[k + i] = key;
+                    sr[k + i] = (uint32_t)row;
+                }
             }
-            if (lane == 0) {
-                sk[i] = key;
-                sr[i] = (uint32_t)row;
-            }
+            __syncthreads();
+            bitonic_sort_pairs(sk, sr, SCAN_CHUNK, tid, 256);
         }
-        __syncthreads();
-        bitonic_sort_pairs(sk, sr, SCAN_CHUNK, tid, 256);
-        const size_t o = ((size_t)q * gridDim.x + chunk) * k;
+        const size_t o = ((size_t)(f - f0) * gridDim.x + blockIdx.x) * k;
         for (int i = tid; i < k; i += 256) {
             part_key[o + i] = sk[i];
             part_row[o + i] = sr[i];
@@ -647,17 +679,19 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void scan_merge_kernel(const uint64_t* __restrict__ part_key, const uint32_t* __restrict__ part_row,
-                                                          int n_chunks, int k, const int64_t* __restrict__ ids, int64_t id_base,
+                                                          int n_blocks, int k, const int64_t* __restrict__ ids, int64_t id_base,
+                                                          const int* __restrict__ list, const int* __restrict__ count, int f0,
                                                           int* __restrict__ flag, int64_t* __restrict__ ids_out,
                                                           int32_t* __restrict__ rows_out, double* __restrict__ scores_out,
                                                           int* __restrict__ stats) {
     __shared__ uint64_t sk[SCAN_CHUNK];
     __shared__ uint32_t sr[SCAN_CHUNK];
-    const int q = blockIdx.x, tid = threadIdx.x;
-    if (flag[q] != 2) return;
-    const size_t total = (size_t)n_chunks * k;
-    const uint64_t* pk = part_key + (size_t)q * total;
-    const uint32_t* pr = part_row + (size_t)q * total;
+    const int f = f0 + blockIdx.x, tid = threadIdx.x;
+    if (f >= *count) return;
+    const int q = list[f];
+    const size_t total = (size_t)n_blocks * k;
+    const uint64_t* pk = part_key + (size_t)blockIdx.x * total;
+    const uint32_t* pr = part_row + (size_t)blockIdx.x * total;
     for (int i = tid; i < SCAN_CHUNK; i += 256) { sk[i] = 0ull; sr[i] = 0xFFFFFFFFu; }
     __syncthreads();
     size_t pos = 0;
@@ -687,6 +721,46 @@ __global__ __launch_bounds__(256) void scan_merge_kernel(const uint64_t* __restr
     }
 }
 
+// ---- second pass for queries whose candidate buffer overflowed -------------------------------------------------------
+// An overflow loses candidates, but the select that follows still tightens tau from the keys that were kept (the k-th best
+// of ANY subset of the rows seen is a valid lower bound of the final k-th best). With the final tau the number of rows
+// above it is almost always small again, so those queries (up to 256 per search) are re-emitted over the whole corpus with
+// that tau into a fresh buffer by the same MFMA kernel; only if THAT overflows too does the query go to the float64 scan.
+// gather: workgroup f copies the fp16 query row and tau of the f-th overflowed query; unused slots get tau = +inf.
+__global__ __launch_bounds__(256) void overflow_gather_kernel(const int* __restrict__ list, const int* __restrict__ count,
+                                                               const half_t* __restrict__ q16, const float* __restrict__ tau, int Dp,
+                                                               half_t* __restrict__ q16b, float* __restrict__ taub,
+                                                               float* __restrict__ boundb, unsigned* __restrict__ cntb) {
+    const int f = blockIdx.x;
+    const bool live = f < *count;
+    if (threadIdx.x == 0) {
+        taub[f] = live ? tau[list[f]] : INFINITY;
+        boundb[f] = -INFINITY;
+        cntb[f] = 0u;
+    }
+    if (!live) return;
+    const half8* src = reinterpret_cast<const half8*>(q16 + (size_t)list[f] * Dp);
+    half8* dst = reinterpret_cast<half8*>(q16b + (size_t)f * Dp);
+    for (int i = threadIdx.x; i < Dp / 8; i += 256) dst[i] = src[i];
+}
+
+// scatter: a second pass that did not overflow replaces the query's candidate list and clears its overflow mark
+__global__ __launch_bounds__(256) void overflow_scatter_kernel(const int* __restrict__ list, const int* __restrict__ count,
+                                                                const uint64_t* __restrict__ candb, const int* __restrict__ n_sortedb,
+                                                                const float* __restrict__ boundb, uint64_t* __restrict__ cand,
+                                                                int* __restrict__ n_sorted, float* __restrict__ bound,
+                                                                int* __restrict__ stats) {
+    const int f = blockIdx.x;
+    if (f >= *count || boundb[f] == INFINITY) return;
+    const int q = list[f], m = n_sortedb[f];
+    for (int i = threadIdx.x; i < m; i += 256) cand[(size_t)q * RAG_CAND_CAP + i] = candb[(size_t)f * RAG_CAND_CAP + i];
+    if (threadIdx.x == 0) {
+        n_sorted[q] = m;
+        bound[q] = -INFINITY;
+        atomicAdd(&stats[5], 1);
+    }
+}
+
 // per-search state in one launch: thresholds / proof bounds to -inf, candidate counters and statistics to 0
 __global__ void search_init_kernel(float* __restrict__ tau, float* __restrict__ bound, unsigned* __restrict__ cnt,
                                    int* __restrict__ stats, int n) {
@@ -702,7 +776,7 @@ __global__ void search_init_kernel(float* __restrict__ tau, float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static int ensure_workspace(rag_ctx* h, int Q) {
+static int ensure_workspace(rag_ctx* h, int Q, hipStream_t st) {
     if (Q <= h->ws_q) return RAG_OK;
     hipFree(h->q32); hipFree(h->q16); hipFree(h->cand); hipFree(h->cnt); hipFree(h->tau); hipFree(h->bound);
     hipFree(h->n_sorted); hipFree(h->exact); hipFree(h->flag);
@@ -718,8 +792,56 @@ static int ensure_workspace(rag_ctx* h, int Q) {
     HIP_TRY(h, hipMalloc(&h->exact, (size_t)qpad * RAG_CAND_CAP * sizeof(double)));
     HIP_TRY(h, hipMalloc(&h->flag, (size_t)qpad * sizeof(int)));
     if (!h->stats) HIP_TRY(h, hipMalloc(&h->stats, 8 * sizeof(int)));
-    HIP_TRY(h, hipMemset(h->q16, 0, (size_t)qpad * h->dim_pad * sizeof(half_t)));
+    // zero fills go on the search's own stream: a null-stream hipMemset is not ordered against a non-blocking stream
+    HIP_TRY(h, hipMemsetAsync(h->q16, 0, (size_t)qpad * h->dim_pad * sizeof(half_t), st));
+    if (!h->q16b) {      // second pass (overflowed queries): one 256-query tile, allocated once per handle
+        HIP_TRY(h, hipMalloc(&h->q16b, (size_t)RAG_TILE * h->dim_pad * sizeof(half_t)));
+        HIP_TRY(h, hipMalloc(&h->candb, (size_t)RAG_TILE * RAG_CAND_CAP * sizeof(uint64_t)));
+        HIP_TRY(h, hipMalloc(&h->cntb, RAG_TILE * sizeof(unsigned)));
+        HIP_TRY(h, hipMalloc(&h->taub, RAG_TILE * sizeof(float)));
+        HIP_TRY(h, hipMalloc(&h->boundb, RAG_TILE * sizeof(float)));
+        HIP_TRY(h, hipMalloc(&h->n_sortedb, RAG_TILE * sizeof(int)));
+        HIP_TRY(h, hipMalloc(&h->ovf_list, (RAG_TILE + 1) * sizeof(int)));
+        HIP_TRY(h, hipMemsetAsync(h->q16b, 0, (size_t)RAG_TILE * h->dim_pad * sizeof(half_t), st));
+    }
     h->ws_q = Q;
+    return RAG_OK;
+}
+
+// multiplier of the tile-order permutation p -> (p * a) mod T: close to the golden-ratio conjugate of T (every prefix of
+// positions is then spread evenly over the table) and coprime to T (a bijection)
+static int tile_multiplier(int T) {
+    if (T <= 2) return 1;
+    auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+    int a = (int)(0.6180339887498949 * T);
+    if (a < 1) a = 1;
+    while (a > 1 && gcd(a, T) != 1) --a;
+    return a;
+}
+
+// Tenant tile lists (built once per rag_index_set_tenants_host): for every tenant the ascending list of 256-row tiles that
+// hold at least one of its rows. A tenant-filtered search walks ONLY those tiles - a tenant stored contiguously (the usual
+// export order) costs its own rows, not a pass over the table - and draws its threshold stages from them.
+int dense_build_tenant_tiles(rag_ctx* h, const int32_t* tenants_host, int64_t n_rows) {
+    hipFree(h->tenant_tiles);
+    h->tenant_tiles = nullptr;
+    h->tenant_span.clear();
+    h->tenant_rows = 0;
+    if (!tenants_host || n_rows == 0) return RAG_OK;
+    std::unordered_map<int32_t, std::vector<int32_t>> lists;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        auto& v = lists[tenants_host[r]];
+        const int32_t t = (int32_t)(r / RAG_TILE);
+        if (v.empty() || v.back() != t) v.push_back(t);
+    }
+    std::vector<int32_t> flat;
+    for (auto& kv : lists) {
+        h->tenant_span[kv.first] = {(int64_t)flat.size(), (int)kv.second.size()};
+        flat.insert(flat.end(), kv.second.begin(), kv.second.end());
+    }
+    HIP_TRY(h, hipMalloc(&h->tenant_tiles, std::max<size_t>(1, flat.size()) * sizeof(int32_t)));
+    HIP_TRY(h, hipMemcpy(h->tenant_tiles, flat.data(), flat.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->tenant_rows = n_rows;
     return RAG_OK;
 }
 
@@ -727,6 +849,7 @@ int dense_free(rag_ctx* h) {
     hipFree(h->emb32); hipFree(h->emb16); hipFree(h->ids); hipFree(h->tenants); hipFree(h->bad_rows);
     h->emb32 = nullptr; h->emb16 = nullptr; h->ids = nullptr; h->tenants = nullptr; h->bad_rows = nullptr;
     hipFree(h->scan_scores); h->scan_scores = nullptr; h->scan_rows = 0;
+    hipFree(h->tenant_tiles); h->tenant_tiles = nullptr; h->tenant_span.clear(); h->tenant_rows = 0;
     h->n_rows = h->n_rows_pad = 0;
     h->n_reserved = 0;
     return RAG_OK;
@@ -775,7 +898,7 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
     ARG_CHECK(h, h->emb16 != nullptr, "no index loaded");
     ARG_CHECK(h, Q > 0 && k > 0 && k <= RAG_MAX_K, "need Q>0 and 0<k<=256");
     ARG_CHECK(h, tenant < 0 || h->tenants != nullptr, "tenant filter requested but no tenants loaded");
-    int rc = ensure_workspace(h, Q);
+    int rc = ensure_workspace(h, Q, st);
     if (rc) return rc;
     const int32_t* tenants = tenant >= 0 ? h->tenants : nullptr;
     const double eps = fp16_pass_eps(h->dim_pad);
@@ -808,13 +931,28 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
         attr_set = true;
     }
 
-    // ---- stage schedule over row tiles: [0, 2048), then ~8x growth each -------------------------
-    const int total_tiles = (int)(round_up(h->n_rows, RAG_TILE) / RAG_TILE);
+    // ---- tile universe: all tiles in permuted order, or the tenant's tile list in permuted order --------------------
+    const int total_tiles_all = (int)(round_up(h->n_rows, RAG_TILE) / RAG_TILE);
+    const int32_t* tile_list = nullptr;
+    int total_tiles = total_tiles_all;
+    if (tenant >= 0) {
+        ARG_CHECK(h, h->tenant_rows == h->n_rows, "tenant table is stale (rows were appended after rag_index_set_tenants_host)");
+        const auto it = h->tenant_span.find(tenant);
+        total_tiles = it == h->tenant_span.end() ? 0 : it->second.second;
+        tile_list = it == h->tenant_span.end() ? nullptr : h->tenant_tiles + it->second.first;
+    }
+    const int tile_mul = tile_multiplier(total_tiles), tile_mod = std::max(1, total_tiles);
+    const bool smallq = Q <= 128 && !getenv("RAG_NO_SMALLQ");
+
+    // ---- stage schedule over tile POSITIONS: 8 tiles (2048 rows) scored densely, then ~8x growth each. The expected
+    // emission of a stage is ~k x growth keys per query (tau = k-th best of everything seen so far), so the growth is
+    // capped by k: it must stay well inside the 4096-entry buffer (r1 used 32x for small batches at any k; at k = 100
+    // that sat at the edge of the buffer and a single query could fall into the exact scan).
     const int stage0_tiles = std::min(total_tiles, RAG_STAGE0_ROWS / RAG_TILE);
-    // stage growth: 8x for batches (keeps emission and the selects small), 32x for latency-bound small batches, where one
-    // launch + select fewer is worth more than the extra keys (Q = 1 on 1M rows: 0.71 -> 0.67 ms)
-    static const int growth_env = [] { const char* g = getenv("RAG_STAGE_GROWTH"); const int v = g ? atoi(g) : 0; return v >= 2 ? v : 0; }();
-    const int growth = growth_env ? growth_env : (Q <= 64 ? 4 * RAG_STAGE_GROWTH : RAG_STAGE_GROWTH);
+    const char* growth_s = getenv("RAG_STAGE_GROWTH");                 // diagnostic: read per call so tests can set it
+    const int growth_env = growth_s && atoi(growth_s) >= 2 ? atoi(growth_s) : 0;
+    const int growth = growth_env ? growth_env
+                                  : std::max(3, std::min(Q <= 64 ? 4 * RAG_STAGE_GROWTH : RAG_STAGE_GROWTH, (Q <= 64 ? 1024 : 1536) / k));
     int begin = 0, stage = 0;
     while (begin < total_tiles) {
         int end;
@@ -830,13 +968,16 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
         }
         if (stage == 0)
             hipLaunchKernelGGL((dense_emit_kernel<true, false>), dim3(grid), dim3(512), DENSE_LDS_BYTES, st, h->emb16, h->q16,
-                               h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant STAMP_ARG);
-        else if (Q <= 128 && !getenv("RAG_NO_SMALLQ"))
+                               h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant,
+                               tile_list, tile_mul, tile_mod, (const int*)nullptr STAMP_ARG);
+        else if (smallq)
             hipLaunchKernelGGL((dense_emit_kernel<false, true>), dim3(grid), dim3(512), DENSE_LDS_BYTES_SMALLQ, st, h->emb16, h->q16,
-                               h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant STAMP_ARG);
+                               h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant,
+                               tile_list, tile_mul, tile_mod, (const int*)nullptr STAMP_ARG);
         else
             hipLaunchKernelGGL((dense_emit_kernel<false, false>), dim3(grid), dim3(512), DENSE_LDS_BYTES, st, h->emb16, h->q16,
-                               h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant STAMP_ARG);
+                               h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant,
+                               tile_list, tile_mul, tile_mod, (const int*)nullptr STAMP_ARG);
         HIP_TRY(h, hipGetLastError());
         if (stage > 0) {
             const int prc = prof_end(h, 0, st);
@@ -844,14 +985,31 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
         }
         const bool last = end == total_tiles;
         hipLaunchKernelGGL(select_kernel, dim3((Q + 3) / 4), dim3(256), SELECT_LDS_BYTES, st, h->cand, h->cnt, tau, h->bound,
-                           h->n_sorted, h->stats, Q, stage == 0 ? stage0_tiles * RAG_TILE : 0, k, two_eps, last ? 1 : 0);
+                           h->n_sorted, h->stats, Q, stage == 0 ? stage0_tiles * RAG_TILE : 0, k, two_eps, last ? 1 : 0,
+                           (const int*)nullptr);
         HIP_TRY(h, hipGetLastError());
         begin = end;
         ++stage;
     }
-    if (total_tiles == 0) {   // empty index: nothing found
+    if (total_tiles == 0) {   // empty index / unknown tenant: nothing found
         hipLaunchKernelGGL(select_kernel, dim3((Q + 3) / 4), dim3(256), SELECT_LDS_BYTES, st, h->cand, h->cnt, tau, h->bound,
-                           h->n_sorted, h->stats, Q, 0, k, two_eps, 1);
+                           h->n_sorted, h->stats, Q, 0, k, two_eps, 1, (const int*)nullptr);
+    }
+
+    // ---- second pass for overflowed queries (device-side early exit when there are none) ---------------------------
+    if (total_tiles > 0 && !getenv("RAG_NO_SECOND_PASS")) {
+        int* ovf_count = h->ovf_list + RAG_TILE;
+        hipLaunchKernelGGL(flag_list_kernel, dim3(1), dim3(256), 0, st, (const int*)nullptr, h->bound, Q, 0, RAG_TILE, h->ovf_list, ovf_count);
+        hipLaunchKernelGGL(overflow_gather_kernel, dim3(RAG_TILE), dim3(256), 0, st, h->ovf_list, ovf_count, h->q16, tau, h->dim_pad,
+                           h->q16b, h->taub, h->boundb, h->cntb);
+        hipLaunchKernelGGL((dense_emit_kernel<false, false>), dim3((int)round_up(total_tiles, 8)), dim3(512), DENSE_LDS_BYTES, st,
+                           h->emb16, h->q16b, h->dim_pad, 0, total_tiles, 1, (int)h->n_rows, RAG_TILE, h->taub, h->cntb, h->candb,
+                           tenants, tenant, tile_list, tile_mul, tile_mod, (const int*)ovf_count STAMP_ARG);
+        hipLaunchKernelGGL(select_kernel, dim3(RAG_TILE / 4), dim3(256), SELECT_LDS_BYTES, st, h->candb, h->cntb, h->taub, h->boundb,
+                           h->n_sortedb, (int*)nullptr, RAG_TILE, 0, k, two_eps, 1, (const int*)ovf_count);
+        hipLaunchKernelGGL(overflow_scatter_kernel, dim3(RAG_TILE), dim3(256), 0, st, h->ovf_list, ovf_count, h->candb, h->n_sortedb,
+                           h->boundb, h->cand, h->n_sorted, h->bound, h->stats);
+        HIP_TRY(h, hipGetLastError());
     }
 
     hipLaunchKernelGGL(rescore_kernel, dim3(16, Q), dim3(256), 0, st, q_dev, h->emb32, h->cand, h->n_sorted, h->exact, h->dim);
@@ -860,25 +1018,30 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
     hipLaunchKernelGGL(wide_kernel, dim3(Q), dim3(512), RAG_CAND_CAP * 12, st, h->cand, h->n_sorted, h->exact, h->ids, h->id_base, k,
                        ids_dev, rows_dev, scores_dev, h->flag, h->stats);
     HIP_TRY(h, hipGetLastError());
-    // exact scan for whatever is still unproven (device-side early exit when nothing is flagged)
+    // exact scan for whatever is still unproven: rounds of SCAN_ROUND flagged queries, device-side early exit when none
     if (h->n_rows > 0) {
-        const int n_chunks = (int)((h->n_rows + SCAN_CHUNK - 1) / SCAN_CHUNK);
-        const size_t need = (size_t)Q * n_chunks * k;
+        const int window = SCAN_CHUNK - k;
+        const int64_t rows_per_block = std::max<int64_t>(1, (h->n_rows + 1023) / 1024 + window - 1) / window * window;
+        const int n_blocks = (int)((h->n_rows + rows_per_block - 1) / rows_per_block);
+        const size_t need = (size_t)std::min(Q, SCAN_ROUND) * n_blocks * k;
         if ((int64_t)need > h->scan_rows) {
             hipFree(h->scan_scores);
             h->scan_scores = nullptr;
+            h->scan_rows = 0;
             HIP_TRY(h, hipMalloc(&h->scan_scores, need * 12));
             h->scan_rows = (int64_t)need;
         }
         uint64_t* pk = reinterpret_cast<uint64_t*>(h->scan_scores);
-        uint32_t* pr = reinterpret_cast<uint32_t*>(pk + need);
+        uint32_t* pr = reinterpret_cast<uint32_t*>(pk + h->scan_rows);
         int* scan_list = h->n_sorted;                 // free after the wide kernel; [Q] ints
         int* scan_count = h->stats + 7;
-        hipLaunchKernelGGL(scan_list_kernel, dim3(1), dim3(256), 0, st, h->flag, Q, scan_list, scan_count);
-        hipLaunchKernelGGL(scan_chunk_kernel, dim3(n_chunks), dim3(256), 0, st, q_dev, h->emb32, tenants, tenant,
-                           h->n_rows, h->dim, k, scan_list, scan_count, pk, pr);
-        hipLaunchKernelGGL(scan_merge_kernel, dim3(Q), dim3(256), 0, st, pk, pr, n_chunks, k, h->ids, h->id_base, h->flag,
-                           ids_dev, rows_dev, scores_dev, h->stats);
+        hipLaunchKernelGGL(flag_list_kernel, dim3(1), dim3(256), 0, st, (const int*)h->flag, (const float*)nullptr, Q, 2, Q, scan_list, scan_count);
+        for (int f0 = 0; f0 < Q; f0 += SCAN_ROUND) {
+            hipLaunchKernelGGL(scan_chunk_kernel, dim3(n_blocks), dim3(256), 0, st, q_dev, h->emb32, tenants, tenant, h->n_rows,
+                               rows_per_block, h->dim, k, scan_list, scan_count, f0, pk, pr);
+            hipLaunchKernelGGL(scan_merge_kernel, dim3(std::min(Q - f0, SCAN_ROUND)), dim3(256), 0, st, pk, pr, n_blocks, k, h->ids,
+                               h->id_base, scan_list, scan_count, f0, h->flag, ids_dev, rows_dev, scores_dev, h->stats);
+        }
         HIP_TRY(h, hipGetLastError());
     }
     h->last_q = Q;

@@ -97,6 +97,40 @@ class GpuDocumentIndex:
             logger.error("Search failed: %s", e)
             return []
 
+    def search_many(self, agent_id: str, queries: List[str], top_k: int = 5, with_embeddings: bool = True) -> List[List[Dict[str, Any]]]:
+        """Batched `search` (the reference agent can only submit one query per call, so nothing in
+        its surface reaches the batched throughput): ONE embedding call for all queries when the service offers
+        `generate_embeddings_batch`, ONE rag_dense_topk_host call with Q = len(queries), one row fetch. Element i equals
+        `search(agent_id, queries[i], top_k, with_embeddings)`; on failure every element is [] (the reference's log-and-
+        return-empty, :483-485)."""
+        try:
+            if not queries:
+                return []
+            if hasattr(self.embeddings, "generate_embeddings_batch"):
+                embs = self.embeddings.generate_embeddings_batch(list(queries))
+            else:
+                embs = [self.embeddings.generate_embedding(q) for q in queries]
+            rows, scores = self._search_rows(agent_id, embs, top_k)
+            hits = [[int(r) for r in rows[i] if r >= 0] for i in range(len(queries))]
+            flat = [r for h in hits for r in h]
+            fetched = self.engine.fetch_rows(flat) if (with_embeddings and flat) else None
+            out, pos = [], 0
+            for i, h in enumerate(hits):
+                res = []
+                for j, r in enumerate(h):
+                    row = self.rows[r]
+                    d = {"content": row.get("content", ""), "filename": row.get("filename"), "file_type": row.get("file_type"),
+                         "score": float(scores[i][j]), "metadata": row.get("metadata") or {}}
+                    if fetched is not None:
+                        d["embedding"] = [float(x) for x in fetched[pos + j]]
+                    res.append(d)
+                pos += len(h)
+                out.append(res)
+            return out
+        except Exception as e:
+            logger.error("Batched search failed: %s", e)
+            return [[] for _ in queries]
+
     def search_batch(self, agent_id: Optional[str], query_embeddings, top_k: int = 20):
         """Batched entry the reference lacks: Q query embeddings at once -> (row indices [Q,k], cosines [Q,k])."""
         return self._search_rows(agent_id, query_embeddings, top_k)

@@ -74,6 +74,34 @@ class HybridRetriever:
         logger.info("Retrieved %d total results from %d sources", len(all_results), len(sources))
         return all_results
 
+    def retrieve_batch(self, queries: List[str], sources: List[str], top_k: int = 20) -> List[List[Dict[str, Any]]]:
+        """Batched `retrieve`: element i equals `retrieve(queries[i], sources, top_k)`. The
+        `documents` source - the pgvector scan behind hierarchical_retriever.py:454-458 - is answered for ALL queries by one
+        GPU call when the document store offers `search_many` (GpuDocumentIndex does); the other sources keep the
+        reference's per-query calls (they are remote / SQL round trips, not arithmetic)."""
+        docs = None
+        if 'documents' in sources and hasattr(self.document_store, 'search_many'):
+            try:
+                docs = self.document_store.search_many(self.agent_id, list(queries), top_k=top_k)
+                for res in docs:
+                    for r in res:
+                        r['source'] = 'documents'
+            except Exception as e:
+                logger.error("Document retrieval failed: %s", e)
+                docs = [[] for _ in queries]
+        out = []
+        for i, query in enumerate(queries):
+            res = []
+            if 'archival' in sources or 'archival_memory' in sources:
+                res.extend(self._retrieve_archival(query, top_k))
+            if 'documents' in sources:
+                res.extend(docs[i] if docs is not None else self._retrieve_documents(query, top_k))
+            if 'conversation' in sources or 'conversation_history' in sources:
+                res.extend(self._retrieve_conversation(query, top_k))
+            out.append(res)
+        logger.info("Retrieved results for %d queries from %d sources", len(queries), len(sources))
+        return out
+
     def _retrieve_archival(self, query: str, top_k: int) -> List[Dict[str, Any]]:
         try:
             results = self.memory_manager.archival_memory_search(query, top_k=top_k)

@@ -256,3 +256,98 @@ def test_shard_directory_streams_into_the_index(eng_factory, tmp_path):
     SF.load_shard_into(eng2, sh, begin=b, end=e, chunk_rows=512)
     check(eng2, emb[b:e], queries, 20, ids=pk[b:e])
     sh.close()
+
+
+# ---------------------------------------------------------------------------------------- row-order independence (r2)
+def _clustered(rng, n_clusters, per, D):
+    centers = rng.standard_normal((n_clusters, D))
+    centers /= np.linalg.norm(centers, axis=1, keepdims=True)
+    rows = np.repeat(centers, per, axis=0) + rng.standard_normal((n_clusters * per, D)) / np.sqrt(D)
+    return rows.astype(np.float32)
+
+
+@pytest.mark.parametrize("k", [20, 100])
+def test_cluster_by_cluster_storage_needs_no_fallback(eng_factory, k):
+    """A table stored cluster by cluster (inserted file by file): every query's neighbourhood is ONE contiguous stretch
+    of ~1,000 rows near the END of the table. The threshold stages walk the tiles in a spread-out order, so the result is
+    the oracle's and no query overflows, let alone reaches the float64 scan (r1: contiguous stages)."""
+    rng = np.random.default_rng(1000 + k)
+    corpus = _clustered(rng, 60, 1000, 256)
+    eng = eng_factory(256)
+    eng.index_load(corpus)
+    r = rng.integers(50_000, 60_000, 40)
+    queries = (corpus[r] + 0.5 * rng.standard_normal((40, 256)) / np.sqrt(256)).astype(np.float32)
+    st = check(eng, corpus, queries, k)
+    # scores of foreign rows are correlated inside a cluster, so an unlucky 8-tile sample can leave the first threshold
+    # loose for one query: such an overflow is repaired by the second MFMA pass, never by the float64 scan
+    assert st["exact_scan"] == 0 and st["overflowed"] <= 2 and st["second_pass"] == st["overflowed"], st
+
+
+def test_sorted_table_needs_no_fallback(eng_factory):
+    """Topic-sorted table: a drift along one axis grows with the row number, so the rows most similar to the queries are
+    all at the end of the table."""
+    rng = np.random.default_rng(77)
+    N, D = 70_000, 256
+    u = rng.standard_normal(D)
+    u /= np.linalg.norm(u)
+    corpus = (rng.standard_normal((N, D)) / np.sqrt(D) + (3.0 * np.arange(N) / N - 1.5)[:, None] * u[None, :]).astype(np.float32)
+    eng = eng_factory(D)
+    eng.index_load(corpus)
+    queries = (corpus[rng.integers(N - 5000, N, 50)] + 0.3 * rng.standard_normal((50, D)) / np.sqrt(D)).astype(np.float32)
+    st = check(eng, corpus, queries, 100)
+    assert st["exact_scan"] == 0 and st["second_pass"] == st["overflowed"] <= 2, st
+
+
+def test_contiguous_tenants_walk_only_their_tiles(eng_factory):
+    """`WHERE agent_id = %s` (rag/document_store.py:457) on a table exported tenant by tenant: the tenant's rows are one
+    contiguous range; the search walks only the tiles that hold them. Also: a tenant smaller than k, a tenant id that owns
+    no row, tenants whose ranges do not start on a tile boundary."""
+    rng = np.random.default_rng(78)
+    N, D, k = 50_000, 256, 20
+    corpus = rng.standard_normal((N, D)).astype(np.float32)
+    bounds = [0, 7, 1000, 1300, 20_011, 20_500, 41_000, 49_990, N]                 # tenant t owns rows [bounds[t], bounds[t+1])
+    tenants = np.zeros(N, dtype=np.int32)
+    for t in range(len(bounds) - 1):
+        tenants[bounds[t]:bounds[t + 1]] = t
+    eng = eng_factory(D)
+    eng.index_load(corpus)
+    eng.set_tenants(tenants)
+    for t in (0, 3, 5, 7, 6):
+        rows = np.arange(bounds[t], bounds[t + 1])
+        queries = (corpus[rng.choice(rows, 9)] + 0.5 * rng.standard_normal((9, D))).astype(np.float32)
+        st = check(eng, corpus, queries, k, tenants, t)
+        assert st["exact_scan"] == 0 and st["second_pass"] == st["overflowed"] <= 1, (t, st)
+    ids, rows, sc = eng.dense_topk(corpus[:3], k, tenant=99)                       # unknown tenant: empty result
+    assert (ids == -1).all() and (rows == -1).all() and (sc == 0).all()
+    eng.set_tenants(None)
+
+
+def test_second_pass_replaces_the_exact_scan(eng_factory, monkeypatch):
+    """Forced overflow: one threshold stage over 300k rows with a threshold drawn from 2048 (RAG_STAGE_GROWTH) emits ~15k
+    keys per query into the 4096-entry buffer. The select that follows still tightens tau from what was kept, and the second
+    MFMA pass at that tau recovers every query - no float64 scan - with the oracle's result. With the second pass switched
+    off the same queries take the scan path (in rounds of 256 flagged queries) and give the same answer."""
+    rng = np.random.default_rng(79)
+    N, D, Q, k = 300_000, 64, 200, 100          # the second pass takes up to 256 overflowed queries per search
+    corpus = rng.standard_normal((N, D)).astype(np.float32)
+    queries = planted_queries(rng, corpus, Q)
+    eng = eng_factory(D)
+    eng.index_load(corpus)
+    monkeypatch.setenv("RAG_STAGE_GROWTH", "100000")
+    st = check(eng, corpus, queries, k)
+    assert st["overflowed"] >= Q and st["second_pass"] == Q and st["exact_scan"] == 0, st
+    monkeypatch.setenv("RAG_NO_SECOND_PASS", "1")
+    st = check(eng, corpus, queries[:40], k)
+    assert st["exact_scan"] == 40 and st["second_pass"] == 0, st
+
+
+def test_exact_scan_rounds_beyond_256_flagged_queries(eng_factory, monkeypatch):
+    """The float64 scan handles flagged queries in rounds of 256 with bounded scratch: 300 queries forced through it."""
+    rng = np.random.default_rng(80)
+    corpus = rng.standard_normal((9000, 128)).astype(np.float32)
+    queries = planted_queries(rng, corpus, 300)
+    eng = eng_factory(128)
+    eng.index_load(corpus)
+    monkeypatch.setenv("RAG_FORCE_LEVEL", "2")
+    st = check(eng, corpus, queries, 20)
+    assert st["exact_scan"] == 300, st

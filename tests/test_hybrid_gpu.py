@@ -356,6 +356,46 @@ def test_gpu_document_index_search(eng):
     assert [d["metadata"]["i"] for d in res] == oid[0].tolist() and all(d["source"] == "documents" for d in res)
 
 
+def test_batched_agent_entries_equal_the_per_query_calls(eng):
+    """GpuDocumentIndex.search_many / HybridRetriever.retrieve_batch / retrieve_tier_2_batch answer
+    a list of queries with ONE dense search and must return, element by element, what the reference-shaped single-query
+    calls return (same rows, same float64 scores, same dict keys, `source` / `tier` tags)."""
+    from optimized_rag_amd.document_store import GpuDocumentIndex
+    from optimized_rag_amd.hierarchical import retrieve_tier_2_batch
+    from optimized_rag_amd.retrieval import HybridRetriever
+    rng = np.random.default_rng(43)
+    N, D, Qn = 6000, 1536, 9
+    emb = rng.standard_normal((N, D)).astype(np.float32)
+    rows = [{"content": f"chunk {i}", "agent_id": f"agent-{i % 2}", "filename": "f.txt", "file_type": "txt", "metadata": {"i": i}}
+            for i in range(N)]
+    table = {f"question {j}": [float(x) for x in (emb[100 * j + 3] + 0.4 * rng.standard_normal(D)).astype(np.float32)] for j in range(Qn)}
+    calls = {"single": 0, "batch": 0}
+
+    class Svc:
+        def generate_embedding(self, text):
+            calls["single"] += 1
+            return table[text]
+
+        def generate_embeddings_batch(self, texts):
+            calls["batch"] += 1
+            return [table[t] for t in texts]
+
+    store = GpuDocumentIndex(Svc(), dim=D, engine=eng)
+    store.bulk_load(rows, emb)
+    qs = list(table)
+    many = store.search_many("agent-1", qs, top_k=7)
+    assert calls == {"single": 0, "batch": 1}
+    singles = [store.search("agent-1", q, top_k=7) for q in qs]
+    assert many == singles
+    hr = HybridRetriever(memory_manager=None, document_store=store, agent_id="agent-1", engine=eng)
+    assert hr.retrieve_batch(qs, sources=["documents"], top_k=7) == [hr.retrieve(q, sources=["documents"], top_k=7) for q in qs]
+    tiered = retrieve_tier_2_batch(hr, qs, 7)
+    assert [[d["metadata"]["i"] for d in res] for res in tiered] == [[d["metadata"]["i"] for d in res] for res in singles]
+    assert all(d["tier"] == 2 and d["source"] == "documents" for res in tiered for d in res)
+    assert store.search_many("no-such-agent", qs[:2]) == [[], []] and store.search_many("agent-1", []) == []
+    eng.set_tenants(None)
+
+
 # ---------------------------------------------------------------------------------------- fused device hybrid
 def test_hybrid_rrf_dev_matches_oracle_pipeline(eng):
     """rag_hybrid_rrf_dev (dense top-pool + BM25 top-pool + RRF, all on device) == oracle dense + oracle BM25 + oracle RRF."""
