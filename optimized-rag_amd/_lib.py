@@ -18,7 +18,8 @@ class RagError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "librag_hip.so")
+    # RAG_HIP_LIB: diagnostic builds of the library (tools/ce_probe_build.sh); the product path is the in-tree .so
+    return os.environ.get("RAG_HIP_LIB") or os.path.join(_HERE, "librag_hip.so")
 
 
 class DenseStats(C.Structure):

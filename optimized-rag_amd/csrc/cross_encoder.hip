@@ -5,7 +5,9 @@
 // Numerics: the north star asks for rerank scores within 1e-3. Single fp16 operands give ~2e-2 logit error after
 // 6 layers (measured), so every MFMA operand is a SPLIT fp16 pair x = hi + lo (hi = fp16(x), lo = fp16(x - hi),
 // ~22 significand bits) stored as two planes, and every product is 3 MFMAs: hi*hi + hi*lo + lo*hi with fp32
-// accumulation (3/16 of the f32-MFMA cost for the same accuracy class). Residual stream / LayerNorm / softmax /
+// accumulation (3/16 of the f32-MFMA cost for the same accuracy class). GEMM operands (weights, x, ctx, q, ffn activations)
+// keep the two halves INTERLEAVED per 32-element K group: [hi 32 halfs | lo 32 halfs] = 128 B, so the row piece one K-step
+// (32 elements) stages is one whole 128-B line instead of two 64-B halves of two lines (SPLIT_IDX). Residual stream / LayerNorm / softmax /
 // GELU (erf form, A&S 7.1.26) / pooler are fp32. Layout: tokens are rows, PACKED per pair (pair p owns len_p rounded up
 // to 32 rows, offsets computed on the device), feature contiguous; weights are nn.Linear [out][in] = K-contiguous, so
 // every GEMM is the "both operands K-contiguous" form MFMA wants.
@@ -56,9 +58,11 @@ struct rag_ce_model {
 #define CE_BM 128     // output features per tile (MFMA rows)
 #define CE_BN 256     // tokens per tile (MFMA cols)
 #define CE_BK 32      // K per LDS stage = one mfma_16x16x32 k-step
-#define CE_W_BYTES (CE_BM * CE_BK * 2)                    // one plane of the weight tile: 8 KiB
-#define CE_X_BYTES (CE_BN * CE_BK * 2)                    // one plane of the token tile: 16 KiB
-#define CE_STAGE_BYTES (2 * CE_W_BYTES + 2 * CE_X_BYTES)  // W_hi | W_lo | X_hi | X_lo = 48 KiB
+#define CE_W_TILE (CE_BM * 128)                           // weight tile of one K-step: 128 rows x [hi 64 B | lo 64 B] = 16 KiB
+#define CE_X_TILE (CE_BN * 128)                           // token tile of one K-step: 256 rows x 128 B = 32 KiB
+#define CE_STAGE_BYTES (CE_W_TILE + CE_X_TILE)            // 48 KiB
+// element c of a split row lives at half index SPLIT_IDX(c) (hi) and SPLIT_IDX(c) + 32 (lo); a row of n elements takes 2n halfs
+#define SPLIT_IDX(c) ((((c) >> 5) << 6) + ((c) & 31))
 #define CE_GEMM_LDS (3 * CE_STAGE_BYTES)                  // three stages = 144 KiB
 #define CE_EPI_PLANE16 (16 * 144)                         // one fp16 plane of a 16-token x 64-feature epilogue pass, rows padded to 144 B
 
@@ -87,9 +91,9 @@ __device__ __forceinline__ void store_split4(half_t* __restrict__ p, size_t plan
     *reinterpret_cast<half4*>(p + plane) = lo;
 }
 
-// LDS rows are 64 B (32 halfs = 4 chunks of 16 B). Chunk c of row r is stored at position c ^ ((-(r>>2)) & 3): with
-// that swizzle every 16-lane group of a ds_read_b128 fragment read covers all 16 bank slots once (conflict-free);
-// as in dense.hip it is applied on the DMA SOURCE address, the LDS destination stays lane-linear.
+// LDS rows are 128 B (8 chunks of 16 B: hi chunks 0-3, lo chunks 4-7 of one 32-element K group). Chunk c of row r is
+// stored at position c ^ ((r>>1) & 7) - dense.hip's swizzle, conflict-free for ds_read_b128 fragment reads - applied on the
+// DMA SOURCE address; the LDS destination stays lane-linear.
 __device__ __forceinline__ void ce_dma(const half_t* __restrict__ g, char* lds, int wid) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)(lds + wid * 64 * 16), 16, 0, 0);
@@ -114,10 +118,10 @@ __device__ __forceinline__ void ce_dma(const half_t* __restrict__ g, char* lds, 
 // W_hi * x_lo (undoes the rounding of the ACTIVATIONS). 3 = both (default everywhere); the other instances exist for the
 // per-site ablation of DESIGN.md section 4.5 (RAG_CE_TERMS) and for sites where a term is provably not needed.
 template <int EPI, int TERMS>
-__global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__ W, size_t w_plane, const half_t* __restrict__ X,
-                                                       size_t x_plane, int N, int K, const float* __restrict__ bias,
+__global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__ W, const half_t* __restrict__ X,
+                                                       int N, int K, const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ out32,
-                                                       half_t* __restrict__ out16, size_t out_plane, half_t* __restrict__ kf16,
+                                                       half_t* __restrict__ out16, half_t* __restrict__ kf16,
                                                        half_t* __restrict__ vf16, size_t kv_plane, int hidden, int heads,
                                                        const int32_t* __restrict__ m_packed, const int32_t* __restrict__ row_pair,
                                                        const int32_t* __restrict__ pair_off) {
@@ -137,33 +141,36 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
 #define CE_TILE_M(w) (((w) / n_ft) * 8 + xcd)
 #define CE_TILE_N(w) ((w) % n_ft)
     if (CE_TILE_M(work) * CE_BN >= m_end) return;
-    // DMA source per thread: linear chunk i = tid (+512): row i>>2, position i&3 -> source chunk (i&3) ^ ((-(row>>2))&3)
-    const int sr = tid >> 2;                                          // 0..127
-    const int schunk = (tid & 3) ^ ((-(sr >> 2)) & 3);                // (row+128)>>2 has the same low 2 bits
-    const size_t x_half = (size_t)128 * K;
+    // DMA source per thread: one piece = 64 rows x 128 B; linear chunk i = tid: row i>>3, position i&7 -> source chunk
+    // (i&7) ^ ((row>>1)&7); (row + 64)>>1 has the same low 3 bits, so every piece of a tile uses the same per-thread chunk
+    const int sr = tid >> 3;                                          // 0..63
+    const int schunk = (tid & 7) ^ ((sr >> 1) & 7);
+    const size_t ldk = (size_t)2 * K;                                 // halfs per split row
+    const size_t piece = (size_t)64 * ldk;                            // 64 rows further
     const int fr = lane & 15, fq = lane >> 4;
-    // fragment row r = base16 + fr (base16 multiple of 16 -> (r>>2)&3 == (fr>>2)&3): byte offset inside a plane tile
-    const int off = fr * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
-    const int a_base = wm * 64 * 64, b_base = wn * 64 * 64;
+    // fragment row r = base16 + fr (base16 multiple of 16 -> (r>>1)&7 == (fr>>1)&7): byte offsets of the hi / lo chunk
+    const int sw = (fr >> 1) & 7;
+    const int off = fr * 128 + ((fq ^ sw) << 4), off_lo = fr * 128 + (((4 + fq) ^ sw) << 4);
+    const int a_base = wm * 64 * 128, b_base = CE_W_TILE + wn * 64 * 128;
     const int nt = K / CE_BK;
     const int last = nt - 1;
-    const half_t* w_cur = W + (size_t)(CE_TILE_N(work) * CE_BM + sr) * K + schunk * 8;
-    const half_t* x_cur = X + (size_t)(CE_TILE_M(work) * CE_BN + sr) * K + schunk * 8;   // rows 0..127 of the tile; +128*K for the rest
+    const half_t* w_cur = W + (size_t)(CE_TILE_N(work) * CE_BM + sr) * ldk + schunk * 8;
+    const half_t* x_cur = X + (size_t)(CE_TILE_M(work) * CE_BN + sr) * ldk + schunk * 8;   // rows sr, +64, +128, +192 of the tile
     const half_t *w_nxt = w_cur, *x_nxt = x_cur;
     bool has_next = false;
     int sbase = 0;                               // ring stage of step 0 of the current tile
 #define CE_ISSUE(u)   /* step u of the current tile; u >= nt: step u - nt of the next tile (or a harmless re-load) */     \
     {                                                                                                             \
         const int u_ = (u);                                                                                       \
-        const half_t* ws_ = u_ < nt ? w_cur + u_ * CE_BK : (has_next ? w_nxt + (u_ - nt) * CE_BK : w_cur + last * CE_BK);  \
-        const half_t* xs_ = u_ < nt ? x_cur + u_ * CE_BK : (has_next ? x_nxt + (u_ - nt) * CE_BK : x_cur + last * CE_BK);  \
+        const half_t* ws_ = u_ < nt ? w_cur + u_ * 64 : (has_next ? w_nxt + (u_ - nt) * 64 : w_cur + last * 64);  \
+        const half_t* xs_ = u_ < nt ? x_cur + u_ * 64 : (has_next ? x_nxt + (u_ - nt) * 64 : x_cur + last * 64);  \
         char* st_ = smem + ((sbase + u_) % 3) * CE_STAGE_BYTES;                                                   \
         ce_dma(ws_, st_, wid);                                                                                    \
-        ce_dma(ws_ + w_plane, st_ + CE_W_BYTES, wid);                                                             \
-        ce_dma(xs_, st_ + 2 * CE_W_BYTES, wid);                                                                   \
-        ce_dma(xs_ + x_half, st_ + 2 * CE_W_BYTES + 512 * 16, wid);                                               \
-        ce_dma(xs_ + x_plane, st_ + 2 * CE_W_BYTES + CE_X_BYTES, wid);                                            \
-        ce_dma(xs_ + x_plane + x_half, st_ + 2 * CE_W_BYTES + CE_X_BYTES + 512 * 16, wid);                        \
+        ce_dma(ws_ + piece, st_ + 8192, wid);                                                                     \
+        ce_dma(xs_, st_ + CE_W_TILE, wid);                                                                        \
+        ce_dma(xs_ + piece, st_ + CE_W_TILE + 8192, wid);                                                         \
+        ce_dma(xs_ + 2 * piece, st_ + CE_W_TILE + 2 * 8192, wid);                                                 \
+        ce_dma(xs_ + 3 * piece, st_ + CE_W_TILE + 3 * 8192, wid);                                                 \
     }
 #define CE_BAR __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
     CE_ISSUE(0)
@@ -178,8 +185,8 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
             const int nx = work + n_slots;
             has_next = CE_TILE_M(nx) * CE_BN < m_end;
             if (has_next) {
-                w_nxt = W + (size_t)(CE_TILE_N(nx) * CE_BM + sr) * K + schunk * 8;
-                x_nxt = X + (size_t)(CE_TILE_M(nx) * CE_BN + sr) * K + schunk * 8;
+                w_nxt = W + (size_t)(CE_TILE_N(nx) * CE_BM + sr) * ldk + schunk * 8;
+                x_nxt = X + (size_t)(CE_TILE_M(nx) * CE_BN + sr) * ldk + schunk * 8;
             }
         }
         // bias in registers before the main loop: the epilogue must not start with a global load behind the in-flight DMA
@@ -197,15 +204,17 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
             half8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ah[i] = *reinterpret_cast<const half8*>(st + a_base + i * 16 * 64 + off);
-                if (TERMS & 1) al[i] = *reinterpret_cast<const half8*>(st + CE_W_BYTES + a_base + i * 16 * 64 + off);
+                ah[i] = *reinterpret_cast<const half8*>(st + a_base + i * 16 * 128 + off);
+                if (TERMS & 1) al[i] = *reinterpret_cast<const half8*>(st + a_base + i * 16 * 128 + off_lo);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                bh[j] = *reinterpret_cast<const half8*>(st + 2 * CE_W_BYTES + b_base + j * 16 * 64 + off);
-                if (TERMS & 2) bl[j] = *reinterpret_cast<const half8*>(st + 2 * CE_W_BYTES + CE_X_BYTES + b_base + j * 16 * 64 + off);
+                bh[j] = *reinterpret_cast<const half8*>(st + b_base + j * 16 * 128 + off);
+                if (TERMS & 2) bl[j] = *reinterpret_cast<const half8*>(st + b_base + j * 16 * 128 + off_lo);
             }
+#ifndef CE_PROBE_NO_DMA          // timing experiments only (tools/ce_probe_build.sh): results are wrong without the stream
             CE_ISSUE(t + 2)
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // step t+1 must have landed before the next I-part. On a continued tile steps 0 and 1 were resident before the
             // loop started (see below), so its first wait is skipped: it would only wait for the previous epilogue's stores.
@@ -213,6 +222,7 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
             if (lag && need_wait) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             CE_BAR
             __builtin_amdgcn_s_setprio(1);
+#ifndef CE_PROBE_NO_MFMA
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -221,6 +231,9 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
                     if (TERMS & 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
+#else
+            acc[0][0][0] += (float)ah[0][0] + (float)bh[0][0] + (float)al[3][7] + (float)bl[3][7];    // keep the reads alive
+#endif
             __builtin_amdgcn_s_setprio(0);
             if (!lag && need_wait) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             CE_BAR
@@ -236,6 +249,10 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
         // outputs are streamed with non-temporal stores: they are read again only by a later kernel (GBs later), and as
         // ordinary stores they pushed the shared token tile and the weights out of the XCD's 4 MiB L2
         char* wl = smem + ((sbase + nt + 2) % 3) * CE_STAGE_BYTES + wid * CE_EPI_WAVE_BYTES;
+#ifdef CE_PROBE_NO_EPI
+        if (acc[0][0][0] == 12345.678f) out32[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];
+        else if (false)
+#endif
         if (EPI == EPI_RESID) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {                       // fp32 [16 tokens][64 features], row stride 272 B
@@ -266,17 +283,17 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (EPI == EPI_GELU || nb < hidden) {
-                    // FFN activations [token][ffn], or Q rows [token][hidden]: 8 lanes cover one 128 B line of a row
-                    const int ldo = EPI == EPI_GELU ? N : hidden;
-                    const int rr = lane >> 3, cc = lane & 7;
+                    // FFN activations [token][ffn], or Q rows [token][hidden], in the split-row layout: the wave's 64 features
+                    // of a token are two K groups = [hi 32 | lo 32 | hi 32 | lo 32] = 256 contiguous bytes; 16 lanes cover them
+                    const int ldo = 2 * (EPI == EPI_GELU ? N : hidden);
+                    const int rr = lane >> 4, cc = lane & 15;
+                    const int grp = cc >> 3, part = (cc >> 2) & 1, qtr = cc & 3;
 #pragma unroll
-                    for (int it = 0; it < 2; ++it) {
-                        const int row = it * 8 + rr;
-                        const half8 hi = *reinterpret_cast<const half8*>(wl + row * 144 + cc * 16);
-                        const half8 lo = *reinterpret_cast<const half8*>(wl + CE_EPI_PLANE16 + row * 144 + cc * 16);
-                        half_t* o = out16 + (size_t)(mb + j * 16 + row) * ldo + nb + cc * 8;
-                        __builtin_nontemporal_store(hi, reinterpret_cast<half8*>(o));
-                        __builtin_nontemporal_store(lo, reinterpret_cast<half8*>(o + out_plane));
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = it * 4 + rr;
+                        const half8 v = *reinterpret_cast<const half8*>(wl + part * CE_EPI_PLANE16 + row * 144 + (grp * 4 + qtr) * 16);
+                        half_t* o = out16 + (size_t)(mb + j * 16 + row) * ldo + (nb >> 5) * 64 + cc * 8;
+                        __builtin_nontemporal_store(v, reinterpret_cast<half8*>(o));
                     }
                 } else {
                     // K features -> kf16[pair rows][head][key tile][lane = fq*16 + key%16][8 dims fq*8..]: the MFMA A-fragment
@@ -355,8 +372,7 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
 // ---- LayerNorm helpers: one wave per token row of `hidden` floats (hidden % 64 == 0, <= 1024) --------------
 template <int PER>
 __device__ __forceinline__ void wave_layernorm(float (&v)[PER], const float* __restrict__ g, const float* __restrict__ b,
-                                               int hidden, float eps, int lane, float* __restrict__ o32, half_t* __restrict__ o16,
-                                               size_t plane) {
+                                               int hidden, float eps, int lane, float* __restrict__ o32, half_t* __restrict__ o16) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < PER; ++i) s += v[i];
@@ -375,8 +391,8 @@ __device__ __forceinline__ void wave_layernorm(float (&v)[PER], const float* __r
         const float y = (v[i] - mean) * rstd * g[c] + b[c];
         o32[c] = y;
         const half_t hi = (half_t)y;
-        o16[c] = hi;
-        o16[plane + c] = (half_t)(y - (float)hi);
+        o16[SPLIT_IDX(c)] = hi;
+        o16[SPLIT_IDX(c) + 32] = (half_t)(y - (float)hi);
     }
 }
 
@@ -421,7 +437,7 @@ __global__ __launch_bounds__(256) void ce_embed_ln_kernel(const int32_t* __restr
                                                            const float* __restrict__ b, const int32_t* __restrict__ m_packed,
                                                            const int32_t* __restrict__ row_pair, const int32_t* __restrict__ pair_off,
                                                            int L, int hidden, int vocab, float eps, float* __restrict__ x32,
-                                                           half_t* __restrict__ x16, size_t plane) {
+                                                           half_t* __restrict__ x16) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= m_packed[0]) return;
@@ -437,21 +453,21 @@ __global__ __launch_bounds__(256) void ce_embed_ln_kernel(const int32_t* __restr
         const int c = lane + i * 64;
         v[i] = word[(size_t)id * hidden + c] + type[(size_t)ty * hidden + c] + pos[(size_t)p * hidden + c];
     }
-    wave_layernorm<PER>(v, g, b, hidden, eps, lane, x32 + row * hidden, x16 + row * hidden, plane);
+    wave_layernorm<PER>(v, g, b, hidden, eps, lane, x32 + row * hidden, x16 + row * 2 * hidden);
 }
 
 template <int PER>
 __global__ __launch_bounds__(256) void ce_layernorm_kernel(const float* __restrict__ y32, const float* __restrict__ g,
                                                             const float* __restrict__ b, const int32_t* __restrict__ m_packed,
                                                             int hidden, float eps, float* __restrict__ x32,
-                                                            half_t* __restrict__ x16, size_t plane) {
+                                                            half_t* __restrict__ x16) {
     const int lane = threadIdx.x & 63;
     const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= m_packed[0]) return;
     float v[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) v[i] = y32[tok * hidden + lane + i * 64];
-    wave_layernorm<PER>(v, g, b, hidden, eps, lane, x32 + tok * hidden, x16 + tok * hidden, plane);
+    wave_layernorm<PER>(v, g, b, hidden, eps, lane, x32 + tok * hidden, x16 + tok * 2 * hidden);
 }
 
 // ---- attention: d_head must be 32. One block per (head, pair); every wave owns QB consecutive 16-query blocks.
@@ -475,11 +491,11 @@ __device__ __forceinline__ void ce_dma_at(const half_t* __restrict__ g, char* ld
 }
 
 template <int QB>
-__global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __restrict__ q16, size_t q_plane,
+__global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __restrict__ q16,
                                                              const half_t* __restrict__ kf16, const half_t* __restrict__ vf16,
                                                              size_t kv_plane, const int32_t* __restrict__ lens,
                                                              const int32_t* __restrict__ pair_off, int L, int hidden,
-                                                             int heads, half_t* __restrict__ ctx16, size_t ctx_plane) {
+                                                             int heads, half_t* __restrict__ ctx16) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
@@ -510,9 +526,10 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
     half8 qh[QB], ql[QB];
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        const half_t* qp = q16 + (row0 + (qb0 + b) * 16 + fr) * hidden + head * 32 + fq * 8;
+        // split-row layout: a head's 32 dims are one K group = [hi 32 | lo 32] halfs
+        const half_t* qp = q16 + (row0 + (qb0 + b) * 16 + fr) * (2 * hidden) + head * 64 + fq * 8;
         qh[b] = *reinterpret_cast<const half8*>(qp);
-        ql[b] = *reinterpret_cast<const half8*>(qp + q_plane);
+        ql[b] = *reinterpret_cast<const half8*>(qp + 32);
     }
     f32x4 c0[QB], c1[QB];
     float mrun[QB], lsum[QB];
@@ -590,9 +607,9 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
         const float inv = 1.0f / l;
-        half_t* o = ctx16 + (row0 + (qb0 + b) * 16 + fr) * hidden + head * 32 + fq * 4;
-        store_split4(o, ctx_plane, c0[b][0] * inv, c0[b][1] * inv, c0[b][2] * inv, c0[b][3] * inv);
-        store_split4(o + 16, ctx_plane, c1[b][0] * inv, c1[b][1] * inv, c1[b][2] * inv, c1[b][3] * inv);
+        half_t* o = ctx16 + (row0 + (qb0 + b) * 16 + fr) * (2 * hidden) + head * 64 + fq * 4;
+        store_split4(o, 32, c0[b][0] * inv, c0[b][1] * inv, c0[b][2] * inv, c0[b][3] * inv);
+        store_split4(o + 16, 32, c1[b][0] * inv, c1[b][1] * inv, c1[b][2] * inv, c1[b][3] * inv);
     }
 }
 
@@ -620,12 +637,15 @@ __global__ __launch_bounds__(256) void ce_pool_classify_kernel(const float* __re
     if (tid == 0) logits[pair] = part[0] + part[1] + part[2] + part[3] + bc[0];
 }
 
-__global__ void ce_f32_split_kernel(const float* __restrict__ in, half_t* __restrict__ out, int64_t n) {
+__global__ void ce_f32_split_kernel(const float* __restrict__ in, half_t* __restrict__ out, int64_t n, int cols) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
+        const int64_t row = i / cols;
+        const int c = (int)(i % cols);
         const half_t hi = (half_t)in[i];
-        out[i] = hi;
-        out[n + i] = (half_t)(in[i] - (float)hi);      // lo plane follows the hi plane
+        half_t* o = out + row * 2 * cols + SPLIT_IDX(c);   // split-row layout: [hi 32 | lo 32] per 32-element K group
+        o[0] = hi;
+        o[32] = (half_t)(in[i] - (float)hi);
     }
 }
 
@@ -664,7 +684,7 @@ static int up_f16_concat(rag_ctx* h, rag_ce_model* m, std::vector<const float*> 
     m->allocs.push_back(*dst);
     for (size_t i = 0; i < srcs.size(); ++i)
         HIP_TRY(h, hipMemcpyAsync(tmp + i * n_each, srcs[i], n_each * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(ce_f32_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, tmp, *dst, (int64_t)total);
+    hipLaunchKernelGGL(ce_f32_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, tmp, *dst, (int64_t)total, (int)cols);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     hipFree(tmp);
     return RAG_OK;
@@ -737,15 +757,15 @@ static int launch_attention(rag_ctx* h, rag_ce_model* m, int P, int L, const ce_
         attr_lds = lds;
     }
     const int waves = L / (16 * QB);
-    hipLaunchKernelGGL((ce_attention_kernel<QB>), dim3(m->cfg.heads, P), dim3(64 * waves), lds, st, m->q16, pp.q, m->kf16, m->vf16,
-                       pp.kv, m->lens, m->pair_off, L, m->cfg.hidden, m->cfg.heads, m->ctx16, pp.ctx);
+    hipLaunchKernelGGL((ce_attention_kernel<QB>), dim3(m->cfg.heads, P), dim3(64 * waves), lds, st, m->q16, m->kf16, m->vf16,
+                       pp.kv, m->lens, m->pair_off, L, m->cfg.hidden, m->cfg.heads, m->ctx16);
     return RAG_OK;
 }
 
 template <int PER>
-static void launch_ln(rag_ce_model* m, const float* y, const float* g, const float* b, int64_t M, size_t plane, hipStream_t st) {
+static void launch_ln(rag_ce_model* m, const float* y, const float* g, const float* b, int64_t M, hipStream_t st) {
     hipLaunchKernelGGL(ce_layernorm_kernel<PER>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, y, g, b, m->m_packed, m->cfg.hidden,
-                       (float)m->cfg.ln_eps, m->x32, m->x16, plane);
+                       (float)m->cfg.ln_eps, m->x32, m->x16);
 }
 
 static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t st) {
@@ -782,7 +802,7 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     }
 #define EMB(PER) hipLaunchKernelGGL(ce_embed_ln_kernel<PER>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, m->ids, m->tt, m->word, \
                                     m->pos, m->type, m->emb_ln_g, m->emb_ln_b, m->m_packed, m->row_pair, m->pair_off, L, H,            \
-                                    m->cfg.vocab_size, eps, m->x32, m->x16, pp.x)
+                                    m->cfg.vocab_size, eps, m->x32, m->x16)
     // packed row layout of this chunk (no host round trip: grids cover the padded worst case, kernels stop at m_packed)
     hipLaunchKernelGGL(ce_pack_scan_kernel, dim3(1), dim3(1024), 0, st, m->lens, P, L, m->pair_off, m->m_packed);
     hipLaunchKernelGGL(ce_pack_rows_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, st, m->pair_off, P, L, Mp, m->row_pair);
@@ -792,25 +812,25 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     const half_t* nullh = nullptr;
     for (int l = 0; l < m->cfg.layers; ++l) {
         auto& ly = m->layers[l];
-        CE_GEMM(EPI_QKV, terms[0], ly.wqkv, (size_t)3 * H * H, m->x16, pp.x,
-                3 * H, H, ly.bqkv, (const float*)nullptr, (float*)nullptr, m->q16, pp.q, m->kf16, m->vf16, pp.kv, H,
+        CE_GEMM(EPI_QKV, terms[0], ly.wqkv, m->x16,
+                3 * H, H, ly.bqkv, (const float*)nullptr, (float*)nullptr, m->q16, m->kf16, m->vf16, pp.kv, H,
                 m->cfg.heads, m->m_packed, m->row_pair, m->pair_off)
         {
             const int rc = L == 32 ? launch_attention<1>(h, m, P, L, pp, st) : launch_attention<2>(h, m, P, L, pp, st);
             if (rc != RAG_OK) return rc;
         }
-        CE_GEMM(EPI_RESID, terms[1], ly.wo, (size_t)H * H, m->ctx16, pp.ctx, H, H,
-                ly.bo, (const float*)m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
+        CE_GEMM(EPI_RESID, terms[1], ly.wo, m->ctx16, H, H,
+                ly.bo, (const float*)m->x32, m->y32, (half_t*)nullptr, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
                 m->row_pair, m->pair_off)
-#define LN1(PER) launch_ln<PER>(m, m->y32, ly.ln1_g, ly.ln1_b, M, pp.x, st)
+#define LN1(PER) launch_ln<PER>(m, m->y32, ly.ln1_g, ly.ln1_b, M, st)
         CE_PER_DISPATCH(LN1)
-        CE_GEMM(EPI_GELU, terms[2], ly.w1, (size_t)F * H, m->x16, pp.x, F, H,
-                ly.b1, (const float*)nullptr, (float*)nullptr, m->h16, pp.h, (half_t*)nullptr, (half_t*)nullptr, (size_t)0,
+        CE_GEMM(EPI_GELU, terms[2], ly.w1, m->x16, F, H,
+                ly.b1, (const float*)nullptr, (float*)nullptr, m->h16, (half_t*)nullptr, (half_t*)nullptr, (size_t)0,
                 H, m->cfg.heads, m->m_packed, m->row_pair, m->pair_off)
-        CE_GEMM(EPI_RESID, terms[3], ly.w2, (size_t)H * F, m->h16, pp.h, H, F,
-                ly.b2, (const float*)m->x32, m->y32, (half_t*)nullptr, (size_t)0, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
+        CE_GEMM(EPI_RESID, terms[3], ly.w2, m->h16, H, F,
+                ly.b2, (const float*)m->x32, m->y32, (half_t*)nullptr, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
                 m->row_pair, m->pair_off)
-#define LN2(PER) launch_ln<PER>(m, m->y32, ly.ln2_g, ly.ln2_b, M, pp.x, st)
+#define LN2(PER) launch_ln<PER>(m, m->y32, ly.ln2_g, ly.ln2_b, M, st)
         CE_PER_DISPATCH(LN2)
     }
     (void)nullh;
