@@ -14,7 +14,11 @@
 //
 // Kernels
 //   ce_pack_scan/rows  lens -> pair_off / row_pair / m_packed (the packed row layout of the chunk)
-//   ce_embed_ln        word+pos+type gather -> LayerNorm -> x32 (fp32 residual) + x16 (split-fp16 GEMM operand)
+//   ce_embed_ln        word+pos+type gather -> LayerNorm -> x16: the residual stream IS the split-fp16 GEMM operand (hi + lo
+//                      = 22 significant bits); there is no separate fp32 copy
+//   ce_gemm_ln         out-proj / FFN-down with bias + residual + LayerNorm fused into the epilogue (hidden = 384): a
+//                      workgroup owns ALL features of its 128 tokens, so a row's statistics never leave the CU and the
+//                      pre-LayerNorm tensor never touches HBM
 //   ce_gemm<EPI>       persistent, XCD-aware; 128 (out features) x 256 (tokens) tiles, BK = 32, three LDS stages by
 //                      LDS-DMA with a continuous stream across tiles, 8 staggered waves (2 x 4 of 64 x 64), source-swizzled
 //                      conflict-free ds_read_b128. Output features sit on the MFMA ROW (bias = 4 registers per lane).
@@ -45,7 +49,7 @@ struct rag_ce_model {
     // activation workspace (sized for ws_tokens)
     int64_t ws_tokens = 0;
     int ws_pairs = 0, ws_L = 0;
-    float *x32 = nullptr, *y32 = nullptr;
+    float* y32 = nullptr;                              // pre-LayerNorm sums: only the unfused fallback path allocates it
     half_t *x16 = nullptr, *q16 = nullptr, *kf16 = nullptr, *vf16 = nullptr, *ctx16 = nullptr, *h16 = nullptr;
     int32_t *ids = nullptr, *tt = nullptr, *lens = nullptr;
     // packed (variable-length) row layout of the current chunk: pair p owns rows [pair_off[p], pair_off[p+1]) where
@@ -120,7 +124,7 @@ __device__ __forceinline__ void ce_dma(const half_t* __restrict__ g, char* lds, 
 template <int EPI, int TERMS>
 __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__ W, const half_t* __restrict__ X,
                                                        int N, int K, const float* __restrict__ bias,
-                                                       const float* __restrict__ resid, float* __restrict__ out32,
+                                                       const half_t* __restrict__ resid, float* __restrict__ out32,
                                                        half_t* __restrict__ out16, half_t* __restrict__ kf16,
                                                        half_t* __restrict__ vf16, size_t kv_plane, int hidden, int heads,
                                                        const int32_t* __restrict__ m_packed, const int32_t* __restrict__ row_pair,
@@ -267,8 +271,11 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
                     const int row = it * 4 + rr;
                     const float4 v = *reinterpret_cast<const float4*>(wl + row * 272 + cc * 16);
                     const size_t g = (size_t)(mb + j * 16 + row) * N + nb + cc * 4;
-                    const float4 rv = *reinterpret_cast<const float4*>(resid + g);
-                    __builtin_nontemporal_store((f32x4){v.x + rv.x, v.y + rv.y, v.z + rv.z, v.w + rv.w}, reinterpret_cast<f32x4*>(out32 + g));
+                    const half_t* rp = resid + (size_t)(mb + j * 16 + row) * 2 * N + SPLIT_IDX(nb + cc * 4);      // residual = hi + lo
+                    const half4 rh = *reinterpret_cast<const half4*>(rp), rl = *reinterpret_cast<const half4*>(rp + 32);
+                    __builtin_nontemporal_store((f32x4){v.x + ((float)rh[0] + (float)rl[0]), v.y + ((float)rh[1] + (float)rl[1]),
+                                                        v.z + ((float)rh[2] + (float)rl[2]), v.w + ((float)rh[3] + (float)rl[3])},
+                                                reinterpret_cast<f32x4*>(out32 + g));
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -369,10 +376,240 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // clamped tail re-loads of the last tile: retire them before exit
 }
 
+// ---- out-proj / FFN-down with bias + residual + LayerNorm in the epilogue (hidden = 384) -------------------------------
+// The cross-encoder forward is bound by activation traffic, not by the matrix pipe (tools/ce_probe_build.sh: without MFMAs
+// the forward is 9 % faster, without epilogue stores 35 %). The unfused form moves, per token and LayerNorm site,
+// y32 out (1.5 KB), y32 + residual in (3 KB), x out (1.5 KB); fused, the residual comes in and the new stream goes out
+// (1.5 KB each), and two kernel launches per layer disappear.
+// Geometry: a persistent workgroup owns 128 tokens x ALL 384 features (so the row statistics stay on the CU): 8 waves =
+// 2 feature halves (192 = 12 MFMA row blocks) x 4 token groups (32 = 2 column blocks), 96 accumulator registers per lane.
+// Per 32-deep K-step the W slice (384 rows x [hi|lo] 128 B = 48 KiB, double-buffered: its source is L2-resident) and the
+// token slice (128 rows x 128 B = 16 KiB, triple-buffered: its source is an HBM stream, two steps of lead) arrive by
+// LDS-DMA as ONE continuous stream across tiles; one barrier per K-step (RAW: counted vmcnt(2); WAR: a slot is refilled
+// only after the barrier that follows its last read). The W stage that is free after the last K-step is the epilogue's
+// transpose scratch (6 KiB per wave). K must be a multiple of 192 (stages are then functions of the K-step alone).
+// LDS-DMA piece through a buffer descriptor: per-lane byte offset in one VGPR, piece / K-step offset in a scalar register
+__device__ __forceinline__ void lng_dma(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, char* lds, int wid) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + wid * 64 * 16), 16, voff, soff, 0, 0);
+}
+#define LNG_W_STAGE (384 * 128)                    // 48 KiB
+#define LNG_X_STAGE (128 * 128)                    // 16 KiB
+#define LNG_LDS (2 * LNG_W_STAGE + 3 * LNG_X_STAGE)    // 144 KiB
+template <int TERMS>
+__global__ __launch_bounds__(512) void ce_gemm_ln_kernel(const half_t* __restrict__ W, const half_t* __restrict__ X, int K,
+                                                          const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, half_t* __restrict__ stream16,
+                                                          const int32_t* __restrict__ m_packed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int H = 384;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int m_end = m_packed[0];
+    int tile = blockIdx.x;
+    if (tile * 128 >= m_end) return;
+    const int nt = K / CE_BK;
+    const size_t ldk = (size_t)2 * K;
+    // DMA source per thread: piece pc = p * 8 + wid covers rows pc * 8 .. + 8; lane -> row pc * 8 + (lane >> 3), 16-B position
+    // lane & 7, source chunk = position ^ ((row >> 1) & 7) = position ^ ((wid & 1) * 4 + (lane >> 4))  (p * 8 is even)
+    // Every DMA is a BUFFER load: descriptor (scalar registers: W, or the 128 token rows of one tile) + ONE per-lane byte
+    // offset shared by all pieces + a scalar offset (piece, K-step). No address VGPRs besides that one (the first version
+    // carried 6 + 4 pointer pairs through the main loop and spilled them), no address arithmetic in the loop, and reads
+    // past a descriptor's end return zeros instead of faulting.
+    const int schunk = (lane & 7) ^ ((wid & 1) * 4 + (lane >> 4));
+    const unsigned voff = (unsigned)(((size_t)(wid * 8 + (lane >> 3)) * ldk + schunk * 8) * sizeof(half_t));
+    const unsigned piece_b = (unsigned)(64 * ldk * sizeof(half_t));                           // 64 rows further, in bytes
+    const unsigned tile_b = 2 * piece_b;                                                      // 128 token rows
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(W), 0, (int)(6 * piece_b), 0x00020000);
+    __amdgpu_buffer_rsrc_t x_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(X + (size_t)tile * 128 * ldk), 0, (int)tile_b, 0x00020000);
+    __amdgpu_buffer_rsrc_t x_nxt = x_cur;
+    bool has_next = false;
+    char* const wring = smem;
+    char* const xring = smem + 2 * LNG_W_STAGE;
+    const int fr = lane & 15, fq = lane >> 4, sw = (fr >> 1) & 7;
+    const int off_hi = fr * 128 + ((fq ^ sw) << 4), off_lo = fr * 128 + (((4 + fq) ^ sw) << 4);
+    const int a_base = wm * 192 * 128, b_base = wn * 32 * 128;
+#define LNG_ISSUE_W(u)   /* W slice of K-step (u mod nt) into W stage u & 1 */                                       \
+    {                                                                                                                \
+        const int ks_ = (u) < nt ? (u) : (u) - nt;                                                                  \
+        char* st_ = wring + ((u) & 1) * LNG_W_STAGE;                                                                \
+        _Pragma("unroll") for (int p_ = 0; p_ < 6; ++p_)                                                            \
+            lng_dma(w_rs, voff, p_ * piece_b + ks_ * 128, st_ + p_ * 8192, wid);                                    \
+    }
+#define LNG_ISSUE_X(u)   /* token slice of step u: this tile, or steps 0.. of the next one (clamped at the very end) */ \
+    {                                                                                                                \
+        const bool nx_ = (u) >= nt && has_next;                                                                     \
+        const int ks_ = (u) < nt ? (u) : (has_next ? (u) - nt : nt - 1);                                            \
+        char* st_ = xring + ((u) % 3) * LNG_X_STAGE;                                                                \
+        if (nx_) {                                                                                                  \
+            lng_dma(x_nxt, voff, ks_ * 128, st_, wid);                                                              \
+            lng_dma(x_nxt, voff, piece_b + ks_ * 128, st_ + 8192, wid);                                             \
+        } else {                                                                                                    \
+            lng_dma(x_cur, voff, ks_ * 128, st_, wid);                                                              \
+            lng_dma(x_cur, voff, piece_b + ks_ * 128, st_ + 8192, wid);                                             \
+        }                                                                                                           \
+    }
+    LNG_ISSUE_W(0)
+    LNG_ISSUE_X(0)
+    LNG_ISSUE_X(1)
+    for (bool first = true;; first = false) {
+        const int m0 = tile * 128;
+        {
+            const int nx = tile + gridDim.x;
+            has_next = nx * 128 < m_end;
+            if (has_next) x_nxt = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(X + (size_t)nx * 128 * ldk), 0, (int)tile_b, 0x00020000);
+        }
+        f32x4 acc[12][2];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int t = 0; t < nt; ++t) {
+            // W(t) and X(t) have landed once at most the 2 pieces of X(t+1) are outstanding; the barrier makes that hold for
+            // every wave's pieces and closes every wave's reads of the slots refilled below
+            // (step 0 of a continued tile: both slices were waited for before the previous epilogue's stores; a counted wait
+            // here would only wait for those stores)
+            if (first || t > 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            CE_BAR
+            LNG_ISSUE_W(t + 1)
+            LNG_ISSUE_X(t + 2)
+            const char* ws = wring + (t & 1) * LNG_W_STAGE + a_base;
+            const char* xs = xring + (t % 3) * LNG_X_STAGE + b_base;
+            half8 bh[2], bl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = *reinterpret_cast<const half8*>(xs + j * 16 * 128 + off_hi);
+                if (TERMS & 2) bl[j] = *reinterpret_cast<const half8*>(xs + j * 16 * 128 + off_lo);
+            }
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {               // 4 of the wave's 12 feature blocks at a time (32 fragment VGPRs)
+                half8 ah[4], al[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ah[i] = *reinterpret_cast<const half8*>(ws + (part * 4 + i) * 16 * 128 + off_hi);
+                    if (TERMS & 1) al[i] = *reinterpret_cast<const half8*>(ws + (part * 4 + i) * 16 * 128 + off_lo);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4& a = acc[part * 4 + i][j];
+                        if (TERMS & 1) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], a, 0, 0, 0);
+                        if (TERMS & 2) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], a, 0, 0, 0);
+                    }
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        // ---- epilogue. acc[i][j][r] = sum for feature wm*192 + i*16 + fq*4 + r, token m0 + wn*32 + j*16 + fr.
+        // Every wave is past its reads of W stage (nt-1)&1 = 1 after this barrier; its refill (step 1 of the next tile) comes
+        // after the next tile's first barrier, so the stage is this epilogue's scratch: 6 KiB per wave. Steps 0 and 1 of the next
+        // tile are in flight: retire them here, where no store is outstanding yet.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CE_BAR
+        char* wl = wring + LNG_W_STAGE + wid * 6144;                 // [16 tokens][64 features] fp32, rows 272 B
+        float* st_sum = reinterpret_cast<float*>(wl + 4352);         // [32] per-token partial sums of this wave's 192 features
+        float* st_sq = st_sum + 32;
+        const float* pr_sum = reinterpret_cast<const float*>(wring + LNG_W_STAGE + (wid ^ 4) * 6144 + 4352);   // the other feature half
+        const float* pr_sq = pr_sum + 32;
+        const int rr = lane >> 4, cc = lane & 15;
+        // epilogue addresses = uniform base + ONE per-lane byte offset + compile-time constants. The offsets are made opaque
+        // here, inside the tile loop, so that the compiler derives each address where it is used instead of hoisting ~70
+        // address registers out of the loop and carrying them through the main loop (which spilled its DMA pointers).
+        unsigned so = (unsigned)((rr * 2 * H + (wm * 6 + (cc >> 3)) * 64 + (cc & 7) * 4) * sizeof(half_t));   // stream row, split index
+        unsigned fo = (unsigned)((wm * 192 + cc * 4) * sizeof(float));                                          // bias / gamma / beta
+        asm volatile("" : "+v"(so), "+v"(fo));
+        char* const srow = reinterpret_cast<char*>(stream16 + (size_t)(m0 + wn * 32) * 2 * H);
+        f32x4 vv[2][3][4];                                           // [token block][64-feature group][4 rows per lane]
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+                    *reinterpret_cast<f32x4*>(wl + fr * 272 + (ii * 16 + fq * 4) * 4) = acc[g * 4 + ii][j];
+                __builtin_amdgcn_wave_barrier();
+                const float4 bv = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(bias) + fo + g * 256);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 4 + rr;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(wl + row * 272 + cc * 16);
+                    // token m0 + wn*32 + j*16 + row, features wm*192 + g*64 + cc*4 .. +4: K group wm*6 + g*2 + (cc>>3)
+                    const half_t* rp = reinterpret_cast<const half_t*>(srow + so + ((j * 16 + it * 4) * 2 * H + g * 128) * sizeof(half_t));
+                    const half4 rh = *reinterpret_cast<const half4*>(rp), rl = *reinterpret_cast<const half4*>(rp + 32);
+                    vv[j][g][it] = (f32x4){v[0] + bv.x + ((float)rh[0] + (float)rl[0]), v[1] + bv.y + ((float)rh[1] + (float)rl[1]),
+                                           v[2] + bv.z + ((float)rh[2] + (float)rl[2]), v[3] + bv.w + ((float)rh[3] + (float)rl[3])};
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);        // one pass at a time: hoisting all 24 residual loads costs ~100 VGPRs
+            }
+        // row statistics: two passes (mean, then centred squares) as the stand-alone LayerNorm; a token's 384 features are
+        // spread over 16 lanes x 3 groups in this wave and as many in the wave that owns the other feature half
+        float mean[2][4], rstd[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                float sm = 0.f;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) sm += (vv[j][g][it][0] + vv[j][g][it][1]) + (vv[j][g][it][2] + vv[j][g][it][3]);
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o);
+                mean[j][it] = sm;
+                if (cc == 0) st_sum[j * 16 + it * 4 + rr] = sm;
+            }
+        CE_BAR
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const float mu = (mean[j][it] + pr_sum[j * 16 + it * 4 + rr]) * (1.0f / (float)H);
+                mean[j][it] = mu;
+                float q = 0.f;
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = vv[j][g][it][e] - mu; q += d * d; }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o);
+                rstd[j][it] = q;
+                if (cc == 0) st_sq[j * 16 + it * 4 + rr] = q;
+            }
+        CE_BAR
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                rstd[j][it] = 1.0f / sqrtf((rstd[j][it] + pr_sq[j * 16 + it * 4 + rr]) * (1.0f / (float)H) + eps);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const float4 gv = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(gamma) + fo + g * 256);
+            const float4 be = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(beta) + fo + g * 256);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const f32x4 v = vv[j][g][it];
+                    const float mu = mean[j][it], rs = rstd[j][it];
+                    half_t* o = reinterpret_cast<half_t*>(srow + so + ((j * 16 + it * 4) * 2 * H + g * 128) * sizeof(half_t));
+                    store_split4(o, 32, (v[0] - mu) * rs * gv.x + be.x, (v[1] - mu) * rs * gv.y + be.y, (v[2] - mu) * rs * gv.z + be.z,
+                                 (v[3] - mu) * rs * gv.w + be.w);
+                }
+        }
+        if (!has_next) break;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // scratch reads retired before the stage is refilled
+        tile += gridDim.x;
+        x_cur = x_nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // clamped tail re-loads: retire them before exit
+#undef LNG_ISSUE_W
+#undef LNG_ISSUE_X
+}
+
 // ---- LayerNorm helpers: one wave per token row of `hidden` floats (hidden % 64 == 0, <= 1024) --------------
 template <int PER>
 __device__ __forceinline__ void wave_layernorm(float (&v)[PER], const float* __restrict__ g, const float* __restrict__ b,
-                                               int hidden, float eps, int lane, float* __restrict__ o32, half_t* __restrict__ o16) {
+                                               int hidden, float eps, int lane, half_t* __restrict__ o16) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < PER; ++i) s += v[i];
@@ -389,7 +626,6 @@ __device__ __forceinline__ void wave_layernorm(float (&v)[PER], const float* __r
     for (int i = 0; i < PER; ++i) {
         const int c = lane + i * 64;
         const float y = (v[i] - mean) * rstd * g[c] + b[c];
-        o32[c] = y;
         const half_t hi = (half_t)y;
         o16[SPLIT_IDX(c)] = hi;
         o16[SPLIT_IDX(c) + 32] = (half_t)(y - (float)hi);
@@ -436,8 +672,7 @@ __global__ __launch_bounds__(256) void ce_embed_ln_kernel(const int32_t* __restr
                                                            const float* __restrict__ type, const float* __restrict__ g,
                                                            const float* __restrict__ b, const int32_t* __restrict__ m_packed,
                                                            const int32_t* __restrict__ row_pair, const int32_t* __restrict__ pair_off,
-                                                           int L, int hidden, int vocab, float eps, float* __restrict__ x32,
-                                                           half_t* __restrict__ x16) {
+                                                           int L, int hidden, int vocab, float eps, half_t* __restrict__ x16) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= m_packed[0]) return;
@@ -453,21 +688,20 @@ __global__ __launch_bounds__(256) void ce_embed_ln_kernel(const int32_t* __restr
         const int c = lane + i * 64;
         v[i] = word[(size_t)id * hidden + c] + type[(size_t)ty * hidden + c] + pos[(size_t)p * hidden + c];
     }
-    wave_layernorm<PER>(v, g, b, hidden, eps, lane, x32 + row * hidden, x16 + row * 2 * hidden);
+    wave_layernorm<PER>(v, g, b, hidden, eps, lane, x16 + row * 2 * hidden);
 }
 
 template <int PER>
 __global__ __launch_bounds__(256) void ce_layernorm_kernel(const float* __restrict__ y32, const float* __restrict__ g,
                                                             const float* __restrict__ b, const int32_t* __restrict__ m_packed,
-                                                            int hidden, float eps, float* __restrict__ x32,
-                                                            half_t* __restrict__ x16) {
+                                                            int hidden, float eps, half_t* __restrict__ x16) {
     const int lane = threadIdx.x & 63;
     const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= m_packed[0]) return;
     float v[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) v[i] = y32[tok * hidden + lane + i * 64];
-    wave_layernorm<PER>(v, g, b, hidden, eps, lane, x32 + tok * hidden, x16 + tok * 2 * hidden);
+    wave_layernorm<PER>(v, g, b, hidden, eps, lane, x16 + tok * 2 * hidden);
 }
 
 // ---- attention: d_head must be 32. One block per (head, pair); every wave owns QB consecutive 16-query blocks.
@@ -613,15 +847,15 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
     }
 }
 
-__global__ __launch_bounds__(256) void ce_pool_classify_kernel(const float* __restrict__ x32, const float* __restrict__ wp,
+__global__ __launch_bounds__(256) void ce_pool_classify_kernel(const half_t* __restrict__ x16, const float* __restrict__ wp,
                                                                 const float* __restrict__ bp, const float* __restrict__ wc,
                                                                 const float* __restrict__ bc, const int32_t* __restrict__ pair_off,
                                                                 int hidden, float* __restrict__ logits) {
     __shared__ float xs[1024];
     __shared__ float part[4];
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const float* x = x32 + (size_t)pair_off[pair] * hidden;     // [CLS] = the pair's first packed row
-    for (int i = tid; i < hidden; i += 256) xs[i] = x[i];
+    const half_t* x = x16 + (size_t)pair_off[pair] * 2 * hidden;     // [CLS] = the pair's first packed row (split layout)
+    for (int i = tid; i < hidden; i += 256) xs[i] = (float)x[SPLIT_IDX(i)] + (float)x[SPLIT_IDX(i) + 32];
     __syncthreads();
     float acc = 0.f;
     for (int n = tid; n < hidden; n += 256) {
@@ -651,9 +885,9 @@ __global__ void ce_f32_split_kernel(const float* __restrict__ in, half_t* __rest
 
 // ------------------------------------------------------------------------------------------------
 static void ce_free_ws(rag_ce_model* m) {
-    hipFree(m->x32); hipFree(m->y32); hipFree(m->x16); hipFree(m->q16); hipFree(m->kf16); hipFree(m->vf16); hipFree(m->ctx16);
+    hipFree(m->y32); hipFree(m->x16); hipFree(m->q16); hipFree(m->kf16); hipFree(m->vf16); hipFree(m->ctx16);
     hipFree(m->h16); hipFree(m->ids); hipFree(m->tt); hipFree(m->lens); hipFree(m->logits); hipFree(m->pair_off); hipFree(m->row_pair); hipFree(m->m_packed); hipFree(m->sid); hipFree(m->stt);
-    m->x32 = m->y32 = nullptr; m->x16 = m->q16 = m->kf16 = m->vf16 = m->ctx16 = m->h16 = nullptr;
+    m->y32 = nullptr; m->x16 = m->q16 = m->kf16 = m->vf16 = m->ctx16 = m->h16 = nullptr;
     m->ids = m->tt = m->lens = nullptr; m->logits = nullptr;
     m->pair_off = m->row_pair = m->m_packed = nullptr;
     m->sid = m->stt = nullptr;
@@ -765,7 +999,7 @@ static int launch_attention(rag_ctx* h, rag_ce_model* m, int P, int L, const ce_
 template <int PER>
 static void launch_ln(rag_ce_model* m, const float* y, const float* g, const float* b, int64_t M, hipStream_t st) {
     hipLaunchKernelGGL(ce_layernorm_kernel<PER>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, y, g, b, m->m_packed, m->cfg.hidden,
-                       (float)m->cfg.ln_eps, m->x32, m->x16);
+                       (float)m->cfg.ln_eps, m->x16);
 }
 
 static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t st) {
@@ -794,6 +1028,22 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
         case 2: hipLaunchKernelGGL((ce_gemm_kernel<E, 2>), dim3(n_cu), blk, lds, st, __VA_ARGS__); break;        \
         default: hipLaunchKernelGGL((ce_gemm_kernel<E, 3>), dim3(n_cu), blk, lds, st, __VA_ARGS__); break;       \
     }
+ // bias + residual + LayerNorm in the GEMM epilogue when the geometry allows (hidden = 384, K a multiple of 192: the
+    // MiniLM-L-6 shape); RAG_CE_NO_FUSED_LN=1 forces the stand-alone path (parity test of both)
+    const bool fused_ln = H == 384 && F % 192 == 0 && !getenv("RAG_CE_NO_FUSED_LN");
+    if (!fused_ln && !m->y32) HIP_TRY(h, hipMalloc(&m->y32, (size_t)Mp * H * 4));
+    if (fused_ln && !h->attr_ce_gemm_ln) {
+#define CE_ATTR_LN(T) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_ln_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LNG_LDS));
+        CE_ATTR_LN(0) CE_ATTR_LN(1) CE_ATTR_LN(2) CE_ATTR_LN(3)
+        h->attr_ce_gemm_ln = true;
+    }
+#define CE_GEMM_LN(T, ...)                                                                                        \
+    switch (T) {                                                                                                  \
+        case 0: hipLaunchKernelGGL((ce_gemm_ln_kernel<0>), dim3(n_cu), blk, LNG_LDS, st, __VA_ARGS__); break;    \
+        case 1: hipLaunchKernelGGL((ce_gemm_ln_kernel<1>), dim3(n_cu), blk, LNG_LDS, st, __VA_ARGS__); break;    \
+        case 2: hipLaunchKernelGGL((ce_gemm_ln_kernel<2>), dim3(n_cu), blk, LNG_LDS, st, __VA_ARGS__); break;    \
+        default: hipLaunchKernelGGL((ce_gemm_ln_kernel<3>), dim3(n_cu), blk, LNG_LDS, st, __VA_ARGS__); break;   \
+    }
 #define CE_PER_DISPATCH(CALL)                                                                 \
     switch (per) {                                                                            \
         case 2: CALL(2); break; case 4: CALL(4); break; case 6: CALL(6); break;               \
@@ -802,7 +1052,7 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     }
 #define EMB(PER) hipLaunchKernelGGL(ce_embed_ln_kernel<PER>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, m->ids, m->tt, m->word, \
                                     m->pos, m->type, m->emb_ln_g, m->emb_ln_b, m->m_packed, m->row_pair, m->pair_off, L, H,            \
-                                    m->cfg.vocab_size, eps, m->x32, m->x16)
+                                    m->cfg.vocab_size, eps, m->x16)
     // packed row layout of this chunk (no host round trip: grids cover the padded worst case, kernels stop at m_packed)
     hipLaunchKernelGGL(ce_pack_scan_kernel, dim3(1), dim3(1024), 0, st, m->lens, P, L, m->pair_off, m->m_packed);
     hipLaunchKernelGGL(ce_pack_rows_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, st, m->pair_off, P, L, Mp, m->row_pair);
@@ -813,28 +1063,36 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     for (int l = 0; l < m->cfg.layers; ++l) {
         auto& ly = m->layers[l];
         CE_GEMM(EPI_QKV, terms[0], ly.wqkv, m->x16,
-                3 * H, H, ly.bqkv, (const float*)nullptr, (float*)nullptr, m->q16, m->kf16, m->vf16, pp.kv, H,
+                3 * H, H, ly.bqkv, (const half_t*)nullptr, (float*)nullptr, m->q16, m->kf16, m->vf16, pp.kv, H,
                 m->cfg.heads, m->m_packed, m->row_pair, m->pair_off)
         {
             const int rc = L == 32 ? launch_attention<1>(h, m, P, L, pp, st) : launch_attention<2>(h, m, P, L, pp, st);
             if (rc != RAG_OK) return rc;
         }
-        CE_GEMM(EPI_RESID, terms[1], ly.wo, m->ctx16, H, H,
-                ly.bo, (const float*)m->x32, m->y32, (half_t*)nullptr, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
-                m->row_pair, m->pair_off)
 #define LN1(PER) launch_ln<PER>(m, m->y32, ly.ln1_g, ly.ln1_b, M, st)
-        CE_PER_DISPATCH(LN1)
+        if (fused_ln) {
+            CE_GEMM_LN(terms[1], ly.wo, m->ctx16, H, ly.bo, ly.ln1_g, ly.ln1_b, eps, m->x16, m->m_packed)
+        } else {
+            CE_GEMM(EPI_RESID, terms[1], ly.wo, m->ctx16, H, H,
+                    ly.bo, (const half_t*)m->x16, m->y32, (half_t*)nullptr, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
+                    m->row_pair, m->pair_off)
+            CE_PER_DISPATCH(LN1)
+        }
         CE_GEMM(EPI_GELU, terms[2], ly.w1, m->x16, F, H,
-                ly.b1, (const float*)nullptr, (float*)nullptr, m->h16, (half_t*)nullptr, (half_t*)nullptr, (size_t)0,
+                ly.b1, (const half_t*)nullptr, (float*)nullptr, m->h16, (half_t*)nullptr, (half_t*)nullptr, (size_t)0,
                 H, m->cfg.heads, m->m_packed, m->row_pair, m->pair_off)
-        CE_GEMM(EPI_RESID, terms[3], ly.w2, m->h16, H, F,
-                ly.b2, (const float*)m->x32, m->y32, (half_t*)nullptr, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
-                m->row_pair, m->pair_off)
 #define LN2(PER) launch_ln<PER>(m, m->y32, ly.ln2_g, ly.ln2_b, M, st)
-        CE_PER_DISPATCH(LN2)
+        if (fused_ln) {
+            CE_GEMM_LN(terms[3], ly.w2, m->h16, F, ly.b2, ly.ln2_g, ly.ln2_b, eps, m->x16, m->m_packed)
+        } else {
+            CE_GEMM(EPI_RESID, terms[3], ly.w2, m->h16, H, F,
+                    ly.b2, (const half_t*)m->x16, m->y32, (half_t*)nullptr, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
+                    m->row_pair, m->pair_off)
+            CE_PER_DISPATCH(LN2)
+        }
     }
     (void)nullh;
-    hipLaunchKernelGGL(ce_pool_classify_kernel, dim3(P), dim3(256), 0, st, m->x32, m->wp, m->bp, m->wc, m->bc, m->pair_off, H, m->logits);
+    hipLaunchKernelGGL(ce_pool_classify_kernel, dim3(P), dim3(256), 0, st, m->x16, m->wp, m->bp, m->wc, m->bc, m->pair_off, H, m->logits);
     HIP_TRY(h, hipGetLastError());
     return RAG_OK;
 }
@@ -847,8 +1105,6 @@ static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t s
     ce_free_ws(m);
     const int H = m->cfg.hidden;
     const int64_t Mp = round_up((int64_t)P * L, CE_BN);
-    HIP_TRY(h, hipMalloc(&m->x32, (size_t)Mp * H * 4));
-    HIP_TRY(h, hipMalloc(&m->y32, (size_t)Mp * H * 4));
     m->ws_pairs = P;                                     // planes_for() uses the allocated pair count
     const ce_planes pp = planes_for(m, Mp);
     HIP_TRY(h, hipMalloc(&m->x16, 2 * pp.x * 2));
@@ -873,7 +1129,6 @@ static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t s
     HIP_TRY(h, hipMemsetAsync(m->q16, 0, 2 * pp.q * 2, st));
     HIP_TRY(h, hipMemsetAsync(m->kf16, 0, 2 * pp.kv * 2, st));
     HIP_TRY(h, hipMemsetAsync(m->vf16, 0, 2 * pp.kv * 2, st));
-    HIP_TRY(h, hipMemsetAsync(m->x32, 0, (size_t)Mp * H * 4, st));
     m->ws_pairs = P;
     m->ws_L = L;
     m->ws_tokens = Mp;
