@@ -325,11 +325,14 @@ def hybrid_block(eng, q, N, cpu_baseline=True):
     nnz_touched = float(counts[terms[terms >= 0]].sum())
     bm_gbs = nnz_touched * 12.0 / (bm_ms / bm_spans * 1e-3) / 1e9
     p50_1 = _p50_ms(lambda: hybrid(1), 100, 10)
+    # the reference's OTHER fusion (rag/retrieval.py:294-322: weighted linear sum over every document), index-level
+    t_lin = timed(lambda: eng.hybrid_linear_dev(q[:256], ptr_d[:257], terms_d, k, 0.55, 0.35, 0.10), 3, 1)
     block = {
         "workload": f"{N} docs: dense top-{pool} + BM25(CSR, nnz={int(indptr[-1])}) top-{pool} + RRF(k=60) -> top-{k} "
                     "(BASELINE.json configs[2]); one rag_hybrid_rrf_dev call per batch, everything resident in HBM",
         "value": round(Q / t_1024, 1), "unit": "queries/sec", "batch_queries": Q, "ms_per_batch": round(t_1024 * 1e3, 3),
         "queries_per_sec_batch256": round(256 / t_256, 1), "p50_single_query_latency_ms": round(p50_1, 4),
+        "linear_fusion_queries_per_sec_batch256": round(256 / t_lin, 1),
         "roofline": {"bound": "hbm", "kernel": "bm25_range_kernel + bm25_merge_stage_kernel (BM25 top-100 of one batch)",
                      "achieved": round(bm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(bm_gbs / PEAK_HBM_GBS, 4),
                      "traffic": None, "avg_call_ms": round(bm_ms / bm_spans, 4),

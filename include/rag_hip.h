@@ -203,6 +203,22 @@ int rag_linear_fuse_topk_host(rag_handle_t h, const double* semantic_host, const
                               const double* temporal_host /*NULL = zeros*/, int n, double alpha, double beta,
                               double gamma, int top_k, int32_t* idx_out_host, double* hybrid_out_host);
 
+/* Index-level linear fusion (SURVEY.md section 8b `rag_hybrid_linear`): HybridRetriever.hybrid_search
+ * (rag/retrieval.py:214-322) with the WHOLE resident index as its corpus. Per query and row:
+ *   hybrid = (alpha * cosine + beta * keyword) + gamma * temporal      (:302, CPython's operation order, float64)
+ * keyword = BM25Okapi score / max over all documents (1.0 when that max is <= 0, :343-345); temporal = the per-row vector
+ * of rag_index_set_temporal_host (RECENCY_WEIGHT * 0.5 ** (days_old / half_life), computed by the host as :266-292 does;
+ * NULL = zeros). Result: stable sort descending (lower row first on ties), first k; rows_out are index rows, ids_out doc
+ * ids, hybrid_out the float64 hybrid scores; semantic / keyword / temporal_out (each [Q*k], may be NULL) are the
+ * components the reference returns next to them. alpha must be > 0; tenant as in rag_dense_topk_dev. The postings must be
+ * row-aligned with the index. Exact by the same construction as the dense search: the fp16 MFMA pass only discards rows
+ * whose FUSED score is provably below the k-th best, survivors are rescored in float64. */
+int rag_index_set_temporal_host(rag_handle_t h, const double* temporal_host, int64_t n_rows);
+int rag_hybrid_linear_dev(rag_handle_t h, const float* q_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev,
+                          int n_queries, int k, double alpha, double beta, double gamma, int tenant,
+                          int64_t* ids_out_dev, int32_t* rows_out_dev, double* hybrid_out_dev, double* semantic_out_dev,
+                          double* keyword_out_dev, double* temporal_out_dev, void* stream);
+
 /* ---- cross-encoder (BertForSequenceClassification, ms-marco-MiniLM-L-6-v2 shape): replaces
  *      CrossEncoder.predict (rag/reranker.py:355). Weights are handed over as float32 host arrays in the
  *      HF state-dict layout (nn.Linear [out,in]); see optimized-rag_amd/cross_encoder.py for the order. */

@@ -75,6 +75,9 @@ _SIGS = {
     "rag_rrf_fuse_dev": ([_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
     "rag_bm25_topk_dev": ([_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P], C.c_int),
     "rag_hybrid_rrf_dev": ([_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P], C.c_int),
+    "rag_index_set_temporal_host": ([_P, _P, C.c_int64], C.c_int),
+    "rag_hybrid_linear_dev": ([_P, _P, _P, _P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _P, _P, _P, _P, _P, _P,
+                               _P], C.c_int),
     "rag_linear_fuse_topk_host": ([_P, _P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _P, _P], C.c_int),
     "rag_ce_load_host": ([_P, C.POINTER(CeConfig), C.POINTER(_P), C.c_int], C.c_int),
     "rag_ce_score_host": ([_P, _P, _P, _P, C.c_int, C.c_int, _P], C.c_int),
@@ -435,6 +438,32 @@ class RagEngine:
                                                 C.c_void_p(keys.data_ptr()), C.c_void_p(rrf.data_ptr()),
                                                 C.c_void_p(ranks.data_ptr()), st), "rag_hybrid_rrf_dev")
         return keys, rrf, ranks
+
+    def set_temporal(self, temporal):
+        """Per-row temporal scores (float64 [n_rows], e.g. shard_format.temporal_scores) for hybrid_linear_dev; None clears."""
+        t = None if temporal is None else _np(temporal, np.float64)
+        self._check(self.lib.rag_index_set_temporal_host(self.h, _ptr(t), 0 if t is None else t.shape[0]), "rag_index_set_temporal_host")
+
+    def hybrid_linear_dev(self, q, term_ptr, terms, k, alpha, beta, gamma, tenant=-1, stream=None):
+        """hybrid_search over the whole resident index (CUDA tensors in): returns dict of CUDA tensors ids [Q,k] int64, rows
+        [Q,k] int32, hybrid / semantic / keyword / temporal [Q,k] float64."""
+        import torch
+        Q, dev = q.shape[0], q.device
+        key = ("lin", Q, k)
+        if getattr(self, "_lin_key", None) != key:
+            f64 = torch.float64
+            self._lin = dict(ids=torch.empty((Q, k), dtype=torch.int64, device=dev), rows=torch.empty((Q, k), dtype=torch.int32, device=dev),
+                             hybrid=torch.empty((Q, k), dtype=f64, device=dev), semantic=torch.empty((Q, k), dtype=f64, device=dev),
+                             keyword=torch.empty((Q, k), dtype=f64, device=dev), temporal=torch.empty((Q, k), dtype=f64, device=dev))
+            self._lin_key = key
+        o = self._lin
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        self._check(self.lib.rag_hybrid_linear_dev(
+            self.h, C.c_void_p(q.data_ptr()), C.c_void_p(term_ptr.data_ptr()), C.c_void_p(terms.data_ptr()), Q, int(k), float(alpha),
+            float(beta), float(gamma), int(tenant), C.c_void_p(o["ids"].data_ptr()), C.c_void_p(o["rows"].data_ptr()),
+            C.c_void_p(o["hybrid"].data_ptr()), C.c_void_p(o["semantic"].data_ptr()), C.c_void_p(o["keyword"].data_ptr()),
+            C.c_void_p(o["temporal"].data_ptr()), st), "rag_hybrid_linear_dev")
+        return o
 
     def bm25_scores(self, term_ptr, terms):
         term_ptr = _np(term_ptr, np.int32)

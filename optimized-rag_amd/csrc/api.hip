@@ -18,6 +18,7 @@ int bm25_scores_adhoc_host(rag_ctx* h, const int64_t* indptr, const int32_t* doc
                            const double* idf, int64_t n_docs, int64_t n_terms, double avgdl, double k1, double b,
                            const int32_t* term_ptr, const int32_t* terms, int Q, double* out);
 int64_t bm25_n_docs(const rag_ctx* h);
+int bm25_scores_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, double* out_dev, hipStream_t st);
 int bm25_scores_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, double* out);
 int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int tenant, int64_t* ids_dev,
                   int32_t* rows_dev, double* scores_dev, double* raw_max_dev, hipStream_t st);
@@ -93,6 +94,7 @@ int rag_destroy(rag_handle_t h) {
     pipeline_free(h);
     hipFree(h->q32); hipFree(h->q16); hipFree(h->cand); hipFree(h->cnt); hipFree(h->tau); hipFree(h->bound);
     hipFree(h->n_sorted); hipFree(h->exact); hipFree(h->flag); hipFree(h->stats); hipFree(h->stage);
+    hipFree(h->temporal); hipFree(h->lin_ws);
     hipFree(h->q16b); hipFree(h->candb); hipFree(h->cntb); hipFree(h->taub); hipFree(h->boundb); hipFree(h->n_sortedb); hipFree(h->ovf_list);
     for (auto& p : h->prof)
         for (auto& e : p.ev) {
@@ -435,6 +437,72 @@ int rag_hybrid_rrf_dev(rag_handle_t h, const float* q_dev, const int32_t* term_p
     rc = bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, tenant, lists_ws_dev + (size_t)Q * pool, nullptr, scores_ws_dev, nullptr, st);
     if (rc) return rc;
     return rrf_fuse_dev(h, lists_ws_dev, Q, 2, pool, (int64_t)Q * pool, pool, rrf_k, k, keys_out_dev, rrf_out_dev, ranks_out_dev, st);
+}
+
+// Per-row temporal score of the linear fusion: RECENCY_WEIGHT * 0.5 ** (days_old / half_life) computed by the host from
+// created_at / uploaded_at exactly as rag/retrieval.py:266-292 does (shard_format.temporal_scores). NULL clears it (zeros).
+int rag_index_set_temporal_host(rag_handle_t h, const double* temporal, int64_t n_rows) {
+    if (!h) return RAG_ERR_ARG;
+    LOCK(h);
+    ARG_CHECK(h, temporal == nullptr || n_rows == h->n_rows, "temporal array length must equal the index row count");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipFree(h->temporal);
+    h->temporal = nullptr;
+    if (temporal == nullptr || n_rows == 0) return RAG_OK;
+    HIP_TRY(h, hipMalloc(&h->temporal, (size_t)n_rows * sizeof(double)));
+    HIP_TRY(h, hipMemcpy(h->temporal, temporal, (size_t)n_rows * sizeof(double), hipMemcpyHostToDevice));
+    return RAG_OK;
+}
+
+// HybridRetriever.hybrid_search (rag/retrieval.py:214-322) over the WHOLE resident index instead of a host-side corpus list:
+// per query, hybrid = (alpha * cosine + beta * keyword) + gamma * temporal for every row (keyword = BM25Okapi score / max over
+// the corpus, 1.0 when that max is <= 0; temporal from rag_index_set_temporal_host), stable sort descending, first k.
+// The weights are the caller's (intent table or constructor defaults, :232-238). Queries are processed 256 at a time: the
+// all-document BM25 scores of a sub-batch (float64, 2 GB at 1M rows) and their float32 emission bias stay in a workspace.
+int rag_hybrid_linear_dev(rag_handle_t h, const float* q_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k,
+                          double alpha, double beta, double gamma, int tenant, int64_t* ids_out_dev, int32_t* rows_out_dev,
+                          double* hybrid_out_dev, double* semantic_out_dev, double* keyword_out_dev, double* temporal_out_dev,
+                          void* stream) {
+    if (!h) return RAG_ERR_ARG;
+    LOCK(h);
+    ARG_CHECK(h, q_dev && term_ptr_dev && ids_out_dev && rows_out_dev && hybrid_out_dev, "hybrid_linear: null pointer");
+    ARG_CHECK(h, Q > 0 && k > 0 && k <= RAG_MAX_K, "hybrid_linear: need Q > 0 and 0 < k <= 256");
+    ARG_CHECK(h, alpha > 0.0, "hybrid_linear: alpha must be positive (the cosine drives the candidate search)");
+    ARG_CHECK(h, bm25_n_docs(h) == h->n_rows && h->n_rows > 0, "hybrid_linear: needs BM25 postings row-aligned with a non-empty index");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = h->n_rows, ld = h->n_rows_pad;
+    const int QB = 256;
+    const size_t need = stage_size((size_t)QB * n, 8) + stage_size((size_t)QB * ld, 4) + stage_size(QB, 8);
+    if (need > h->lin_ws_bytes) {
+        hipFree(h->lin_ws);
+        h->lin_ws = nullptr;
+        h->lin_ws_bytes = 0;
+        HIP_TRY(h, hipMalloc(&h->lin_ws, need));
+        h->lin_ws_bytes = need;
+    }
+    char* p = (char*)h->lin_ws;
+    double* raw = stage_take<double>(p, (size_t)QB * n);
+    float* bias = stage_take<float>(p, (size_t)QB * ld);
+    double* mx = stage_take<double>(p, QB);
+    for (int q0 = 0; q0 < Q; q0 += QB) {
+        const int qc = std::min(QB, Q - q0);
+        int rc = bm25_scores_dev(h, term_ptr_dev + q0, terms_dev, qc, raw, st);
+        if (rc) return rc;
+        if ((rc = linear_prepare(h, raw, qc, n, h->temporal, beta, gamma, mx, bias, ld, st))) return rc;
+        const dense_fused fz = {bias, ld, raw, n, mx, h->temporal, alpha, beta, gamma};
+        rc = dense_search_fused(h, q_dev + (size_t)q0 * h->dim, qc, k, tenant, ids_out_dev + (size_t)q0 * k, rows_out_dev + (size_t)q0 * k,
+                                hybrid_out_dev + (size_t)q0 * k, st, &fz);
+        if (rc) return rc;
+        if (semantic_out_dev || keyword_out_dev || temporal_out_dev) {
+            rc = linear_components(h, q_dev + (size_t)q0 * h->dim, rows_out_dev + (size_t)q0 * k, qc, k, &fz,
+                                   semantic_out_dev ? semantic_out_dev + (size_t)q0 * k : nullptr,
+                                   keyword_out_dev ? keyword_out_dev + (size_t)q0 * k : nullptr,
+                                   temporal_out_dev ? temporal_out_dev + (size_t)q0 * k : nullptr, st);
+            if (rc) return rc;
+        }
+    }
+    return RAG_OK;
 }
 
 int rag_bm25_set_normalize(rag_handle_t h, int on) {

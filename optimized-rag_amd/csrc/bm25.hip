@@ -720,6 +720,21 @@ int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_
     return prof_end(h, 1, st);
 }
 
+// raw float64 scores of EVERY document for Q queries, device pointers, asynchronous: out_dev[Q][n_docs]
+// (the all-document BM25Okapi.get_scores of rag/retrieval.py:340-341, for the index-level linear fusion)
+int bm25_scores_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, double* out_dev, hipStream_t st) {
+    ARG_CHECK(h, h->bm25 != nullptr, "no BM25 index loaded");
+    ARG_CHECK(h, Q > 0 && Q <= 65535 && term_ptr_dev && out_dev, "bm25_scores_dev: bad arguments");
+    rag_bm25_index* ix = h->bm25;
+    const int rc = bm25_set_attr(h);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bm25_range_kernel, dim3(ix->n_ranges, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc, ix->w, ix->idf,
+                       ix->range_off, ix->n_ranges, term_ptr_dev, terms_dev, ix->n_docs, ix->n_terms, 1, 1, out_dev, (uint64_t*)nullptr,
+                       (uint32_t*)nullptr, 0, (const uint64_t*)nullptr, (int*)nullptr, (const int32_t*)nullptr, -1);
+    HIP_TRY(h, hipGetLastError());
+    return RAG_OK;
+}
+
 int bm25_set_normalize(rag_ctx* h, int on) {
     ARG_CHECK(h, h->bm25 != nullptr, "no BM25 index loaded");
     h->bm25->normalize = on ? 1 : 0;

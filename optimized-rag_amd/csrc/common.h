@@ -42,6 +42,9 @@ struct rag_ctx {
     half_t* emb16 = nullptr;     // [n_rows_pad][dim_pad] fp16 (2^7 * unit rows), zero padded
     int64_t* ids = nullptr;      // [n_rows] or null
     int32_t* tenants = nullptr;  // [n_rows] or null
+    double* temporal = nullptr;                                        // [n_rows] per-row temporal score (linear fusion) or null
+    void* lin_ws = nullptr;                                            // rag_hybrid_linear_dev: raw BM25 + bias + max of one sub-batch
+    size_t lin_ws_bytes = 0;
     int32_t* tenant_tiles = nullptr;                                   // concatenated per-tenant lists of 256-row tiles
     std::unordered_map<int32_t, std::pair<int64_t, int>> tenant_span;  // tenant -> (offset, count) into tenant_tiles
     int64_t tenant_rows = 0;                                           // row count the tenant table was built for
@@ -88,8 +91,8 @@ struct rag_ctx {
     double last_eps = 0;
 
     rag_bm25_index* bm25 = nullptr;
-    // passage token store (pipeline.hip): [tok_rows][tok_L] int32 + lengths, row-aligned with the index
-    int32_t* tok = nullptr;
+    // passage token store (pipeline.hip): [tok_rows][tok_L] uint16 WordPiece ids + lengths, row-aligned with the index
+    uint16_t* tok = nullptr;
     int32_t* tok_len = nullptr;
     int64_t tok_rows = 0;
     int tok_L = 0;
@@ -187,6 +190,20 @@ int dense_index_build(rag_ctx* h, const float* emb_dev, int64_t n_rows, hipStrea
 int dense_index_normalize_range(rag_ctx* h, int64_t first_row, int64_t n_rows, hipStream_t st);
 int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev,
                  double* scores_dev, hipStream_t st);
+// linear fusion inputs of one query sub-batch (rag_hybrid_linear_dev): float32 emission bias [Q][bias_ld], float64 raw BM25
+// scores [Q][n] with their per-query divisor, per-row temporal scores (or null), the three weights
+struct dense_fused {
+    const float* bias; int64_t bias_ld;
+    const double* raw; int64_t n;
+    const double* mx; const double* temporal;
+    double alpha, beta, gamma;
+};
+int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev,
+                       double* scores_dev, hipStream_t st, const dense_fused* fz);
+int linear_prepare(rag_ctx* h, const double* raw, int Q, int64_t n, const double* temporal, double beta, double gamma, double* mx,
+                   float* bias, int64_t ld, hipStream_t st);
+int linear_components(rag_ctx* h, const float* q_dev, const int32_t* rows_dev, int Q, int k, const dense_fused* fz, double* sem_out,
+                      double* kw_out, double* tmp_out, hipStream_t st);
 int dense_free(rag_ctx* h);
 int dense_build_tenant_tiles(rag_ctx* h, const int32_t* tenants_host, int64_t n_rows);
 int merge_topk(rag_ctx* h, const int64_t* ids, const double* scores, int n_lists, int64_t list_stride, int Q, int k,

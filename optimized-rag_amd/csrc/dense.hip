@@ -179,16 +179,21 @@ __device__ __forceinline__ void load_fragB(FragB& f, const char* base, const int
 // half-tile slots): A(t+3) issued in IB(t), B(t+2) in IA(t); the per-step wait is vmcnt(10) = {A(t+2), B(t+2), A(t+3)}
 // may still be in flight, A(t+1) and B(t+1) (both older in issue order) have landed. 64-96 KiB of corpus per CU in
 // flight instead of 32-64 KiB.
-template <bool DENSE0, bool SMALLQ>
+// FUSED (rag_hybrid_linear_dev): the score that is thresholded and keyed is the weighted LINEAR fusion
+// alpha * cosine + bias[q][row], bias = beta * bm25_normalised + gamma * temporal precomputed per (query, row) in float32
+// (rag/retrieval.py:302); everything downstream (select, float64 rescoring, ranking) is unchanged.
+template <bool DENSE0, bool SMALLQ, bool FUSED = false>
 __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restrict__ corpus16, const half_t* __restrict__ q16,
                                                           int Dp, int rtile_begin, int n_rtiles, int n_qtiles,
                                                           int n_rows_valid, int q_valid, const float* __restrict__ tau,
                                                           unsigned* __restrict__ cnt, uint64_t* __restrict__ cand,
                                                           const int32_t* __restrict__ tenants, int tenant,
                                                           const int32_t* __restrict__ tile_list, int tile_mul, int tile_mod,
-                                                          const int* __restrict__ active_count
+                                                          const int* __restrict__ active_count,
+                                                          const float* __restrict__ bias = nullptr, int64_t bias_ld = 0,
+                                                          float alpha = 1.0f, const int* __restrict__ qmap = nullptr
 #ifdef DENSE_STAMP
-                                                          , unsigned long long* __restrict__ stamp_out
+                                                          , unsigned long long* __restrict__ stamp_out = nullptr
 #endif
 ) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -299,6 +304,24 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
 
     // ---- epilogue: C layout col = lane&15 (query), row = (lane>>4)*4 + reg (corpus row) ----------
     const float scale = 1.0f / (float)(1 << (2 * RAG_SCALE_LOG2));
+    if (FUSED) {
+        // accumulators -> fused score, kept in the accumulators' 2^14 scale so that the threshold / key code below is shared:
+        // acc' = acc * alpha + bias * 2^14. Each (query, row) bias element is read exactly once per pass (float4 per 4 rows).
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + wn * 64 + j * 16 + fr;
+            if (q >= q_valid) continue;
+            const float* brow = bias + (size_t)(qmap != nullptr ? qmap[q] : q) * bias_ld + row0 + wm * 128 + fq * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 b = *reinterpret_cast<const float4*>(brow + i * 16);
+                acc[i][j][0] = fmaf(acc[i][j][0], alpha, b.x * (float)(1 << (2 * RAG_SCALE_LOG2)));
+                acc[i][j][1] = fmaf(acc[i][j][1], alpha, b.y * (float)(1 << (2 * RAG_SCALE_LOG2)));
+                acc[i][j][2] = fmaf(acc[i][j][2], alpha, b.z * (float)(1 << (2 * RAG_SCALE_LOG2)));
+                acc[i][j][3] = fmaf(acc[i][j][3], alpha, b.w * (float)(1 << (2 * RAG_SCALE_LOG2)));
+            }
+        }
+    }
     if (DENSE0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -642,7 +665,9 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const float* __restrict
                                                           const int32_t* __restrict__ tenants, int tenant, int64_t n_rows,
                                                           int64_t rows_per_block, int dim, int k, const int* __restrict__ list,
                                                           const int* __restrict__ count, int f0, uint64_t* __restrict__ part_key,
-                                                          uint32_t* __restrict__ part_row) {
+                                                          uint32_t* __restrict__ part_row, const double* __restrict__ raw,
+                                                          int64_t raw_ld, const double* __restrict__ raw_mx,
+                                                          const double* __restrict__ temporal, double fa, double fb, double fg) {
     __shared__ uint64_t sk[SCAN_CHUNK];
     __shared__ uint32_t sr[SCAN_CHUNK];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -658,7 +683,9 @@ __global__ __launch_bounds__(256) void scan_chunk_kernel(const float* __restrict
                 const int64_t row = w0 + i;
                 uint64_t key = 0ull;          // 0 = empty (below every real score: orderable(-inf) > 0)
                 if (row < base_end && (tenants == nullptr || tenants[row] == tenant)) {
-                    const double v = exact_cosine_wave(q32 + (size_t)q * dim, emb32 + (size_t)row * dim, dim, lane);
+                    double v = exact_cosine_wave(q32 + (size_t)q * dim, emb32 + (size_t)row * dim, dim, lane);
+                    if (raw != nullptr)               // linear fusion (rag/retrieval.py:302), same operation order as linear_fuse_kernel
+                        v = (fa * v + fb * (raw[(size_t)q * raw_ld + row] / raw_mx[q])) + fg * (temporal ? temporal[row] : 0.0);
                     key = f64_orderable(v);
                 }
                 if (lane == 0) {
@@ -758,6 +785,78 @@ __global__ __launch_bounds__(256) void overflow_scatter_kernel(const int* __rest
         n_sorted[q] = m;
         bound[q] = -INFINITY;
         atomicAdd(&stats[5], 1);
+    }
+}
+
+// ---- linear fusion over the resident index (rag_hybrid_linear_dev) -------------------------------------------------------
+// rag/retrieval.py:294-322 evaluated over ALL rows: hybrid = (alpha * cosine + beta * keyword) + gamma * temporal, keyword =
+// raw BM25 / max over the corpus (1.0 when that max is <= 0), stable sort descending, [:top_k].
+// raw[Q][N] are the float64 BM25 scores of every document (bm25_range_kernel, mode 1).
+__global__ __launch_bounds__(256) void linear_max_kernel(const double* __restrict__ raw, int64_t n, double* __restrict__ mx) {
+    __shared__ double part[4];
+    const double* r = raw + (size_t)blockIdx.x * n;
+    double m = -INFINITY;
+    for (int64_t i = threadIdx.x; i < n; i += 256) m = fmax(m, r[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmax(fmax(part[0], part[1]), fmax(part[2], part[3]));
+        mx[blockIdx.x] = m > 0.0 ? m : 1.0;                       // `max_score if max_score > 0 else 1.0`, retrieval.py:343-344
+    }
+}
+
+// float32 emission bias of every (query, row): beta * keyword + gamma * temporal (the float64 values are recomputed exactly
+// for the survivors; the float32 rounding is covered by the emission margin)
+__global__ __launch_bounds__(256) void linear_bias_kernel(const double* __restrict__ raw, const double* __restrict__ mx,
+                                                           const double* __restrict__ temporal, int64_t n, int64_t ld, double beta,
+                                                           double gamma, float* __restrict__ bias) {
+    const int q = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ld) return;
+    float b = 0.f;
+    if (i < n) b = (float)(beta * (raw[(size_t)q * n + i] / mx[q]) + gamma * (temporal ? temporal[i] : 0.0));
+    bias[(size_t)q * ld + i] = b;
+}
+
+// survivors: exact[q][j] holds the float64 cosine (rescore_kernel) -> the float64 hybrid score, CPython's operation order
+__global__ __launch_bounds__(256) void linear_fuse_kernel(const uint64_t* __restrict__ cand, const int* __restrict__ n_sorted,
+                                                           double* __restrict__ exact, const double* __restrict__ raw, int64_t n,
+                                                           const double* __restrict__ mx, const double* __restrict__ temporal,
+                                                           double alpha, double beta, double gamma) {
+    const int q = blockIdx.y;
+    const int m = n_sorted[q];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < m; j += gridDim.x * 256) {
+        const uint32_t row = key_row(cand[(size_t)q * RAG_CAND_CAP + j]);
+        const double sem = exact[(size_t)q * RAG_CAND_CAP + j];
+        const double kw = raw[(size_t)q * n + row] / mx[q];
+        exact[(size_t)q * RAG_CAND_CAP + j] = (alpha * sem + beta * kw) + gamma * (temporal ? temporal[row] : 0.0);
+    }
+}
+
+// the three components of the returned rows (semantic_score, keyword_score, temporal_score of the reference's result dicts)
+__global__ __launch_bounds__(256) void linear_components_kernel(const float* __restrict__ q32, const float* __restrict__ emb32,
+                                                                 const int32_t* __restrict__ rows, int Q, int k, int dim,
+                                                                 const double* __restrict__ raw, int64_t n,
+                                                                 const double* __restrict__ mx, const double* __restrict__ temporal,
+                                                                 double* __restrict__ sem_out, double* __restrict__ kw_out,
+                                                                 double* __restrict__ tmp_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= (int64_t)Q * k) return;
+    const int q = (int)(e / k);
+    const int32_t row = rows[e];
+    double sem = 0.0, kw = 0.0, t = 0.0;
+    if (row >= 0) {
+        sem = exact_cosine_wave(q32 + (size_t)q * dim, emb32 + (size_t)row * dim, dim, lane);
+        kw = raw[(size_t)q * n + row] / mx[q];
+        t = temporal ? temporal[row] : 0.0;
+    }
+    if (lane == 0) {
+        if (sem_out) sem_out[e] = sem;
+        if (kw_out) kw_out[e] = kw;
+        if (tmp_out) tmp_out[e] = t;
     }
 }
 
@@ -895,14 +994,25 @@ static double fp16_pass_eps(int dim_pad) {
 
 int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev,
                  double* scores_dev, hipStream_t st) {
+    return dense_search_fused(h, q_dev, Q, k, tenant, ids_dev, rows_dev, scores_dev, st, nullptr);
+}
+
+// fz == nullptr: plain cosine top-k. Otherwise the linear fusion of rag_hybrid_linear_dev: the emitted / keyed / ranked score
+// is alpha * cosine + beta * keyword + gamma * temporal (fz carries the per-(query,row) bias and the float64 inputs).
+int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev,
+                       double* scores_dev, hipStream_t st, const dense_fused* fz) {
     ARG_CHECK(h, h->emb16 != nullptr, "no index loaded");
     ARG_CHECK(h, Q > 0 && k > 0 && k <= RAG_MAX_K, "need Q>0 and 0<k<=256");
     ARG_CHECK(h, tenant < 0 || h->tenants != nullptr, "tenant filter requested but no tenants loaded");
     int rc = ensure_workspace(h, Q, st);
     if (rc) return rc;
     const int32_t* tenants = tenant >= 0 ? h->tenants : nullptr;
-    const double eps = fp16_pass_eps(h->dim_pad);
+    // fused: |alpha| * (fp16-pass error of the cosine) + float32 rounding of the bias and of the fma (values are O(1))
+    const double eps = fz ? fabs(fz->alpha) * fp16_pass_eps(h->dim_pad) + 4e-7 : fp16_pass_eps(h->dim_pad);
     const float two_eps = (float)(2.0 * eps * 1.0001 + 1e-7);        // float subtraction in the select kernel: round up
+    const float* bias = fz ? fz->bias : nullptr;
+    const int64_t bias_ld = fz ? fz->bias_ld : 0;
+    const float alpha_f = fz ? (float)fz->alpha : 1.0f;
     const int qpad = (int)round_up(Q, RAG_TILE);
     const int n_qtiles = qpad / RAG_TILE;
     float* tau = h->tau;
@@ -924,6 +1034,10 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES_SMALLQ));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<true, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<false, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wide_kernel),
@@ -966,18 +1080,25 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
             const int prc = prof_begin(h, 0, st);
             if (prc) return prc;
         }
-        if (stage == 0)
-            hipLaunchKernelGGL((dense_emit_kernel<true, false>), dim3(grid), dim3(512), DENSE_LDS_BYTES, st, h->emb16, h->q16,
-                               h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant,
-                               tile_list, tile_mul, tile_mod, (const int*)nullptr STAMP_ARG);
+#define EMIT_ARGS(QP, NQT, QV, TAU, CNT, CAND, ACT, QMAP)                                                        \
+    h->emb16, QP, h->dim_pad, begin_, n_rt_, NQT, (int)h->n_rows, QV, TAU, CNT, CAND, tenants, tenant, tile_list, tile_mul, tile_mod, \
+        (const int*)(ACT), bias, bias_ld, alpha_f, (const int*)(QMAP) STAMP_ARG
+        const int begin_ = begin, n_rt_ = n_rt;
+        if (stage == 0 && fz)
+            hipLaunchKernelGGL((dense_emit_kernel<true, false, true>), dim3(grid), dim3(512), DENSE_LDS_BYTES, st,
+                               EMIT_ARGS(h->q16, n_qtiles, Q, tau, h->cnt, h->cand, nullptr, nullptr));
+        else if (fz)
+            hipLaunchKernelGGL((dense_emit_kernel<false, false, true>), dim3(grid), dim3(512), DENSE_LDS_BYTES, st,
+                               EMIT_ARGS(h->q16, n_qtiles, Q, tau, h->cnt, h->cand, nullptr, nullptr));
+        else if (stage == 0)
+            hipLaunchKernelGGL((dense_emit_kernel<true, false>), dim3(grid), dim3(512), DENSE_LDS_BYTES, st,
+                               EMIT_ARGS(h->q16, n_qtiles, Q, tau, h->cnt, h->cand, nullptr, nullptr));
         else if (smallq)
-            hipLaunchKernelGGL((dense_emit_kernel<false, true>), dim3(grid), dim3(512), DENSE_LDS_BYTES_SMALLQ, st, h->emb16, h->q16,
-                               h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant,
-                               tile_list, tile_mul, tile_mod, (const int*)nullptr STAMP_ARG);
+            hipLaunchKernelGGL((dense_emit_kernel<false, true>), dim3(grid), dim3(512), DENSE_LDS_BYTES_SMALLQ, st,
+                               EMIT_ARGS(h->q16, n_qtiles, Q, tau, h->cnt, h->cand, nullptr, nullptr));
         else
-            hipLaunchKernelGGL((dense_emit_kernel<false, false>), dim3(grid), dim3(512), DENSE_LDS_BYTES, st, h->emb16, h->q16,
-                               h->dim_pad, begin, n_rt, n_qtiles, (int)h->n_rows, Q, tau, h->cnt, h->cand, tenants, tenant,
-                               tile_list, tile_mul, tile_mod, (const int*)nullptr STAMP_ARG);
+            hipLaunchKernelGGL((dense_emit_kernel<false, false>), dim3(grid), dim3(512), DENSE_LDS_BYTES, st,
+                               EMIT_ARGS(h->q16, n_qtiles, Q, tau, h->cnt, h->cand, nullptr, nullptr));
         HIP_TRY(h, hipGetLastError());
         if (stage > 0) {
             const int prc = prof_end(h, 0, st);
@@ -1002,9 +1123,15 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
         hipLaunchKernelGGL(flag_list_kernel, dim3(1), dim3(256), 0, st, (const int*)nullptr, h->bound, Q, 0, RAG_TILE, h->ovf_list, ovf_count);
         hipLaunchKernelGGL(overflow_gather_kernel, dim3(RAG_TILE), dim3(256), 0, st, h->ovf_list, ovf_count, h->q16, tau, h->dim_pad,
                            h->q16b, h->taub, h->boundb, h->cntb);
-        hipLaunchKernelGGL((dense_emit_kernel<false, false>), dim3((int)round_up(total_tiles, 8)), dim3(512), DENSE_LDS_BYTES, st,
-                           h->emb16, h->q16b, h->dim_pad, 0, total_tiles, 1, (int)h->n_rows, RAG_TILE, h->taub, h->cntb, h->candb,
-                           tenants, tenant, tile_list, tile_mul, tile_mod, (const int*)ovf_count STAMP_ARG);
+        {
+            const int begin_ = 0, n_rt_ = total_tiles;
+            if (fz)
+                hipLaunchKernelGGL((dense_emit_kernel<false, false, true>), dim3((int)round_up(total_tiles, 8)), dim3(512), DENSE_LDS_BYTES,
+                                   st, EMIT_ARGS(h->q16b, 1, RAG_TILE, h->taub, h->cntb, h->candb, ovf_count, h->ovf_list));
+            else
+                hipLaunchKernelGGL((dense_emit_kernel<false, false>), dim3((int)round_up(total_tiles, 8)), dim3(512), DENSE_LDS_BYTES,
+                                   st, EMIT_ARGS(h->q16b, 1, RAG_TILE, h->taub, h->cntb, h->candb, ovf_count, nullptr));
+        }
         hipLaunchKernelGGL(select_kernel, dim3(RAG_TILE / 4), dim3(256), SELECT_LDS_BYTES, st, h->candb, h->cntb, h->taub, h->boundb,
                            h->n_sortedb, (int*)nullptr, RAG_TILE, 0, k, two_eps, 1, (const int*)ovf_count);
         hipLaunchKernelGGL(overflow_scatter_kernel, dim3(RAG_TILE), dim3(256), 0, st, h->ovf_list, ovf_count, h->candb, h->n_sortedb,
@@ -1013,6 +1140,9 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
     }
 
     hipLaunchKernelGGL(rescore_kernel, dim3(16, Q), dim3(256), 0, st, q_dev, h->emb32, h->cand, h->n_sorted, h->exact, h->dim);
+    if (fz)
+        hipLaunchKernelGGL(linear_fuse_kernel, dim3(4, Q), dim3(256), 0, st, h->cand, h->n_sorted, h->exact, fz->raw, fz->n, fz->mx,
+                           fz->temporal, fz->alpha, fz->beta, fz->gamma);
     hipLaunchKernelGGL(finalize_kernel, dim3(Q), dim3(256), 0, st, h->cand, h->n_sorted, h->exact, h->bound, h->ids, h->id_base, k,
                        force_level, ids_dev, rows_dev, scores_dev, h->flag, h->stats);
     hipLaunchKernelGGL(wide_kernel, dim3(Q), dim3(512), RAG_CAND_CAP * 12, st, h->cand, h->n_sorted, h->exact, h->ids, h->id_base, k,
@@ -1038,7 +1168,9 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
         hipLaunchKernelGGL(flag_list_kernel, dim3(1), dim3(256), 0, st, (const int*)h->flag, (const float*)nullptr, Q, 2, Q, scan_list, scan_count);
         for (int f0 = 0; f0 < Q; f0 += SCAN_ROUND) {
             hipLaunchKernelGGL(scan_chunk_kernel, dim3(n_blocks), dim3(256), 0, st, q_dev, h->emb32, tenants, tenant, h->n_rows,
-                               rows_per_block, h->dim, k, scan_list, scan_count, f0, pk, pr);
+                               rows_per_block, h->dim, k, scan_list, scan_count, f0, pk, pr, fz ? fz->raw : (const double*)nullptr,
+                               fz ? fz->n : (int64_t)0, fz ? fz->mx : (const double*)nullptr, fz ? fz->temporal : (const double*)nullptr,
+                               fz ? fz->alpha : 0.0, fz ? fz->beta : 0.0, fz ? fz->gamma : 0.0);
             hipLaunchKernelGGL(scan_merge_kernel, dim3(std::min(Q - f0, SCAN_ROUND)), dim3(256), 0, st, pk, pr, n_blocks, k, h->ids,
                                h->id_base, scan_list, scan_count, f0, h->flag, ids_dev, rows_dev, scores_dev, h->stats);
         }
@@ -1050,6 +1182,23 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
     h->last_shortlist = k;
     h->last_eps = eps;
     h->last_stats_valid = true;
+    return RAG_OK;
+}
+
+// bias / max / components of the linear fusion (called by rag_hybrid_linear_dev around dense_search_fused)
+int linear_prepare(rag_ctx* h, const double* raw, int Q, int64_t n, const double* temporal, double beta, double gamma, double* mx,
+                   float* bias, int64_t ld, hipStream_t st) {
+    hipLaunchKernelGGL(linear_max_kernel, dim3(Q), dim3(256), 0, st, raw, n, mx);
+    hipLaunchKernelGGL(linear_bias_kernel, dim3((unsigned)((ld + 255) / 256), Q), dim3(256), 0, st, raw, mx, temporal, n, ld, beta, gamma, bias);
+    HIP_TRY(h, hipGetLastError());
+    return RAG_OK;
+}
+
+int linear_components(rag_ctx* h, const float* q_dev, const int32_t* rows_dev, int Q, int k, const dense_fused* fz, double* sem_out,
+                      double* kw_out, double* tmp_out, hipStream_t st) {
+    hipLaunchKernelGGL(linear_components_kernel, dim3((unsigned)(((int64_t)Q * k + 3) / 4)), dim3(256), 0, st, q_dev, h->emb32, rows_dev, Q, k,
+                       h->dim, fz->raw, fz->n, fz->mx, fz->temporal, sem_out, kw_out, tmp_out);
+    HIP_TRY(h, hipGetLastError());
     return RAG_OK;
 }
 

@@ -27,13 +27,40 @@ void pipeline_free(rag_ctx* h) {
     h->tok_rows = 0; h->tok_L = 0; h->pipe_ws_bytes = 0;
 }
 
+// int32 token ids -> the 16-bit resident store (WordPiece vocabularies have < 65536 entries: 30522 for the MiniLM
+// checkpoints); ids outside [0, 65535] are flagged
+__global__ void tokens_narrow_kernel(const int32_t* __restrict__ in, uint16_t* __restrict__ out, int64_t n, int* __restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t v = in[i];
+    if (v < 0 || v > 65535) atomicAdd(bad, 1);
+    out[i] = (uint16_t)v;
+}
+
+// The token store is kept as uint16: 2 B per token (51 GB for 100M x 256-token passages replicated per GPU, the budget of
+// SURVEY.md section 8e; the r1 int32 store would have been 102 GB). The ABI takes int32 ids; they are narrowed on the
+// device while streaming in (64 Mi tokens per piece through the staging arena).
 int tokens_load_host(rag_ctx* h, const int32_t* tokens, const int32_t* lens, int64_t n_rows, int L) {
     ARG_CHECK(h, tokens && lens && n_rows > 0 && L > 0 && L <= 512, "tokens_load: bad arguments (passage length <= 512)");
     hipFree(h->tok); hipFree(h->tok_len);
     h->tok = nullptr; h->tok_len = nullptr; h->tok_rows = 0;
-    HIP_TRY(h, hipMalloc(&h->tok, (size_t)n_rows * L * sizeof(int32_t)));
+    const int64_t total = n_rows * (int64_t)L, piece = (int64_t)64 << 20;
+    HIP_TRY(h, hipMalloc(&h->tok, (size_t)total * sizeof(uint16_t)));
     HIP_TRY(h, hipMalloc(&h->tok_len, (size_t)n_rows * sizeof(int32_t)));
-    HIP_TRY(h, hipMemcpy(h->tok, tokens, (size_t)n_rows * L * sizeof(int32_t), hipMemcpyHostToDevice));
+    int rc = stage_reserve(h, stage_size((size_t)std::min(total, piece), 4) + 256);
+    if (rc) return rc;
+    int32_t* buf = reinterpret_cast<int32_t*>(h->stage);
+    int* bad = reinterpret_cast<int*>(reinterpret_cast<char*>(h->stage) + stage_size((size_t)std::min(total, piece), 4));
+    HIP_TRY(h, hipMemsetAsync(bad, 0, sizeof(int), h->stream));
+    for (int64_t o = 0; o < total; o += piece) {
+        const int64_t nn = std::min(piece, total - o);
+        HIP_TRY(h, hipMemcpyAsync(buf, tokens + o, (size_t)nn * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(tokens_narrow_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, buf, h->tok + o, nn, bad);
+        HIP_TRY(h, hipStreamSynchronize(h->stream));                 // buf is reused by the next piece
+    }
+    int n_bad = 0;
+    HIP_TRY(h, hipMemcpy(&n_bad, bad, sizeof(int), hipMemcpyDeviceToHost));
+    ARG_CHECK(h, n_bad == 0, "tokens_load: token ids must be in [0, 65535]");
     HIP_TRY(h, hipMemcpy(h->tok_len, lens, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice));
     h->tok_rows = n_rows;
     h->tok_L = L;
@@ -43,7 +70,7 @@ int tokens_load_host(rag_ctx* h, const int32_t* tokens, const int32_t* lens, int
 // one wave per pair: cand[q][j] is a doc id (id_base + row) or -1
 __global__ __launch_bounds__(256) void ce_build_pairs_kernel(const int32_t* __restrict__ q_tok, const int32_t* __restrict__ q_len,
                                                               int Lq, const int64_t* __restrict__ cand, int64_t id_base,
-                                                              const int32_t* __restrict__ tok, const int32_t* __restrict__ tok_len,
+                                                              const uint16_t* __restrict__ tok, const int32_t* __restrict__ tok_len,
                                                               int Ld, int64_t n_rows, int n_pairs, int pool, int L, int cls_id,
                                                               int sep_id, int32_t* __restrict__ ids, int32_t* __restrict__ tt,
                                                               int32_t* __restrict__ lens) {
@@ -68,7 +95,7 @@ __global__ __launch_bounds__(256) void ce_build_pairs_kernel(const int32_t* __re
     }
     const int total = ql + dl + 3;
     const int32_t* qt = q_tok + (size_t)q * Lq;
-    const int32_t* dt = tok + (size_t)(row < 0 ? 0 : row) * Ld;
+    const uint16_t* dt = tok + (size_t)(row < 0 ? 0 : row) * Ld;
     for (int t = lane; t < L; t += 64) {
         int v = 0, ty = 0;
         if (t == 0) v = cls_id;

@@ -265,3 +265,44 @@ def test_structured_row_order_full_size(world, kind):
             np.testing.assert_allclose(sc_h[qi], exact[order], atol=1e-9)
     finally:
         eng.close()
+
+
+def test_index_level_linear_hybrid_full_size(world):
+    """rag_hybrid_linear_dev at 1M rows x 300 queries (two 256-query sub-batches): properties that do not need the CPU
+    oracle - hybrid == (alpha*sem + beta*kw) + gamma*tmp recomputed from the returned components bit for bit, scores sorted,
+    distinct rows, keyword in [0, 1] with the per-query maximum reachable - plus 3 queries checked against a float64
+    recomputation over a shortlist that provably contains the top-k (every row whose upper bound alpha + beta*kw + gamma*t
+    could reach the k-th score)."""
+    import torch
+    from oracle import rag_oracle as O
+    eng = world["whole"]
+    post, ptr, terms = _postings(world)
+    Ql, k, a, b, g = 300, 20, 0.55, 0.35, 0.10
+    rng = np.random.default_rng(11)
+    temporal = np.where(rng.uniform(size=N) < 0.3, 0.15 * 0.5 ** (rng.uniform(0, 200, N) / 30.0), 0.0)
+    eng.set_temporal(temporal)
+    q = world["q"][:Ql].contiguous()
+    out = eng.hybrid_linear_dev(q, torch.from_numpy(ptr[:Ql + 1]).cuda(), torch.from_numpy(terms).cuda(), k, a, b, g)
+    torch.cuda.synchronize()
+    got = {key: v.cpu().numpy() for key, v in out.items()}
+    assert (got["rows"] >= 0).all() and all(len(set(r)) == k for r in got["rows"])
+    assert (np.diff(got["hybrid"], axis=1) <= 0).all()
+    assert ((a * got["semantic"] + b * got["keyword"]) + g * got["temporal"] == got["hybrid"]).all()
+    assert (got["keyword"] >= 0).all() and (got["keyword"] <= 1).all()
+    np.testing.assert_array_equal(got["temporal"], temporal[got["rows"]])
+    hc = world["corpus"].cpu().numpy()
+    unit = hc / np.linalg.norm(hc, axis=1, keepdims=True)
+    for qi in (0, 255, 299):
+        raw = O.bm25_scores_csr(post.indptr, post.doc, post.tf, post.doc_len, post.idf, post.avgdl, terms[ptr[qi]:ptr[qi + 1]].tolist())
+        kw = raw / (raw.max() if raw.max() > 0 else 1.0)
+        hq = q[qi:qi + 1].cpu().numpy()
+        s32 = ((hq / np.linalg.norm(hq)) @ unit.T)[0].astype(np.float64)
+        approx = (a * s32 + b * kw) + g * temporal
+        short = np.nonzero(approx >= np.sort(approx)[-k] - 1e-3)[0]                 # float32 cosine error << 1e-3
+        exact = O.cosine_matrix(hq, hc[short])[0]
+        hyb = (a * exact + b * kw[short]) + g * temporal[short]
+        order = np.lexsort((short, -hyb))[:k]
+        np.testing.assert_array_equal(got["rows"][qi], short[order])
+        np.testing.assert_allclose(got["hybrid"][qi], hyb[order], atol=1e-12)
+        assert got["keyword"][qi].tolist() == kw[short[order]].tolist()
+    eng.set_temporal(None)

@@ -667,3 +667,52 @@ def test_adhoc_hybrid_search_keeps_resident_postings(eng):
     qd = torch.from_numpy(emb[:2].copy()).cuda()
     with pytest.raises(RagError, match="row-aligned"):
         eng.hybrid_rrf_dev(qd, torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda(), 10, 5)
+
+
+@pytest.mark.parametrize("intent", ["search", "summarization", None])
+def test_index_level_linear_hybrid_equals_hybrid_search(eng, intent):
+    """rag_hybrid_linear_dev over the RESIDENT index == HybridRetriever.hybrid_search with the whole index
+    as its corpus (oracle restatement of rag/retrieval.py:214-322, BM25 path): same rows in the same (stable) order, hybrid
+    / keyword / temporal scores bit-identical float64 (same operation order), cosine within 1e-12. N = 4096 rows incl.
+    duplicated rows (exact ties -> lower row first), an empty document, a zero embedding, timestamps old / recent / absent."""
+    import torch
+    from datetime import timedelta
+    import tools_textgen as T
+    from optimized_rag_amd.bm25 import Bm25Postings
+    rng = np.random.default_rng(4096)
+    N, D, k = 4096, 1536, 25
+    corpus = [T.make_doc(rng, int(rng.integers(1, 4))) for _ in range(N)]
+    corpus[77] = ""
+    emb = rng.standard_normal((N, D)).astype(np.float32)
+    corpus[300], emb[300] = corpus[200], emb[200]                                   # exact duplicate: tie on every component
+    emb[500] = 0.0
+    now = datetime(2026, 3, 27, 12, 0, 0)
+    meta = []
+    for i in range(N):
+        if i % 5 == 0:
+            meta.append({})
+        elif i % 5 == 1:
+            meta.append({"created_at": (now - timedelta(days=float(rng.uniform(0, 3)))).isoformat()})
+        else:
+            meta.append({"uploaded_at": (now - timedelta(days=float(rng.uniform(3, 400)))).isoformat()})
+    meta[300] = meta[200]
+    temporal = np.asarray(O.temporal_scores(N, meta, now), dtype=np.float64)
+    queries = ["memory vector index", "paris london paris berlin", "zzz-unknown-token", "kernel bandwidth matrix tile stream"]
+    q_emb = (emb[[200, 9, 1000, 4000]] + 0.4 * rng.standard_normal((4, D))).astype(np.float32)
+    a, b, g = O.weights_for_intent(intent) if intent else (0.55, 0.35, 0.10)
+    eng.index_load(emb)
+    eng.set_temporal(temporal)
+    post = Bm25Postings.from_corpus(corpus).load(eng)
+    ptr, terms = post.encode_queries(queries)
+    out = eng.hybrid_linear_dev(torch.from_numpy(q_emb).cuda(), torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda(), k, a, b, g)
+    torch.cuda.synchronize()
+    got = {key: v.cpu().numpy() for key, v in out.items()}
+    for qi, query in enumerate(queries):
+        idx, rows = O.hybrid_search(query, corpus, emb, q_emb[qi], top_k=k, metadata=meta, intent=intent, bm25_available=True, now=now)
+        assert got["rows"][qi].tolist() == idx, query
+        assert got["ids"][qi].tolist() == idx
+        np.testing.assert_allclose(got["semantic"][qi], [r["semantic_score"] for r in rows], atol=1e-12)
+        assert got["keyword"][qi].tolist() == [r["keyword_score"] for r in rows]
+        assert got["temporal"][qi].tolist() == [r["temporal_score"] for r in rows]
+        np.testing.assert_allclose(got["hybrid"][qi], [r["hybrid_score"] for r in rows], atol=1e-12)
+    eng.set_temporal(None)
