@@ -261,8 +261,8 @@ def main():
     # HBM traffic per launch: from the committed rocprofv3 --pmc passes of this same command (profiles/), which
     # cannot be collected from inside the timed run. FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950).
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_c_dense_pmc.json")
-    if world == 1 and args.rows == 1_000_000 and Q == 1024 and os.path.exists(pmc_path):
+    pmc_path = os.path.join(ROOT, "profiles", "r02_g_dense_pmc.json")
+    if world == 1 and args.rows == 1_000_000 and Q == 1024 and args.corpus == "iid" and os.path.exists(pmc_path):
         with open(pmc_path) as f:
             traffic = json.load(f)["kernels"]["dense_emit_kernel<false>"]["hbm_traffic_bytes_per_launch"]["total"]
     mfma_view = {"achieved": round(achieved_tflops, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -272,7 +272,7 @@ def main():
     roofline = {
         "bound": "mfma" if mfma_bound else "hbm", "kernel": "dense_emit_kernel<false>",
         **(mfma_view if mfma_bound else hbm_view),
-        "traffic": traffic, "traffic_source": "profiles/r01_c_dense_pmc.json (bytes per launch; algorithmic: "
+        "traffic": traffic, "traffic_source": "profiles/r02_g_dense_pmc.json (rocprofv3 --pmc passes of this command, bytes per launch; algorithmic: "
         f"{bytes_per_step / launches_per_step:.4g})" if traffic else None,
         "launches_per_step": launches_per_step, "avg_launch_ms": round(avg_launch_ms, 4),
         "algorithmic_flops_per_launch": flops_per_step / launches_per_step,

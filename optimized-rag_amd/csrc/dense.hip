@@ -182,20 +182,25 @@ __device__ __forceinline__ void load_fragB(FragB& f, const char* base, const int
 // FUSED (rag_hybrid_linear_dev): the score that is thresholded and keyed is the weighted LINEAR fusion
 // alpha * cosine + bias[q][row], bias = beta * bm25_normalised + gamma * temporal precomputed per (query, row) in float32
 // (rag/retrieval.py:302); everything downstream (select, float64 rescoring, ranking) is unchanged.
-template <bool DENSE0, bool SMALLQ, bool FUSED = false>
-__global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restrict__ corpus16, const half_t* __restrict__ q16,
-                                                          int Dp, int rtile_begin, int n_rtiles, int n_qtiles,
-                                                          int n_rows_valid, int q_valid, const float* __restrict__ tau,
-                                                          unsigned* __restrict__ cnt, uint64_t* __restrict__ cand,
-                                                          const int32_t* __restrict__ tenants, int tenant,
-                                                          const int32_t* __restrict__ tile_list, int tile_mul, int tile_mod,
-                                                          const int* __restrict__ active_count,
-                                                          const float* __restrict__ bias = nullptr, int64_t bias_ld = 0,
-                                                          float alpha = 1.0f, const int* __restrict__ qmap = nullptr
 #ifdef DENSE_STAMP
-                                                          , unsigned long long* __restrict__ stamp_out = nullptr
+#define STAMP_PARAM , unsigned long long* __restrict__ stamp_out
+#define STAMP_PASS , stamp_out
+#else
+#define STAMP_PARAM
+#define STAMP_PASS
 #endif
-) {
+#define EMIT_PARAMS                                                                                                   \
+    const half_t *__restrict__ corpus16, const half_t *__restrict__ q16, int Dp, int rtile_begin, int n_rtiles, int n_qtiles,  \
+        int n_rows_valid, int q_valid, const float *__restrict__ tau, unsigned *__restrict__ cnt, uint64_t *__restrict__ cand, \
+        const int32_t *__restrict__ tenants, int tenant, const int32_t *__restrict__ tile_list, int tile_mul, int tile_mod,    \
+        int tile_cnt, const int *__restrict__ active_count, const float *__restrict__ bias, int64_t bias_ld, float alpha,      \
+        const int *__restrict__ qmap STAMP_PARAM
+#define EMIT_PASS                                                                                                     \
+    corpus16, q16, Dp, rtile_begin, n_rtiles, n_qtiles, n_rows_valid, q_valid, tau, cnt, cand, tenants, tenant, tile_list,    \
+        tile_mul, tile_mod, tile_cnt, active_count, bias, bias_ld, alpha, qmap STAMP_PASS
+// one 256 x 256 tile; vb = the (virtual) block index that selects it
+template <bool DENSE0, bool SMALLQ, bool FUSED>
+__device__ __forceinline__ void dense_emit_tile(const int vb, EMIT_PARAMS) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
     // nothing to do: the device-side count of such queries decides, no host round trip
     if (active_count != nullptr && *active_count == 0) return;
     // XCD-aware tile assignment (speed only; any placement is correct)
-    const int b = blockIdx.x;
+    const int b = vb;
     const int xcd = b & 7, seq = b >> 3;
     const int rt = (seq / n_qtiles) * 8 + xcd;
     const int qt = seq % n_qtiles;
@@ -222,9 +227,12 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
     // ROW ORDER. The threshold stages must each see a REPRESENTATIVE sample of the rows, whatever order the table was
     // exported in (file by file, tenant by tenant, topic-sorted): position p of the schedule maps to corpus tile
     // (p * tile_mul) mod tile_mod - a multiplicative low-discrepancy permutation (tile_mul ~ 0.618 * tile_mod, coprime), so
-    // every prefix of positions is spread evenly over the table - and, under a tenant filter, through tile_list: the
-    // tiles that hold at least one row of that tenant (other tiles are never read).
+    // every prefix of positions is spread evenly over the table - and, under a tenant filter, through tile_list: the tiles
+    // that hold at least one row of that tenant (other tiles are never read). (Permuting GROUPS of 8 tiles instead was
+    // measured and rejected: stage 0 is then one contiguous 2048-row stretch, and on the topic-sorted corpus every late
+    // group overflowed the buffer: 612 queries/s.)
     const int pos = rtile_begin + rt;
+    if (pos >= tile_cnt) return;
     int tile = (int)(((int64_t)pos * tile_mul) % tile_mod);
     if (tile_list != nullptr) tile = tile_list[tile];
     const int row0 = tile * RAG_TILE;
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // clamped tail re-loads still in flight: retire them
 #ifdef DENSE_STAMP
     if (lane == 0 && stamp_out)
-        for (int i = 0; i < 4; ++i) stamp_out[((size_t)blockIdx.x * 8 + wid) * 4 + i] = stamp_acc[i];
+        for (int i = 0; i < 4; ++i) stamp_out[((size_t)vb * 8 + wid) * 4 + i] = stamp_acc[i];
 #endif
 
     // ---- epilogue: C layout col = lane&15 (query), row = (lane>>4)*4 + reg (corpus row) ----------
@@ -401,6 +409,23 @@ __global__ __launch_bounds__(512) void dense_emit_kernel(const half_t* __restric
                         dst[s_] = make_key(acc[i][j][r] * scale, (uint32_t)(row0 + wm * 128 + i * 16 + fq * 4 + r));
                     ++s_;
                 }
+    }
+}
+
+template <bool DENSE0, bool SMALLQ, bool FUSED = false>
+__global__ __launch_bounds__(512) void dense_emit_kernel(EMIT_PARAMS) {
+    dense_emit_tile<DENSE0, SMALLQ, FUSED>(blockIdx.x, EMIT_PASS);
+}
+
+// Second pass (queries whose buffer overflowed): almost always there is nothing to do, and a corpus-sized grid of 128 KiB-LDS
+// workgroups costs ~40 us just to be dispatched and retired. One workgroup per CU walks the tiles instead; idle, the launch
+// costs one read of the device-side count per workgroup.
+template <bool FUSED>
+__global__ __launch_bounds__(512) void dense_emit_persist_kernel(int n_vblocks, EMIT_PARAMS) {
+    if (active_count != nullptr && *active_count == 0) return;
+    for (int vb = blockIdx.x; vb < n_vblocks; vb += gridDim.x) {
+        dense_emit_tile<false, false, FUSED>(vb, EMIT_PASS);
+        __syncthreads();                                   // the next tile's prologue refills LDS stages this tile still reads
     }
 }
 
@@ -664,14 +689,15 @@ __global__ __launch_bounds__(256) void flag_list_kernel(const int* __restrict__ 
 __global__ __launch_bounds__(256) void scan_chunk_kernel(const float* __restrict__ q32, const float* __restrict__ emb32,
                                                           const int32_t* __restrict__ tenants, int tenant, int64_t n_rows,
                                                           int64_t rows_per_block, int dim, int k, const int* __restrict__ list,
-                                                          const int* __restrict__ count, int f0, uint64_t* __restrict__ part_key,
+                                                          const int* __restrict__ count, int f0, int round_q,
+                                                          uint64_t* __restrict__ part_key,
                                                           uint32_t* __restrict__ part_row, const double* __restrict__ raw,
                                                           int64_t raw_ld, const double* __restrict__ raw_mx,
                                                           const double* __restrict__ temporal, double fa, double fb, double fg) {
     __shared__ uint64_t sk[SCAN_CHUNK];
     __shared__ uint32_t sr[SCAN_CHUNK];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int f_end = min(*count, f0 + SCAN_ROUND);
+    const int f_end = min(*count, f0 + round_q);
     const int64_t base = (int64_t)blockIdx.x * rows_per_block;
     const int64_t base_end = min(n_rows, base + rows_per_block);
     const int window = SCAN_CHUNK - k;
@@ -1038,6 +1064,10 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<false, false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_persist_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_persist_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wide_kernel),
@@ -1055,14 +1085,16 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
         total_tiles = it == h->tenant_span.end() ? 0 : it->second.second;
         tile_list = it == h->tenant_span.end() ? nullptr : h->tenant_tiles + it->second.first;
     }
-    const int tile_mul = tile_multiplier(total_tiles), tile_mod = std::max(1, total_tiles);
+    const int n_tiles = total_tiles;
+    // RAG_DENSE_LINEAR_ORDER=1 (diagnostic): r1's table order, to price the permutation on one box
+    const int tile_mul = getenv("RAG_DENSE_LINEAR_ORDER") ? 1 : tile_multiplier(n_tiles), tile_mod = std::max(1, n_tiles);
     const bool smallq = Q <= 128 && !getenv("RAG_NO_SMALLQ");
 
     // ---- stage schedule over tile POSITIONS: 8 tiles (2048 rows) scored densely, then ~8x growth each. The expected
     // emission of a stage is ~k x growth keys per query (tau = k-th best of everything seen so far), so the growth is
     // capped by k: it must stay well inside the 4096-entry buffer (r1 used 32x for small batches at any k; at k = 100
     // that sat at the edge of the buffer and a single query could fall into the exact scan).
-    const int stage0_tiles = std::min(total_tiles, RAG_STAGE0_ROWS / RAG_TILE);
+    const int stage0_tiles = std::min(n_tiles, RAG_STAGE0_ROWS / RAG_TILE);
     const char* growth_s = getenv("RAG_STAGE_GROWTH");                 // diagnostic: read per call so tests can set it
     const int growth_env = growth_s && atoi(growth_s) >= 2 ? atoi(growth_s) : 0;
     const int growth = growth_env ? growth_env
@@ -1082,7 +1114,7 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
         }
 #define EMIT_ARGS(QP, NQT, QV, TAU, CNT, CAND, ACT, QMAP)                                                        \
     h->emb16, QP, h->dim_pad, begin_, n_rt_, NQT, (int)h->n_rows, QV, TAU, CNT, CAND, tenants, tenant, tile_list, tile_mul, tile_mod, \
-        (const int*)(ACT), bias, bias_ld, alpha_f, (const int*)(QMAP) STAMP_ARG
+        n_tiles, (const int*)(ACT), bias, bias_ld, alpha_f, (const int*)(QMAP) STAMP_ARG
         const int begin_ = begin, n_rt_ = n_rt;
         if (stage == 0 && fz)
             hipLaunchKernelGGL((dense_emit_kernel<true, false, true>), dim3(grid), dim3(512), DENSE_LDS_BYTES, st,
@@ -1125,12 +1157,13 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
                            h->q16b, h->taub, h->boundb, h->cntb);
         {
             const int begin_ = 0, n_rt_ = total_tiles;
+            static const int n_cu = [] { int d = 0, n = 0; hipGetDevice(&d); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
             if (fz)
-                hipLaunchKernelGGL((dense_emit_kernel<false, false, true>), dim3((int)round_up(total_tiles, 8)), dim3(512), DENSE_LDS_BYTES,
-                                   st, EMIT_ARGS(h->q16b, 1, RAG_TILE, h->taub, h->cntb, h->candb, ovf_count, h->ovf_list));
+                hipLaunchKernelGGL((dense_emit_persist_kernel<true>), dim3(std::min(n_cu, total_tiles)), dim3(512), DENSE_LDS_BYTES, st, total_tiles,
+                                   EMIT_ARGS(h->q16b, 1, RAG_TILE, h->taub, h->cntb, h->candb, ovf_count, h->ovf_list));
             else
-                hipLaunchKernelGGL((dense_emit_kernel<false, false>), dim3((int)round_up(total_tiles, 8)), dim3(512), DENSE_LDS_BYTES,
-                                   st, EMIT_ARGS(h->q16b, 1, RAG_TILE, h->taub, h->cntb, h->candb, ovf_count, nullptr));
+                hipLaunchKernelGGL((dense_emit_persist_kernel<false>), dim3(std::min(n_cu, total_tiles)), dim3(512), DENSE_LDS_BYTES, st, total_tiles,
+                                   EMIT_ARGS(h->q16b, 1, RAG_TILE, h->taub, h->cntb, h->candb, ovf_count, nullptr));
         }
         hipLaunchKernelGGL(select_kernel, dim3(RAG_TILE / 4), dim3(256), SELECT_LDS_BYTES, st, h->candb, h->cntb, h->taub, h->boundb,
                            h->n_sortedb, (int*)nullptr, RAG_TILE, 0, k, two_eps, 1, (const int*)ovf_count);
@@ -1153,7 +1186,10 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
         const int window = SCAN_CHUNK - k;
         const int64_t rows_per_block = std::max<int64_t>(1, (h->n_rows + 1023) / 1024 + window - 1) / window * window;
         const int n_blocks = (int)((h->n_rows + rows_per_block - 1) / rows_per_block);
-        const size_t need = (size_t)std::min(Q, SCAN_ROUND) * n_blocks * k;
+        // flagged queries per round: as many as a 512 MB partial-list scratch holds (k = 20 at 1M rows: every query of a
+        // 1024-batch in ONE round = two idle launches per search), at least SCAN_ROUND
+        const int round_q = std::min(Q, std::max(SCAN_ROUND, (int)std::min<size_t>(65535, ((size_t)512 << 20) / ((size_t)n_blocks * k * 12))));
+        const size_t need = (size_t)round_q * n_blocks * k;
         if ((int64_t)need > h->scan_rows) {
             hipFree(h->scan_scores);
             h->scan_scores = nullptr;
@@ -1166,12 +1202,12 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
         int* scan_list = h->n_sorted;                 // free after the wide kernel; [Q] ints
         int* scan_count = h->stats + 7;
         hipLaunchKernelGGL(flag_list_kernel, dim3(1), dim3(256), 0, st, (const int*)h->flag, (const float*)nullptr, Q, 2, Q, scan_list, scan_count);
-        for (int f0 = 0; f0 < Q; f0 += SCAN_ROUND) {
+        for (int f0 = 0; f0 < Q; f0 += round_q) {
             hipLaunchKernelGGL(scan_chunk_kernel, dim3(n_blocks), dim3(256), 0, st, q_dev, h->emb32, tenants, tenant, h->n_rows,
-                               rows_per_block, h->dim, k, scan_list, scan_count, f0, pk, pr, fz ? fz->raw : (const double*)nullptr,
+                               rows_per_block, h->dim, k, scan_list, scan_count, f0, round_q, pk, pr, fz ? fz->raw : (const double*)nullptr,
                                fz ? fz->n : (int64_t)0, fz ? fz->mx : (const double*)nullptr, fz ? fz->temporal : (const double*)nullptr,
                                fz ? fz->alpha : 0.0, fz ? fz->beta : 0.0, fz ? fz->gamma : 0.0);
-            hipLaunchKernelGGL(scan_merge_kernel, dim3(std::min(Q - f0, SCAN_ROUND)), dim3(256), 0, st, pk, pr, n_blocks, k, h->ids,
+            hipLaunchKernelGGL(scan_merge_kernel, dim3(std::min(Q - f0, round_q)), dim3(256), 0, st, pk, pr, n_blocks, k, h->ids,
                                h->id_base, scan_list, scan_count, f0, h->flag, ids_dev, rows_dev, scores_dev, h->stats);
         }
         HIP_TRY(h, hipGetLastError());

@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
         CK(hipMemset(cnt, 0, Q * 4));
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL((dense_emit_kernel<false, false>), dim3(grid), dim3(512), DENSE_LDS_BYTES, 0, c, q, D, 0, n_rt, n_qt, N, Q, tau, cnt,
-                           cand, (const int32_t*)nullptr, 0 EXTRA);
+                           cand, (const int32_t*)nullptr, 0, (const int32_t*)nullptr, 1, (N + 2047) / 2048, (N + 255) / 256, (const int*)nullptr, (const float*)nullptr, (int64_t)0, 1.0f, (const int*)nullptr EXTRA);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
                                DENSE_LDS_BYTES));
         CK(hipMemset(cand, 0, (size_t)Q * RAG_CAND_CAP * 8));
         hipLaunchKernelGGL((dense_emit_kernel<true, false>), dim3(8 * n_qt), dim3(512), DENSE_LDS_BYTES, 0, c, q, D, 0, 8, n_qt, 2048, Q, tau, cnt,
-                           cand, (const int32_t*)nullptr, 0 EXTRA);
+                           cand, (const int32_t*)nullptr, 0, (const int32_t*)nullptr, 1, (N + 2047) / 2048, (N + 255) / 256, (const int*)nullptr, (const float*)nullptr, (int64_t)0, 1.0f, (const int*)nullptr EXTRA);
         CK(hipDeviceSynchronize());
         std::vector<uint64_t> hk((size_t)Q * RAG_CAND_CAP);
         CK(hipMemcpy(hk.data(), cand, hk.size() * 8, hipMemcpyDeviceToHost));
