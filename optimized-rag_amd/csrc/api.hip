@@ -472,7 +472,9 @@ int rag_hybrid_linear_dev(rag_handle_t h, const float* q_dev, const int32_t* ter
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = h->n_rows, ld = h->n_rows_pad;
-    const int QB = 256;
+    // queries per sub-batch: one query tile when the all-document scores fit 8 GB (2 GB + 1 GB at 1M rows), fewer on large
+    // shards (12.5M rows: 53 queries, 8 GB instead of 38 GB)
+    const int QB = (int)std::max<int64_t>(16, std::min<int64_t>(256, ((int64_t)8 << 30) / (n * 12)));
     const size_t need = stage_size((size_t)QB * n, 8) + stage_size((size_t)QB * ld, 4) + stage_size(QB, 8);
     if (need > h->lin_ws_bytes) {
         hipFree(h->lin_ws);
