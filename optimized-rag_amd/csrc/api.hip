@@ -143,6 +143,7 @@ static int index_load_common(rag_ctx* h, const float* emb, const int64_t* ids, i
     }
     int rc = dense_index_build(h, h->emb32, n_rows, st);
     if (rc) return rc;
+    h->index_loaded = true;
     if (host) HIP_TRY(h, hipStreamSynchronize(st));
     return RAG_OK;
 }
@@ -177,6 +178,7 @@ int rag_index_reserve(rag_handle_t h, int64_t n_rows_total, int64_t id_base) {
     // rows not appended yet (and the tile padding) must read as zero vectors
     HIP_TRY(h, hipMemsetAsync(h->emb16, 0, (size_t)h->n_rows_pad * h->dim_pad * sizeof(half_t), h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->index_loaded = true;
     return RAG_OK;
 }
 

@@ -37,6 +37,7 @@ struct rag_ctx {
 
     // dense index
     int64_t n_rows = 0, n_rows_pad = 0, id_base = 0;
+    bool index_loaded = false;   // rag_index_load_* / rag_index_reserve ran (an EMPTY index is a valid, searchable state)
     int64_t n_reserved = 0;      // rows allocated by rag_index_reserve (chunked bulk load), 0 otherwise
     float* emb32 = nullptr;      // [n_rows][dim]        fp32 master rows
     half_t* emb16 = nullptr;     // [n_rows_pad][dim_pad] fp16 (2^7 * unit rows), zero padded

@@ -977,6 +977,7 @@ int dense_free(rag_ctx* h) {
     hipFree(h->tenant_tiles); h->tenant_tiles = nullptr; h->tenant_span.clear(); h->tenant_rows = 0;
     h->n_rows = h->n_rows_pad = 0;
     h->n_reserved = 0;
+    h->index_loaded = false;
     return RAG_OK;
 }
 
@@ -1027,7 +1028,7 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
 // is alpha * cosine + beta * keyword + gamma * temporal (fz carries the per-(query,row) bias and the float64 inputs).
 int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev,
                        double* scores_dev, hipStream_t st, const dense_fused* fz) {
-    ARG_CHECK(h, h->emb16 != nullptr, "no index loaded");
+    ARG_CHECK(h, h->index_loaded, "no index loaded");
     ARG_CHECK(h, Q > 0 && k > 0 && k <= RAG_MAX_K, "need Q>0 and 0<k<=256");
     ARG_CHECK(h, tenant < 0 || h->tenants != nullptr, "tenant filter requested but no tenants loaded");
     int rc = ensure_workspace(h, Q, st);

@@ -351,3 +351,12 @@ def test_exact_scan_rounds_beyond_256_flagged_queries(eng_factory, monkeypatch):
     monkeypatch.setenv("RAG_FORCE_LEVEL", "2")
     st = check(eng, corpus, queries, 20)
     assert st["exact_scan"] == 300, st
+
+
+def test_empty_index_searches_to_empty_results(eng_factory):
+    """An index with zero rows is a valid state (a tenant's table before its first upload): every slot comes back -1 / 0.0,
+    as `ORDER BY ... LIMIT k` over an empty table returns no rows (the zero-row branch could never run)."""
+    eng = eng_factory(128)
+    eng.index_load(np.zeros((0, 128), dtype=np.float32))
+    ids, rows, sc = eng.dense_topk(np.ones((3, 128), dtype=np.float32), 5)
+    assert (ids == -1).all() and (rows == -1).all() and (sc == 0).all()
