@@ -103,6 +103,12 @@ __device__ __forceinline__ void ce_dma(const half_t* __restrict__ g, char* lds, 
                                      (__attribute__((address_space(3))) void*)(lds + wid * 64 * 16), 16, 0, 0);
 }
 
+// LDS-DMA piece through a buffer descriptor: per-lane byte offset in ONE VGPR, piece / K-step offset in a scalar register
+// (no 64-bit address arithmetic per piece; reads past the descriptor's end return zeros)
+__device__ __forceinline__ void ce_bdma(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, char* lds, int wid) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + wid * 64 * 16), 16, voff, soff, 0, 0);
+}
+
 // C^T[n][m] = sum_k W[n][k] * X[m][k].   W: [2 planes][N][K] fp16, X: [2 planes][M_pad][K] fp16 (hi plane, then lo).
 // N % 128 == 0, M_pad % 256 == 0, K % 32 == 0, K >= 64.
 // 128 (features) x 256 (tokens) tile, 8 waves (2 x 4, each 64 x 64), BK = 32, THREE LDS stages filled by LDS-DMA two
@@ -158,23 +164,38 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
     const int a_base = wm * 64 * 128, b_base = CE_W_TILE + wn * 64 * 128;
     const int nt = K / CE_BK;
     const int last = nt - 1;
-    const half_t* w_cur = W + (size_t)(CE_TILE_N(work) * CE_BM + sr) * ldk + schunk * 8;
-    const half_t* x_cur = X + (size_t)(CE_TILE_M(work) * CE_BN + sr) * ldk + schunk * 8;   // rows sr, +64, +128, +192 of the tile
-    const half_t *w_nxt = w_cur, *x_nxt = x_cur;
+    // Buffer addressing (as ce_gemm_ln_kernel): W through one descriptor + a scalar tile offset, the 256 token rows of a tile
+    // through a per-tile descriptor, ONE per-lane byte offset for all six pieces of a stage. The pointer form spent ~14 VALU
+    // instructions per K-step on 64-bit source addresses inside the part of the step that is on the critical path.
+    const unsigned voff = (unsigned)(((size_t)sr * ldk + schunk * 8) * sizeof(half_t));
+    const unsigned piece_b = (unsigned)(piece * sizeof(half_t));
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(W), 0, (int)((size_t)N * ldk * sizeof(half_t)), 0x00020000);
+    unsigned w_cur = (unsigned)((size_t)CE_TILE_N(work) * CE_BM * ldk * sizeof(half_t)), w_nxt = w_cur;      // byte offset of the feature tile
+    __amdgpu_buffer_rsrc_t x_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(X + (size_t)CE_TILE_M(work) * CE_BN * ldk), 0,
+                                                                     (int)(4 * piece_b), 0x00020000);
+    __amdgpu_buffer_rsrc_t x_nxt = x_cur;
     bool has_next = false;
     int sbase = 0;                               // ring stage of step 0 of the current tile
 #define CE_ISSUE(u)   /* step u of the current tile; u >= nt: step u - nt of the next tile (or a harmless re-load) */     \
     {                                                                                                             \
         const int u_ = (u);                                                                                       \
-        const half_t* ws_ = u_ < nt ? w_cur + u_ * 64 : (has_next ? w_nxt + (u_ - nt) * 64 : w_cur + last * 64);  \
-        const half_t* xs_ = u_ < nt ? x_cur + u_ * 64 : (has_next ? x_nxt + (u_ - nt) * 64 : x_cur + last * 64);  \
+        const bool nx_ = u_ >= nt && has_next;                                                                    \
+        const unsigned ks_ = (unsigned)(u_ < nt ? u_ : (has_next ? u_ - nt : last)) * 128u;                       \
+        const unsigned ws_ = (nx_ ? w_nxt : w_cur) + ks_;                                                         \
         char* st_ = smem + ((sbase + u_) % 3) * CE_STAGE_BYTES;                                                   \
-        ce_dma(ws_, st_, wid);                                                                                    \
-        ce_dma(ws_ + piece, st_ + 8192, wid);                                                                     \
-        ce_dma(xs_, st_ + CE_W_TILE, wid);                                                                        \
-        ce_dma(xs_ + piece, st_ + CE_W_TILE + 8192, wid);                                                         \
-        ce_dma(xs_ + 2 * piece, st_ + CE_W_TILE + 2 * 8192, wid);                                                 \
-        ce_dma(xs_ + 3 * piece, st_ + CE_W_TILE + 3 * 8192, wid);                                                 \
+        ce_bdma(w_rs, voff, ws_, st_, wid);                                                                       \
+        ce_bdma(w_rs, voff, ws_ + piece_b, st_ + 8192, wid);                                                      \
+        if (nx_) {                                                                                                \
+            ce_bdma(x_nxt, voff, ks_, st_ + CE_W_TILE, wid);                                                      \
+            ce_bdma(x_nxt, voff, ks_ + piece_b, st_ + CE_W_TILE + 8192, wid);                                     \
+            ce_bdma(x_nxt, voff, ks_ + 2 * piece_b, st_ + CE_W_TILE + 2 * 8192, wid);                             \
+            ce_bdma(x_nxt, voff, ks_ + 3 * piece_b, st_ + CE_W_TILE + 3 * 8192, wid);                             \
+        } else {                                                                                                  \
+            ce_bdma(x_cur, voff, ks_, st_ + CE_W_TILE, wid);                                                      \
+            ce_bdma(x_cur, voff, ks_ + piece_b, st_ + CE_W_TILE + 8192, wid);                                     \
+            ce_bdma(x_cur, voff, ks_ + 2 * piece_b, st_ + CE_W_TILE + 2 * 8192, wid);                             \
+            ce_bdma(x_cur, voff, ks_ + 3 * piece_b, st_ + CE_W_TILE + 3 * 8192, wid);                             \
+        }                                                                                                         \
     }
 #define CE_BAR __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
     CE_ISSUE(0)
@@ -189,8 +210,8 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
             const int nx = work + n_slots;
             has_next = CE_TILE_M(nx) * CE_BN < m_end;
             if (has_next) {
-                w_nxt = W + (size_t)(CE_TILE_N(nx) * CE_BM + sr) * ldk + schunk * 8;
-                x_nxt = X + (size_t)(CE_TILE_M(nx) * CE_BN + sr) * ldk + schunk * 8;
+                w_nxt = (unsigned)((size_t)CE_TILE_N(nx) * CE_BM * ldk * sizeof(half_t));
+                x_nxt = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(X + (size_t)CE_TILE_M(nx) * CE_BN * ldk), 0, (int)(4 * piece_b), 0x00020000);
             }
         }
         // bias in registers before the main loop: the epilogue must not start with a global load behind the in-flight DMA
@@ -388,10 +409,7 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
 // LDS-DMA as ONE continuous stream across tiles; one barrier per K-step (RAW: counted vmcnt(2); WAR: a slot is refilled
 // only after the barrier that follows its last read). The W stage that is free after the last K-step is the epilogue's
 // transpose scratch (6 KiB per wave). K must be a multiple of 192 (stages are then functions of the K-step alone).
-// LDS-DMA piece through a buffer descriptor: per-lane byte offset in one VGPR, piece / K-step offset in a scalar register
-__device__ __forceinline__ void lng_dma(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, char* lds, int wid) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + wid * 64 * 16), 16, voff, soff, 0, 0);
-}
+#define lng_dma ce_bdma
 #define LNG_W_STAGE (384 * 128)                    // 48 KiB
 #define LNG_X_STAGE (128 * 128)                    // 16 KiB
 #define LNG_LDS (2 * LNG_W_STAGE + 3 * LNG_X_STAGE)    // 144 KiB

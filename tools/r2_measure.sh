@@ -21,7 +21,11 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CON
   tag=$(echo $pmc | tr ' ' '_' | cut -c1-24)
   echo "== pmc $pmc"; timeout -k 10 300 rocprofv3 --pmc $pmc --kernel-trace -d $S/r2m_pmc_$tag -o p -- python3 $R/bench.py --dense-only --no-cpu-baseline --steps 5 --warmup 1 --latency-batches 1 > $O/r2m_pmc_$tag.log 2>&1
 done
+for pmc in "FETCH_SIZE" "WRITE_SIZE"; do
+  echo "== rerank pmc $pmc"; timeout -k 10 300 rocprofv3 --pmc $pmc --kernel-trace -d $S/r2m_cepmc_$pmc -o p -- python3 $R/bench.py --mode rerank > $O/r2m_cepmc_$pmc.log 2>&1
+done
 cd $R
+for d in $S/r2m_cepmc_*/; do python tools/rocpd_pmc.py $d/p_results.db ce_ > $O/$(basename $d).txt 2>&1; done
 python tools/rocpd_top.py $S/r2m_prof_dense/d_results.db > $O/r2m_dense_kernel_stats.csv
 python tools/rocpd_top.py $S/r2m_prof_full/f_results.db > $O/r2m_full_kernel_stats.csv
 for d in $S/r2m_pmc_*/; do python tools/rocpd_pmc.py $d/p_results.db > $O/$(basename $d).txt 2>&1; done
