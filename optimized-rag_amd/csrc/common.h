@@ -101,7 +101,6 @@ struct rag_ctx {
     size_t pipe_ws_bytes = 0;
     // hipFuncSetAttribute (dynamic LDS above 64 KiB) is per device: remembered per handle, not per process
     bool attr_dense = false, attr_bm25 = false, attr_ce_gemm = false, attr_ce_gemm_ln = false;
-    bool attr_ce_gemm12 = false;
     int attr_ce_attn_lds[3] = {0, 0, 0};
     rag_ce_model* ce = nullptr;
 };

@@ -40,7 +40,6 @@ struct rag_ce_model {
     float *word = nullptr, *pos = nullptr, *type = nullptr, *emb_ln_g = nullptr, *emb_ln_b = nullptr;
     struct Layer {
         half_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;      // fp16 [out][in]
-        half_t *wqkv_p = nullptr, *w1_p = nullptr;     // hidden = 384: copies with the Q, K / FFN-up rows permuted for ce_gemm12_kernel
         float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
         float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
     };
@@ -94,14 +93,6 @@ __device__ __forceinline__ void store_split4(half_t* __restrict__ p, size_t plan
                       (half_t)(v3 - (float)hi[3])};
     *reinterpret_cast<half4*>(p) = hi;
     *reinterpret_cast<half4*>(p + plane) = lo;
-}
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint32_t ce_pk(float a, float b) {
-    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
-}
-__device__ __forceinline__ float ce_trunc10(float e) {     // e with the mantissa cut to 10 bits: exactly a fp16 value
-    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, e) & 0xFFFFE000u);
 }
 
 // LDS rows are 128 B (8 chunks of 16 B: hi chunks 0-3, lo chunks 4-7 of one 32-element K group). Chunk c of row r is
@@ -404,511 +395,6 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
         sbase = (sbase + nt) % 3;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // clamped tail re-loads of the last tile: retire them before exit
-}
-
-// ---- K = 384 GEMMs (Q|K, V, FFN-up) with the epilogue of tile i-1 INSIDE the main loop of tile i ---------------------
-// ce_gemm_kernel's epilogue (bias, GELU, split, LDS transposes, stores) ran with the matrix pipe idle: for FFN-up it is
-// as much vector work as 60 % of the tile's MFMA time (tools/ce_probe_build.sh: no epilogue = -35 % forward time). Here the
-// accumulators of a finished tile are kept (pacc) and converted / stored in slices between the MFMAs of the NEXT tile's
-// 12 K-steps, where an MFMA leaves half of the SIMD's issue cycles to other vector work. That needs an epilogue without
-// LDS (the stage ring is busy) and without per-tile scratch:
-//   * the W rows of Q, K and FFN-up are PERMUTED inside each 64-row block when the model is loaded (ce_f32_split_kernel,
-//     stored row i*16 + p <- row (i>>1)*32 + (p>>2)*8 + (i&1)*4 + (p&3)), so lane (fq, fr) holds, in accumulator quads 2g and
-//     2g+1, the 8 CONSECUTIVE features g*32 + fq*8 .. +8 of token fr: one 16-byte piece, and the four fq lanes of a token
-//     together the 64 contiguous bytes of a K group's hi (or lo) half - or one whole 1 KiB fragment tile of K;
-//   * V runs as its own launch with the MFMA operands swapped (tokens on the MFMA row): lane (fq, d) then holds the 8 key
-//     slots of V's fragment layout;
-//   * bias enters as the C operand of the first MFMA of a tile (from a table in LDS); no zeroing, no bias add;
-//   * outputs go through buffer stores: one descriptor per tile, per-lane offset in one VGPR, scalar offsets; a null
-//     descriptor (first tile: nothing to store yet) or the offset G12_DROP (rows past the packed end) drops the store.
-// Stores count in vmcnt like the DMA pieces and retire in issue order, so every counted wait adds the stores issued since.
-// Units: 16 accumulator quads per wave, [2, 1, 1] per K-step; a finished pair of quads = 16 B hi + 16 B lo per lane.
-enum { G12_Q = 0, G12_K = 1, G12_V = 2, G12_GELU = 3 };
-enum { EPI2_QK = 0, EPI2_V = 1, EPI2_GELU = 2 };
-#define G12_LDS (CE_GEMM_LDS + 1536 * 4)                  // stage ring + bias table (N <= 1536)
-#define G12_DROP 0xF0000000u                              // per-lane byte offset beyond any descriptor: the store is dropped
-#ifdef G12_PROBE_NO_STORE       // timing experiments only: every epilogue store is dropped by a zero-size descriptor
-#define G12_PROBE_BYTES(b) 0
-#else
-#define G12_PROBE_BYTES(b) (b)
-#endif
-#ifdef G12_PROBE_SAME_ROWS      // timing experiment only: every tile writes the same 256 output rows (they stay in L2)
-#define G12_PROBE_ROW(r) ((r) & 255)
-#else
-#define G12_PROBE_ROW(r) (r)
-#endif
-#ifdef G12_PROBE_NO_NT
-#define G12_NT 0
-#else
-#define G12_NT 2                                          // non-temporal: outputs are read again only by a later kernel
-#endif
-#define G12_STORES(t) (((t) + 12) % 3 != 1 ? 2 : 0)       // buffer stores a wave issues in K-step t
-
-// erf-GELU as ce_gelu, arranged for few issue slots: gelu(x) = h + |h| - |h| q with h = x/2, q = erfc(|x|/sqrt 2) by
-// A&S 7.1.26 (13 plain operations + rcp + exp2; no cancellation on the negative side)
-__device__ __forceinline__ float ce_gelu_q(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float xs = x * 0.84932180028801904272f;         // sqrt(log2(e) / 2)
-    const float e = __builtin_amdgcn_exp2f(-(xs * xs));
-    const float q = (p * t) * e;
-    const float h = 0.5f * x;
-    return fmaf(-fabsf(h), q, h + fabsf(h));
-}
-
-template <bool GELU>
-__device__ __forceinline__ void g12_split(f32x4 v, uint32_t& h0, uint32_t& h1, uint32_t& l0, uint32_t& l1) {
-#ifndef G12_PROBE_NO_GELU       // timing experiments only (tools/ce_probe_build.sh)
-    if (GELU) { v[0] = ce_gelu_q(v[0]); v[1] = ce_gelu_q(v[1]); v[2] = ce_gelu_q(v[2]); v[3] = ce_gelu_q(v[3]); }
-#endif
-    const float a0 = ce_trunc10(v[0]), a1 = ce_trunc10(v[1]), a2 = ce_trunc10(v[2]), a3 = ce_trunc10(v[3]);
-    h0 = ce_pk(a0, a1);
-    h1 = ce_pk(a2, a3);
-    l0 = ce_pk(v[0] - a0, v[1] - a1);
-    l1 = ce_pk(v[2] - a2, v[3] - a3);
-}
-
-template <int KIND, int TERMS>
-__device__ __forceinline__ void g12_body(char* smem, const half_t* __restrict__ W, const half_t* __restrict__ X, int N,
-                                         half_t* __restrict__ out16, half_t* __restrict__ kv16, size_t kv_plane, int hidden,
-                                         int heads, int m_end, const int32_t* __restrict__ row_pair,
-                                         const int32_t* __restrict__ pair_off, int work, int xcd, int n_slots, int n_ft) {
-    constexpr int K = 384, NT = 12;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;
-    const bool lag = wm != 0;
-#define G12_TILE_M(w) (((w) / n_ft) * 8 + xcd)
-#define G12_TILE_N(w) (KIND <= G12_K ? ((((w) % n_ft) >> 1) + (((w) % n_ft) & 1) * (n_ft >> 1)) : ((w) % n_ft))
-    const int sr = tid >> 3;
-    const int schunk = (tid & 7) ^ ((sr >> 1) & 7);
-    constexpr size_t ldk = (size_t)2 * K;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int sw = (fr >> 1) & 7;
-    const int off = fr * 128 + ((fq ^ sw) << 4), off_lo = fr * 128 + (((4 + fq) ^ sw) << 4);
-    const int a_base = wm * 64 * 128, b_base = CE_W_TILE + wn * 64 * 128;
-    const unsigned voff = (unsigned)(((size_t)sr * ldk + schunk * 8) * sizeof(half_t));
-    constexpr unsigned piece_b = (unsigned)(64 * ldk * sizeof(half_t));
-    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(W), 0, (int)((size_t)N * ldk * sizeof(half_t)), 0x00020000);
-    unsigned w_cur = (unsigned)((size_t)G12_TILE_N(work) * CE_BM * ldk * sizeof(half_t)), w_nxt = w_cur;
-    __amdgpu_buffer_rsrc_t x_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(X + (size_t)G12_TILE_M(work) * CE_BN * ldk), 0,
-                                                                     (int)(4 * piece_b), 0x00020000);
-    __amdgpu_buffer_rsrc_t x_nxt = x_cur;
-    bool has_next = false;
-#define G12_ISSUE(u)   /* step u of the current tile; u >= NT: step u - NT of the next tile (or a harmless re-load) */     \
-    {                                                                                                             \
-        const int u_ = (u);                                                                                       \
-        const bool nx_ = u_ >= NT && has_next;                                                                    \
-        const unsigned ks_ = (unsigned)(u_ < NT ? u_ : (has_next ? u_ - NT : NT - 1)) * 128u;                     \
-        const unsigned ws_ = (nx_ ? w_nxt : w_cur) + ks_;                                                         \
-        char* st_ = smem + (u_ % 3) * CE_STAGE_BYTES;                                                             \
-        ce_bdma(w_rs, voff, ws_, st_, wid);                                                                       \
-        ce_bdma(w_rs, voff, ws_ + piece_b, st_ + 8192, wid);                                                      \
-        if (nx_) {                                                                                                \
-            ce_bdma(x_nxt, voff, ks_, st_ + CE_W_TILE, wid);                                                      \
-            ce_bdma(x_nxt, voff, ks_ + piece_b, st_ + CE_W_TILE + 8192, wid);                                     \
-            ce_bdma(x_nxt, voff, ks_ + 2 * piece_b, st_ + CE_W_TILE + 2 * 8192, wid);                             \
-            ce_bdma(x_nxt, voff, ks_ + 3 * piece_b, st_ + CE_W_TILE + 3 * 8192, wid);                             \
-        } else {                                                                                                  \
-            ce_bdma(x_cur, voff, ks_, st_ + CE_W_TILE, wid);                                                      \
-            ce_bdma(x_cur, voff, ks_ + piece_b, st_ + CE_W_TILE + 8192, wid);                                     \
-            ce_bdma(x_cur, voff, ks_ + 2 * piece_b, st_ + CE_W_TILE + 2 * 8192, wid);                             \
-            ce_bdma(x_cur, voff, ks_ + 3 * piece_b, st_ + CE_W_TILE + 3 * 8192, wid);                             \
-        }                                                                                                         \
-    }
-#ifdef G12_PROBE_LOOSE_WAIT     // timing experiment only (RACY): the counted waits allow 4 more operations in flight
-#define G12_WAIT(n)                                                                                               \
-    { if ((n) == 6) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");                                             \
-      else if ((n) == 8) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                                        \
-      else asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); }
-#else
-#define G12_WAIT(n)   /* n is a compile-time constant after unrolling: 6, 8 or 10 */                              \
-    { if ((n) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                              \
-      else if ((n) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                         \
-      else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
-#endif
-    // ---- deferred-store plan of the PREVIOUS tile (see the header comment)
-    const float* const lbias = reinterpret_cast<const float*>(smem + CE_GEMM_LDS);
-    const int ldo = 2 * (KIND == G12_GELU ? N : hidden);                  // halfs per output row (Q rows / FFN activations)
-    const unsigned kvp_b = (unsigned)(kv_plane * sizeof(half_t));         // hi plane -> lo plane of K / V, bytes
-    const __amdgpu_buffer_rsrc_t null_rs = __builtin_amdgcn_make_buffer_rsrc(out16 ? out16 : kv16, 0, 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t kv_rs = __builtin_amdgcn_make_buffer_rsrc(kv16 ? kv16 : out16, 0, (int)(G12_PROBE_BYTES(2u * kvp_b)), 0x00020000);
-    __amdgpu_buffer_rsrc_t p_rs = null_rs;
-    unsigned p_so[4] = {0u, 0u, 0u, 0u};                                  // scalar byte offsets (per token block j / key block kl)
-    unsigned p_lp[4] = {0u, 0u, 0u, 0u};                                  // K / V: packed rows of the pair of token block j / key block kl
-    unsigned p_vo[4];                                                     // per-lane byte offsets
-    const unsigned vo_q = (unsigned)(fr * ldo * sizeof(half_t) + fq * 16);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) p_vo[j] = KIND == G12_K ? G12_DROP : (KIND == G12_V ? (unsigned)lane * 16u : vo_q);
-    int rp[4] = {0, 0, 0, 0}, po[4] = {0, 0, 0, 0}, pn[4] = {0, 0, 0, 0};   // this tile's (pair, offsets), fetched in steps 8 and 9
-    f32x4 acc[4][4], pacc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    uint32_t ph[4] = {0u, 0u, 0u, 0u}, pl[4] = {0u, 0u, 0u, 0u};          // the pair of quads being assembled
-    // unit u of the previous tile -> pacc quad; pair p = u >> 1 -> one 16-B hi + one 16-B lo store
-#define G12_UNIT(u)                                                                                               \
-    {                                                                                                             \
-        const int u_ = (u);                                                                                       \
-        f32x4 q_ = KIND == G12_V ? pacc[u_ >> 2][u_ & 3] : pacc[u_ & 3][u_ >> 2];                                 \
-        asm volatile("" : "+v"(q_));          /* the conversion stays inside this K-step ... */                  \
-        g12_split<KIND == G12_GELU>(q_, ph[(u_ & 1) * 2], ph[(u_ & 1) * 2 + 1], pl[(u_ & 1) * 2], pl[(u_ & 1) * 2 + 1]); \
-        if (!(u_ & 1)) asm volatile("" : "+v"(ph[0]), "+v"(ph[1]), "+v"(pl[0]), "+v"(pl[1]));   /* ... on both sides */ \
-        if (u_ & 1) {                                                                                             \
-            const int p_ = u_ >> 1;                                                                               \
-            const u32x4 hv_ = {ph[0], ph[1], ph[2], ph[3]}, lv_ = {pl[0], pl[1], pl[2], pl[3]};                   \
-            if (KIND == G12_V) {                                                                                  \
-                const int i_ = p_ >> 1, kl_ = p_ & 1;                                                             \
-                const unsigned so_ = p_so[kl_] + (unsigned)(i_ >> 1) * p_lp[kl_] * 64u + (unsigned)(i_ & 1) * 1024u; \
-                __builtin_amdgcn_raw_buffer_store_b128(hv_, p_rs, p_vo[kl_], so_, G12_NT);                        \
-                __builtin_amdgcn_raw_buffer_store_b128(lv_, p_rs, p_vo[kl_], so_ + kvp_b, G12_NT);                \
-            } else if (KIND == G12_K) {                                                                           \
-                const int j_ = p_ >> 1, ip_ = p_ & 1;            /* head head0 + ip, dims fq*8 .. +8: lane' = lane */ \
-                const unsigned so_ = p_so[j_] + (unsigned)ip_ * p_lp[j_] * 64u;                                   \
-                __builtin_amdgcn_raw_buffer_store_b128(hv_, p_rs, p_vo[j_], so_, G12_NT);                         \
-                __builtin_amdgcn_raw_buffer_store_b128(lv_, p_rs, p_vo[j_], so_ + kvp_b, G12_NT);                 \
-            } else {                                                                                              \
-                const int j_ = p_ >> 1, ip_ = p_ & 1;                                                             \
-                __builtin_amdgcn_raw_buffer_store_b128(hv_, p_rs, p_vo[0] + ip_ * 128, p_so[j_], G12_NT);         \
-                __builtin_amdgcn_raw_buffer_store_b128(lv_, p_rs, p_vo[0] + ip_ * 128 + 64, p_so[j_], G12_NT);    \
-            }                                                                                                     \
-        }                                                                                                         \
-    }
-    // plan for the tile (m0, n0) that has just finished; its (pair, offsets) are in rp / po / pn
-#define G12_PLAN(m0, n0)                                                                                          \
-    {                                                                                                             \
-        const int mb_ = (m0) + wn * 64, nb_ = (n0) + wm * 64;                                                     \
-        if (KIND == G12_Q || KIND == G12_GELU) {                                                                  \
-            p_rs = __builtin_amdgcn_make_buffer_rsrc(out16 + (size_t)G12_PROBE_ROW(mb_) * ldo, 0, (int)(G12_PROBE_BYTES(64 * ldo * sizeof(half_t))), 0x00020000); \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
-                p_so[j] = (unsigned)(((nb_ >> 5) * 64 + j * 16 * ldo) * sizeof(half_t));                          \
-        } else if (KIND == G12_K) {                                                                               \
-            p_rs = kv_rs;                                                                                         \
-            const unsigned head0_ = (unsigned)((nb_ - hidden) >> 5);                                              \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                       \
-                const unsigned lp_ = (unsigned)(pn[j] - po[j]), t16_ = (unsigned)((mb_ + j * 16 - po[j]) >> 4);   \
-                p_so[j] = (((unsigned)po[j] * (unsigned)heads + head0_ * lp_) * 32u + t16_ * 512u) * 2u;          \
-                p_lp[j] = lp_;                                                                                    \
-                p_vo[j] = rp[j] >= 0 ? (unsigned)lane * 16u : G12_DROP;                                           \
-            }                                                                                                     \
-        } else {                                                                                                  \
-            p_rs = kv_rs;                                                                                         \
-            const unsigned head0_ = (unsigned)(nb_ >> 5);                                                         \
-            _Pragma("unroll") for (int kl = 0; kl < 2; ++kl) {                                                    \
-                const unsigned lp_ = (unsigned)(pn[kl] - po[kl]), kb_ = (unsigned)((mb_ + kl * 32 - po[kl]) >> 5); \
-                p_so[kl] = ((unsigned)po[kl] * (unsigned)heads + head0_ * lp_) * 64u + kb_ * 2048u;               \
-                p_lp[kl] = lp_;                                                                                   \
-                p_vo[kl] = rp[kl] >= 0 ? (unsigned)lane * 16u : G12_DROP;                                         \
-            }                                                                                                     \
-        }                                                                                                         \
-    }
-    G12_ISSUE(0)
-    G12_ISSUE(1)
-    {   // two dropped stores: the stream then looks like the steady state (2 stores follow the pieces of step 1) to the counted waits
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        __builtin_amdgcn_raw_buffer_store_b128(z, null_rs, 0u, 0u, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(z, null_rs, 16u, 0u, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    CE_BAR
-    if (lag) { CE_BAR }
-    for (;;) {
-        const int n0 = G12_TILE_N(work) * CE_BM, m0 = G12_TILE_M(work) * CE_BN;
-        const int nb = n0 + wm * 64, mb = m0 + wn * 64;
-        {
-            const int nx = work + n_slots;
-            has_next = G12_TILE_M(nx) * CE_BN < m_end;
-            if (has_next) {
-                w_nxt = (unsigned)((size_t)G12_TILE_N(nx) * CE_BM * ldk * sizeof(half_t));
-                x_nxt = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(X + (size_t)G12_TILE_M(nx) * CE_BN * ldk), 0, (int)(4 * piece_b), 0x00020000);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const char* st = smem + (t % 3) * CE_STAGE_BYTES;
-            if (KIND == G12_K || KIND == G12_V) {                 // scalar loads, retired by this step's lgkmcnt(0)
-                constexpr int nblk = KIND == G12_K ? 4 : 2, rows = KIND == G12_K ? 16 : 32;
-                if (t == 8) {
-#pragma unroll
-                    for (int j = 0; j < nblk; ++j) rp[j] = row_pair[mb + j * rows];
-                }
-                if (t == 9) {
-#pragma unroll
-                    for (int j = 0; j < nblk; ++j) { const int pr = rp[j] < 0 ? 0 : rp[j]; po[j] = pair_off[pr]; pn[j] = pair_off[pr + 1]; }
-                }
-            }
-            half8 ah[4], al[4], bh[4], bl[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ah[i] = *reinterpret_cast<const half8*>(st + a_base + i * 16 * 128 + off);
-                if (TERMS & 1) al[i] = *reinterpret_cast<const half8*>(st + a_base + i * 16 * 128 + off_lo);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bh[j] = *reinterpret_cast<const half8*>(st + b_base + j * 16 * 128 + off);
-                if (TERMS & 2) bl[j] = *reinterpret_cast<const half8*>(st + b_base + j * 16 * 128 + off_lo);
-            }
-            f32x4 bq[4];
-            if (t == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (KIND == G12_V) { const float b = lbias[nb + i * 16 + fr]; bq[i] = (f32x4){b, b, b, b}; }
-                    else bq[i] = *reinterpret_cast<const f32x4*>(lbias + nb + (i >> 1) * 32 + fq * 8 + (i & 1) * 4);
-                }
-            }
-            G12_ISSUE(t + 2)
-            // the previous tile's epilogue slice runs HERE, in the half of the K-step where the OTHER wave group issues its
-            // MFMAs (the two groups alternate between the barriers): its vector work fills the issue cycles those MFMAs leave
-            {
-                const int ub = (t / 3) * 4 + (t % 3 == 0 ? 0 : t % 3 + 1);
-                G12_UNIT(ub)
-                if (t % 3 == 0) G12_UNIT(ub + 1)
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lag) G12_WAIT(G12_STORES(t - 1) + 6 + G12_STORES(t))
-            CE_BAR
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 c = t == 0 ? bq[i] : acc[i][j];
-                    if (KIND == G12_V) {
-                        if (TERMS & 1) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], c, 0, 0, 0);
-                        if (TERMS & 2) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], c, 0, 0, 0);
-                    } else {
-                        if (TERMS & 1) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], c, 0, 0, 0);
-                        if (TERMS & 2) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], c, 0, 0, 0);
-                    }
-                    acc[i][j] = c;
-                }
-            __builtin_amdgcn_s_setprio(0);
-            if (!lag) G12_WAIT(G12_STORES(t - 1) + 6 + G12_STORES(t))
-            CE_BAR
-        }
-        // tile switch: no barrier, no wait - the stage ring and the two wave groups simply keep going
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pacc[i][j] = acc[i][j];
-        G12_PLAN(m0, n0)
-        if (!has_next) break;
-        work += n_slots;
-        w_cur = w_nxt;
-        x_cur = x_nxt;
-    }
-    if (!lag) { CE_BAR }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // clamped tail re-loads of the last tile: retire them before exit
-#pragma unroll
-    for (int u = 0; u < 16; ++u) G12_UNIT(u)                // the last tile's epilogue has no main loop to hide in
-#undef G12_TILE_M
-#undef G12_TILE_N
-#undef G12_ISSUE
-#undef G12_WAIT
-}
-
-// ---- the same GEMMs as TWO independent 4-wave workgroups per CU ------------------------------------------------------------
-// What the deferred epilogue above cannot hide are its STORES: a CU moves store data at ~14 B/clk (profiles/r02_k), a wave sits
-// in a store until the data is taken, and in the lock-step of two wave groups any such delay is on the critical path (measured:
-// the stores of a tile cost their full 128 KiB / 14 B/clk whether issued in a burst or spread over the K-steps). Two
-// workgroups that share nothing but the CU do overlap: while one is in its epilogue (vector work, stores) the other has the
-// matrix pipe to itself. 128 x 128 tiles, 4 waves of 64 x 64, two 32 KiB stages (one K-step of lead; the other workgroup
-// covers the exposed latency), ONE barrier per K-step, the epilogue straight from registers as in g12_body (same weight
-// permutation, same V launch, bias as the first MFMA's C operand). 70 KiB of LDS and <= 256 VGPRs: two workgroups per CU.
-#define G2_BN 128
-#define G2_STAGE (2 * 16384)                              // W: 128 rows x 128 B, X: 128 rows x 128 B of one K-step
-#define G2_LDS (2 * G2_STAGE + 1536 * 4)                  // + bias table
-template <int KIND, int TERMS>
-__device__ __forceinline__ void g2_body(char* smem, const half_t* __restrict__ W, const half_t* __restrict__ X, int N,
-                                        half_t* __restrict__ out16, half_t* __restrict__ kv16, size_t kv_plane, int hidden,
-                                        int heads, int m_end, const int32_t* __restrict__ row_pair,
-                                        const int32_t* __restrict__ pair_off, int work, int xcd, int n_slots, int n_ft) {
-    constexpr int K = 384, NT = 12;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 1, wn = wid & 1;
-#define G2_TILE_M(w) (((w) / n_ft) * 8 + xcd)
-#define G2_TILE_N(w) (KIND <= G12_K ? ((((w) % n_ft) >> 1) + (((w) % n_ft) & 1) * (n_ft >> 1)) : ((w) % n_ft))
-    const int sr = tid >> 3;                                          // 0..31: a DMA piece is 32 rows x 128 B
-    const int schunk = (tid & 7) ^ ((sr >> 1) & 7);
-    constexpr size_t ldk = (size_t)2 * K;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int sw = (fr >> 1) & 7;
-    const int off = fr * 128 + ((fq ^ sw) << 4), off_lo = fr * 128 + (((4 + fq) ^ sw) << 4);
-    const int a_base = wm * 64 * 128, b_base = 16384 + wn * 64 * 128;
-    const unsigned voff = (unsigned)(((size_t)sr * ldk + schunk * 8) * sizeof(half_t));
-    constexpr unsigned piece_b = (unsigned)(32 * ldk * sizeof(half_t));
-    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(W), 0, (int)((size_t)N * ldk * sizeof(half_t)), 0x00020000);
-    unsigned w_cur = (unsigned)((size_t)G2_TILE_N(work) * CE_BM * ldk * sizeof(half_t)), w_nxt = w_cur;
-    __amdgpu_buffer_rsrc_t x_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(X + (size_t)G2_TILE_M(work) * G2_BN * ldk), 0,
-                                                                     (int)(4 * piece_b), 0x00020000);
-    __amdgpu_buffer_rsrc_t x_nxt = x_cur;
-    bool has_next = false;
-#define G2_ISSUE(xr, wo, ks, stg)   /* K-step ks of tile (descriptor xr, weight offset wo) into stage stg */               \
-    {                                                                                                             \
-        char* st_ = smem + (stg) * G2_STAGE;                                                                      \
-        _Pragma("unroll") for (int p_ = 0; p_ < 4; ++p_) ce_bdma(w_rs, voff, (wo) + (unsigned)(ks) * 128u + p_ * piece_b, st_ + p_ * 4096, wid); \
-        _Pragma("unroll") for (int p_ = 0; p_ < 4; ++p_) ce_bdma(xr, voff, (unsigned)(ks) * 128u + p_ * piece_b, st_ + 16384 + p_ * 4096, wid); \
-    }
-    const float* const lbias = reinterpret_cast<const float*>(smem + 2 * G2_STAGE);
-    const int ldo = 2 * (KIND == G12_GELU ? N : hidden);
-    const unsigned kvp_b = (unsigned)(kv_plane * sizeof(half_t));
-    const __amdgpu_buffer_rsrc_t kv_rs = __builtin_amdgcn_make_buffer_rsrc(kv16 ? kv16 : out16, 0, (int)(G12_PROBE_BYTES(2u * kvp_b)), 0x00020000);
-    __amdgpu_buffer_rsrc_t p_rs = kv_rs;
-    unsigned p_so[4] = {0u, 0u, 0u, 0u}, p_lp[4] = {0u, 0u, 0u, 0u}, p_vo[4];
-    const unsigned vo_q = (unsigned)(fr * ldo * sizeof(half_t) + fq * 16);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) p_vo[j] = vo_q;
-    int rp[4] = {0, 0, 0, 0}, po[4] = {0, 0, 0, 0}, pn[4] = {0, 0, 0, 0};
-    uint32_t ph[4] = {0u, 0u, 0u, 0u}, pl[4] = {0u, 0u, 0u, 0u};
-    G2_ISSUE(x_cur, w_cur, 0, 0)
-    for (;;) {
-        const int n0 = G2_TILE_N(work) * CE_BM, m0 = G2_TILE_M(work) * G2_BN;
-        const int nb = n0 + wm * 64, mb = m0 + wn * 64;
-        {
-            const int nx = work + n_slots;
-            has_next = G2_TILE_M(nx) * G2_BN < m_end;
-            if (has_next) {
-                w_nxt = (unsigned)((size_t)G2_TILE_N(nx) * CE_BM * ldk * sizeof(half_t));
-                x_nxt = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(X + (size_t)G2_TILE_M(nx) * G2_BN * ldk), 0, (int)(4 * piece_b), 0x00020000);
-            }
-        }
-        f32x4 pacc[4][4];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const char* st = smem + (t & 1) * G2_STAGE;
-            if (KIND == G12_K || KIND == G12_V) {                 // scalar loads, retired by this step's lgkmcnt(0)
-                constexpr int nblk = KIND == G12_K ? 4 : 2, rows = KIND == G12_K ? 16 : 32;
-                if (t == 8) {
-#pragma unroll
-                    for (int j = 0; j < nblk; ++j) rp[j] = row_pair[mb + j * rows];
-                }
-                if (t == 9) {
-#pragma unroll
-                    for (int j = 0; j < nblk; ++j) { const int pr = rp[j] < 0 ? 0 : rp[j]; po[j] = pair_off[pr]; pn[j] = pair_off[pr + 1]; }
-                }
-            }
-            // step t has landed (this wave's pieces; at t = 0 the previous epilogue's stores retire here too); after the barrier
-            // every wave's pieces have, and every wave is past its reads of the other stage, which is refilled next
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            CE_BAR
-            if (t + 1 < NT) G2_ISSUE(x_cur, w_cur, t + 1, (t + 1) & 1)
-            else if (has_next) G2_ISSUE(x_nxt, w_nxt, 0, 0)
-            half8 ah[4], al[4], bh[4], bl[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ah[i] = *reinterpret_cast<const half8*>(st + a_base + i * 16 * 128 + off);
-                if (TERMS & 1) al[i] = *reinterpret_cast<const half8*>(st + a_base + i * 16 * 128 + off_lo);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bh[j] = *reinterpret_cast<const half8*>(st + b_base + j * 16 * 128 + off);
-                if (TERMS & 2) bl[j] = *reinterpret_cast<const half8*>(st + b_base + j * 16 * 128 + off_lo);
-            }
-            f32x4 bq[4];
-            if (t == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (KIND == G12_V) { const float b = lbias[nb + i * 16 + fr]; bq[i] = (f32x4){b, b, b, b}; }
-                    else bq[i] = *reinterpret_cast<const f32x4*>(lbias + nb + (i >> 1) * 32 + fq * 8 + (i & 1) * 4);
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 c = t == 0 ? bq[i] : pacc[i][j];
-                    if (KIND == G12_V) {
-                        if (TERMS & 1) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], c, 0, 0, 0);
-                        if (TERMS & 2) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], c, 0, 0, 0);
-                    } else {
-                        if (TERMS & 1) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], c, 0, 0, 0);
-                        if (TERMS & 2) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], c, 0, 0, 0);
-                    }
-                    pacc[i][j] = c;
-                }
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // epilogue from registers; step 0 of the next tile is in flight into stage 0 meanwhile
-        G12_PLAN(m0, n0)
-#pragma unroll
-        for (int u = 0; u < 16; ++u) G12_UNIT(u)
-        if (!has_next) break;
-        work += n_slots;
-        w_cur = w_nxt;
-        x_cur = x_nxt;
-    }
-#undef G2_TILE_M
-#undef G2_TILE_N
-#undef G2_ISSUE
-}
-#undef G12_UNIT
-#undef G12_PLAN
-
-// gridDim.x = 2 x CUs (a multiple of 16), 256 threads; other requirements as ce_gemm12_kernel
-template <int EPI, int TERMS>
-__global__ __launch_bounds__(256, 2) void ce_gemm2w_kernel(const half_t* __restrict__ W, const half_t* __restrict__ X, int N,
-                                                            const float* __restrict__ bias, half_t* __restrict__ out16,
-                                                            half_t* __restrict__ kv16, size_t kv_plane, int hidden, int heads,
-                                                            const int32_t* __restrict__ m_packed, const int32_t* __restrict__ row_pair,
-                                                            const int32_t* __restrict__ pair_off) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int n_ft = N / CE_BM;
-    const int m_end = m_packed[0];
-    const int xcd = blockIdx.x & 7, n_slots = gridDim.x >> 3;
-    const int work = blockIdx.x >> 3;
-    if (((work / n_ft) * 8 + xcd) * G2_BN >= m_end) return;
-    float* const lbias = reinterpret_cast<float*>(smem + 2 * G2_STAGE);
-    for (int i = threadIdx.x; i < N; i += 256) lbias[i] = bias[i];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // written before the first barrier of g2_body, read after it
-    if (EPI == EPI2_QK) {
-        if (work & 1) g2_body<G12_K, TERMS>(smem, W, X, N, out16, kv16, kv_plane, hidden, heads, m_end, row_pair, pair_off, work, xcd, n_slots, n_ft);
-        else g2_body<G12_Q, TERMS>(smem, W, X, N, out16, kv16, kv_plane, hidden, heads, m_end, row_pair, pair_off, work, xcd, n_slots, n_ft);
-    } else if (EPI == EPI2_V) {
-        g2_body<G12_V, TERMS>(smem, W, X, N, out16, kv16, kv_plane, hidden, heads, m_end, row_pair, pair_off, work, xcd, n_slots, n_ft);
-    } else {
-        g2_body<G12_GELU, TERMS>(smem, W, X, N, out16, kv16, kv_plane, hidden, heads, m_end, row_pair, pair_off, work, xcd, n_slots, n_ft);
-    }
-}
-
-// N % 128 == 0 (EPI2_QK: N = 2 x hidden, Q tiles then K tiles, N / 128 even), M_pad % 256 == 0, gridDim.x % 16 == 0, N <= 1536
-template <int EPI, int TERMS>
-__global__ __launch_bounds__(512) void ce_gemm12_kernel(const half_t* __restrict__ W, const half_t* __restrict__ X, int N,
-                                                         const float* __restrict__ bias, half_t* __restrict__ out16,
-                                                         half_t* __restrict__ kv16, size_t kv_plane, int hidden, int heads,
-                                                         const int32_t* __restrict__ m_packed, const int32_t* __restrict__ row_pair,
-                                                         const int32_t* __restrict__ pair_off) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int n_ft = N / CE_BM;
-    const int m_end = m_packed[0];
-    const int xcd = blockIdx.x & 7, n_slots = gridDim.x >> 3;
-    const int work = blockIdx.x >> 3;
-    if (((work / n_ft) * 8 + xcd) * CE_BN >= m_end) return;
-    float* const lbias = reinterpret_cast<float*>(smem + CE_GEMM_LDS);
-    for (int i = threadIdx.x; i < N; i += 512) lbias[i] = bias[i];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // written before the first barrier of g12_body, read after it
-    if (EPI == EPI2_QK) {
-        // feature tiles are walked Q0 K0 Q1 K1 ...: with n_ft and n_slots even a workgroup's tiles are all Q or all K
-        if (work & 1) g12_body<G12_K, TERMS>(smem, W, X, N, out16, kv16, kv_plane, hidden, heads, m_end, row_pair, pair_off, work, xcd, n_slots, n_ft);
-        else g12_body<G12_Q, TERMS>(smem, W, X, N, out16, kv16, kv_plane, hidden, heads, m_end, row_pair, pair_off, work, xcd, n_slots, n_ft);
-    } else if (EPI == EPI2_V) {
-        g12_body<G12_V, TERMS>(smem, W, X, N, out16, kv16, kv_plane, hidden, heads, m_end, row_pair, pair_off, work, xcd, n_slots, n_ft);
-    } else {
-        g12_body<G12_GELU, TERMS>(smem, W, X, N, out16, kv16, kv_plane, hidden, heads, m_end, row_pair, pair_off, work, xcd, n_slots, n_ft);
-    }
 }
 
 // ---- out-proj / FFN-down with bias + residual + LayerNorm in the epilogue (hidden = 384) -------------------------------
@@ -1244,6 +730,13 @@ __global__ __launch_bounds__(256) void ce_layernorm_kernel(const float* __restri
 // next MFMA if the 32 k-slots of a key block are numbered (fq, e) -> key fq*4 + e (e < 4) | 16 + fq*4 + e - 4: V is
 // stored in that slot order, so P goes registers -> MFMA without touching LDS. Online (flash-style) softmax over
 // 32-key blocks in the exp2 domain; key blocks past the pair's length are skipped, the boundary block is masked.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t ce_pk(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+__device__ __forceinline__ float ce_trunc10(float e) {     // e with the mantissa cut to 10 bits: exactly a fp16 value
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, e) & 0xFFFFE000u);
+}
 __device__ __forceinline__ void ce_dma_at(const half_t* __restrict__ g, char* lds_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_uniform, 16, 0, 0);
@@ -1396,24 +889,15 @@ __global__ __launch_bounds__(256) void ce_pool_classify_kernel(const half_t* __r
     if (tid == 0) logits[pair] = part[0] + part[1] + part[2] + part[3] + bc[0];
 }
 
-// perm_rows > 0: the first perm_rows rows (a multiple of 64) are stored permuted inside each 64-row block, stored row
-// i*16 + p <- source row (i>>1)*32 + (p>>2)*8 + (i&1)*4 + (p&3): MFMA row blocks 2g and 2g+1 of ce_gemm12_kernel then give lane
-// group fq the 8 consecutive features g*32 + fq*8 .. +8, and the four lane groups together one whole 32-feature K group
-__global__ void ce_f32_split_kernel(const float* __restrict__ in, half_t* __restrict__ out, int64_t n, int cols, int64_t perm_rows) {
+__global__ void ce_f32_split_kernel(const float* __restrict__ in, half_t* __restrict__ out, int64_t n, int cols) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const int64_t row = i / cols;
         const int c = (int)(i % cols);
-        int64_t src = row;
-        if (row < perm_rows) {
-            const int s64 = (int)(row & 63), bi = s64 >> 4, p16 = s64 & 15;
-            src = (row & ~(int64_t)63) + (bi >> 1) * 32 + (p16 >> 2) * 8 + (bi & 1) * 4 + (p16 & 3);
-        }
-        const float v = in[src * cols + c];
-        const half_t hi = (half_t)v;
+        const half_t hi = (half_t)in[i];
         half_t* o = out + row * 2 * cols + SPLIT_IDX(c);   // split-row layout: [hi 32 | lo 32] per 32-element K group
         o[0] = hi;
-        o[32] = (half_t)(v - (float)hi);
+        o[32] = (half_t)(in[i] - (float)hi);
     }
 }
 
@@ -1444,8 +928,7 @@ static int up_f32(rag_ctx* h, rag_ce_model* m, const float* src, size_t n, float
 }
 
 // rows of several fp32 host matrices (same `cols`) concatenated -> one fp16 device matrix
-static int up_f16_concat(rag_ctx* h, rag_ce_model* m, std::vector<const float*> srcs, size_t rows_each, size_t cols, half_t** dst,
-                         size_t perm_rows = 0) {
+static int up_f16_concat(rag_ctx* h, rag_ce_model* m, std::vector<const float*> srcs, size_t rows_each, size_t cols, half_t** dst) {
     const size_t n_each = rows_each * cols, total = n_each * srcs.size();
     float* tmp = nullptr;
     HIP_TRY(h, hipMalloc(&tmp, total * sizeof(float)));
@@ -1453,7 +936,7 @@ static int up_f16_concat(rag_ctx* h, rag_ce_model* m, std::vector<const float*> 
     m->allocs.push_back(*dst);
     for (size_t i = 0; i < srcs.size(); ++i)
         HIP_TRY(h, hipMemcpyAsync(tmp + i * n_each, srcs[i], n_each * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(ce_f32_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, tmp, *dst, (int64_t)total, (int)cols, (int64_t)perm_rows);
+    hipLaunchKernelGGL(ce_f32_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, tmp, *dst, (int64_t)total, (int)cols);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     hipFree(tmp);
     return RAG_OK;
@@ -1484,7 +967,6 @@ int ce_load_host(rag_ctx* h, const rag_ce_config* cfg, const float* const* T, in
         const float* const* t = T + 5 + 16 * l;
         auto& ly = m->layers[l];
         if ((rc = up_f16_concat(h, m, {t[0], t[2], t[4]}, H, H, &ly.wqkv))) return rc;
-        if (H == 384 && (rc = up_f16_concat(h, m, {t[0], t[2], t[4]}, H, H, &ly.wqkv_p, 2 * H))) return rc;
         std::vector<float> bq(3 * H);
         std::memcpy(bq.data(), t[1], H * 4); std::memcpy(bq.data() + H, t[3], H * 4); std::memcpy(bq.data() + 2 * H, t[5], H * 4);
         if ((rc = up_f32(h, m, bq.data(), 3 * H, &ly.bqkv))) return rc;
@@ -1494,7 +976,6 @@ int ce_load_host(rag_ctx* h, const rag_ce_config* cfg, const float* const* T, in
         if ((rc = up_f32(h, m, t[8], H, &ly.ln1_g))) return rc;
         if ((rc = up_f32(h, m, t[9], H, &ly.ln1_b))) return rc;
         if ((rc = up_f16_concat(h, m, {t[10]}, F, H, &ly.w1))) return rc;
-        if (H == 384 && (rc = up_f16_concat(h, m, {t[10]}, F, H, &ly.w1_p, F))) return rc;
         if ((rc = up_f32(h, m, t[11], F, &ly.b1))) return rc;
         if ((rc = up_f16_concat(h, m, {t[12]}, H, F, &ly.w2))) return rc;
         if ((rc = up_f32(h, m, t[13], H, &ly.b2))) return rc;
@@ -1568,30 +1049,6 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
  // bias + residual + LayerNorm in the GEMM epilogue when the geometry allows (hidden = 384, K a multiple of 192: the
     // MiniLM-L-6 shape); RAG_CE_NO_FUSED_LN=1 forces the stand-alone path (parity test of both)
     const bool fused_ln = H == 384 && F % 192 == 0 && !getenv("RAG_CE_NO_FUSED_LN");
-    // K = 384 GEMMs with the deferred epilogue (ce_gemm12_kernel): the MiniLM shape; RAG_CE_OLD_GEMM=1 keeps ce_gemm_kernel
-    // (parity test of both). K / V stores go through ONE buffer descriptor per tensor: both planes must stay below G12_DROP.
-    static const unsigned n_cu12 = [] { int d = 0, n = 0; hipGetDevice(&d); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return (unsigned)(n >= 16 ? n / 16 * 16 : 256); }();
-    const bool fast12 = H == 384 && F <= 1536 && m->layers[0].wqkv_p && (uint64_t)pp.kv * 4 < 0xE0000000ull && !getenv("RAG_CE_OLD_GEMM");
-    const bool deferred = fast12 && getenv("RAG_CE_DEFERRED_GEMM");       // ce_gemm12_kernel instead of ce_gemm2w_kernel (kept for the A/B)
-    if (fast12 && !h->attr_ce_gemm12) {
-#define CE_ATTR12(E, T) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm12_kernel<E, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G12_LDS)); \
-                        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm2w_kernel<E, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2_LDS));
-#define CE_ATTR12_4(E) CE_ATTR12(E, 0) CE_ATTR12(E, 1) CE_ATTR12(E, 2) CE_ATTR12(E, 3)
-        CE_ATTR12_4(EPI2_QK) CE_ATTR12_4(EPI2_V) CE_ATTR12_4(EPI2_GELU)
-        h->attr_ce_gemm12 = true;
-    }
-#define CE_GEMM12(E, T, ...)                                                                                      \
-    if (deferred) switch (T) {                                                                                    \
-        case 0: hipLaunchKernelGGL((ce_gemm12_kernel<E, 0>), dim3(n_cu12), blk, G12_LDS, st, __VA_ARGS__); break; \
-        case 1: hipLaunchKernelGGL((ce_gemm12_kernel<E, 1>), dim3(n_cu12), blk, G12_LDS, st, __VA_ARGS__); break; \
-        case 2: hipLaunchKernelGGL((ce_gemm12_kernel<E, 2>), dim3(n_cu12), blk, G12_LDS, st, __VA_ARGS__); break; \
-        default: hipLaunchKernelGGL((ce_gemm12_kernel<E, 3>), dim3(n_cu12), blk, G12_LDS, st, __VA_ARGS__); break; \
-    } else switch (T) {                                                                                           \
-        case 0: hipLaunchKernelGGL((ce_gemm2w_kernel<E, 0>), dim3(2 * n_cu12), dim3(256), G2_LDS, st, __VA_ARGS__); break; \
-        case 1: hipLaunchKernelGGL((ce_gemm2w_kernel<E, 1>), dim3(2 * n_cu12), dim3(256), G2_LDS, st, __VA_ARGS__); break; \
-        case 2: hipLaunchKernelGGL((ce_gemm2w_kernel<E, 2>), dim3(2 * n_cu12), dim3(256), G2_LDS, st, __VA_ARGS__); break; \
-        default: hipLaunchKernelGGL((ce_gemm2w_kernel<E, 3>), dim3(2 * n_cu12), dim3(256), G2_LDS, st, __VA_ARGS__); break; \
-    }
     if (!fused_ln && !m->y32) HIP_TRY(h, hipMalloc(&m->y32, (size_t)Mp * H * 4));
     if (fused_ln && !h->attr_ce_gemm_ln) {
 #define CE_ATTR_LN(T) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_ln_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LNG_LDS));
@@ -1623,16 +1080,9 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     const half_t* nullh = nullptr;
     for (int l = 0; l < m->cfg.layers; ++l) {
         auto& ly = m->layers[l];
-        if (fast12) {
-            CE_GEMM12(EPI2_QK, terms[0], (const half_t*)ly.wqkv_p, (const half_t*)m->x16, 2 * H, (const float*)ly.bqkv, m->q16, m->kf16, pp.kv, H,
-                      m->cfg.heads, m->m_packed, m->row_pair, m->pair_off)
-            CE_GEMM12(EPI2_V, terms[0], (const half_t*)(ly.wqkv_p + (size_t)2 * H * 2 * H), (const half_t*)m->x16, H, (const float*)(ly.bqkv + 2 * H), (half_t*)nullptr,
-                      m->vf16, pp.kv, H, m->cfg.heads, m->m_packed, m->row_pair, m->pair_off)
-        } else {
-            CE_GEMM(EPI_QKV, terms[0], ly.wqkv, m->x16,
-                    3 * H, H, ly.bqkv, (const half_t*)nullptr, (float*)nullptr, m->q16, m->kf16, m->vf16, pp.kv, H,
-                    m->cfg.heads, m->m_packed, m->row_pair, m->pair_off)
-        }
+        CE_GEMM(EPI_QKV, terms[0], ly.wqkv, m->x16,
+                3 * H, H, ly.bqkv, (const half_t*)nullptr, (float*)nullptr, m->q16, m->kf16, m->vf16, pp.kv, H,
+                m->cfg.heads, m->m_packed, m->row_pair, m->pair_off)
         {
             const int rc = L == 32 ? launch_attention<1>(h, m, P, L, pp, st) : launch_attention<2>(h, m, P, L, pp, st);
             if (rc != RAG_OK) return rc;
@@ -1646,14 +1096,9 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
                     m->row_pair, m->pair_off)
             CE_PER_DISPATCH(LN1)
         }
-        if (fast12) {
-            CE_GEMM12(EPI2_GELU, terms[2], (const half_t*)ly.w1_p, (const half_t*)m->x16, F, (const float*)ly.b1, m->h16, (half_t*)nullptr, (size_t)0, H,
-                      m->cfg.heads, m->m_packed, m->row_pair, m->pair_off)
-        } else {
-            CE_GEMM(EPI_GELU, terms[2], ly.w1, m->x16, F, H,
-                    ly.b1, (const half_t*)nullptr, (float*)nullptr, m->h16, (half_t*)nullptr, (half_t*)nullptr, (size_t)0,
-                    H, m->cfg.heads, m->m_packed, m->row_pair, m->pair_off)
-        }
+        CE_GEMM(EPI_GELU, terms[2], ly.w1, m->x16, F, H,
+                ly.b1, (const half_t*)nullptr, (float*)nullptr, m->h16, (half_t*)nullptr, (half_t*)nullptr, (size_t)0,
+                H, m->cfg.heads, m->m_packed, m->row_pair, m->pair_off)
 #define LN2(PER) launch_ln<PER>(m, m->y32, ly.ln2_g, ly.ln2_b, M, st)
         if (fused_ln) {
             CE_GEMM_LN(terms[3], ly.w2, m->h16, F, ly.b2, ly.ln2_g, ly.ln2_b, eps, m->x16, m->m_packed)

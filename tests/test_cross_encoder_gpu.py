@@ -123,36 +123,6 @@ def test_small_multi_chunk_loop(eng, monkeypatch):
     assert np.abs(many[sel] - exp).max() < LOGIT_TOL
 
 
-def test_k384_gemm_variants_agree(eng, monkeypatch):
-    """hidden = 384 runs Q|K, V and FFN-up through ce_gemm2w_kernel (two 4-wave workgroups per CU, epilogue straight from
-    registers, permuted weight rows, V as its own launch); RAG_CE_DEFERRED_GEMM=1 selects ce_gemm12_kernel (epilogue of tile
-    i-1 inside the main loop of tile i), RAG_CE_OLD_GEMM=1 the round-1 ce_gemm_kernel. 700 pairs at L = 128 = ~60k packed rows,
-    so every persistent workgroup walks several tiles in all three. All must match the float64 oracle; between them they differ
-    only by rounding (hi by truncation instead of round-to-nearest, bias as the first addend)."""
-    cfg = B.minilm_config()
-    w = B.seeded_weights(cfg, 99)
-    load_model(eng, cfg, w)
-    rng = np.random.default_rng(700)
-    P, L = 700, 128
-    lens = rng.integers(2, L + 1, P).astype(np.int32)
-    lens[[0, 5, 699]] = [L, 1, L]
-    ids, tt = _random_pairs(rng, cfg, P, L, lens)
-    new = eng.ce_score(ids, tt, lens)
-    monkeypatch.setenv("RAG_CE_DEFERRED_GEMM", "1")
-    deferred = eng.ce_score(ids, tt, lens)
-    monkeypatch.delenv("RAG_CE_DEFERRED_GEMM")
-    monkeypatch.setenv("RAG_CE_OLD_GEMM", "1")
-    old = eng.ce_score(ids, tt, lens)
-    monkeypatch.delenv("RAG_CE_OLD_GEMM")
-    assert np.isfinite(new).all() and np.isfinite(old).all() and np.isfinite(deferred).all()
-    np.testing.assert_array_equal(new, deferred)        # same arithmetic in the same order, different schedule
-    assert np.abs(new - old).max() < 2e-3, np.abs(new - old).max()
-    sel = [0, 1, 5, 350, 698, 699]
-    exp = B.forward_logits(w, cfg, ids[sel].astype(np.int64), tt[sel].astype(np.int64), lens[sel], fast_erf=True)
-    assert np.abs(new[sel] - exp).max() < LOGIT_TOL, (new[sel], exp)
-    assert np.abs(old[sel] - exp).max() < LOGIT_TOL, (old[sel], exp)
-
-
 def test_reranker_from_local_dir(eng, tmp_path):
     """End to end through the mirror class: local checkpoint dir -> tokeniser -> HIP forward -> sigmoid -> sort."""
     from safetensors.numpy import save_file

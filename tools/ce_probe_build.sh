@@ -6,12 +6,9 @@ cd "$(dirname "$0")/../optimized-rag_amd/csrc"
 mkdir -p ../../tools/bin
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -Wno-unused-result"
 OTHERS=$(ls *.o | grep -v cross_encoder.o)
-VARIANTS=${CE_PROBE_VARIANTS:-'NO_MFMA NO_DMA NO_EPI NO_MFMA+NO_EPI NO_DMA+NO_EPI G12_NO_STORE G12_NO_GELU G12_NO_STORE+G12_NO_GELU'}
-for vv in $VARIANTS; do
-  v=$(echo "$vv" | sed 's/+/ -DCE_PROBE_/g; s/CE_PROBE_G12_/G12_PROBE_/g')
-  case "$v" in G12_*) v=$(echo "$v" | sed 's/^G12_/G12_PROBE_/'); D="-D$v";; *) D="-DCE_PROBE_$v";; esac
-  name=$(echo "$vv" | tr '+' '_')
-  /opt/rocm/bin/hipcc $FLAGS $D -c cross_encoder.hip -o /tmp/ce_$name.o
+for v in NO_MFMA NO_DMA NO_EPI "NO_MFMA -DCE_PROBE_NO_EPI" "NO_DMA -DCE_PROBE_NO_EPI"; do
+  name=$(echo "$v" | tr -d ' ' | sed 's/-DCE_PROBE_/_/g')
+  /opt/rocm/bin/hipcc $FLAGS -DCE_PROBE_$v -c cross_encoder.hip -o /tmp/ce_$name.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/bin/librag_$name.so /tmp/ce_$name.o $OTHERS
   echo built $name
 done
