@@ -487,8 +487,16 @@ __global__ __launch_bounds__(512) void ce_gemm_ln_kernel(const half_t* __restric
             // here would only wait for those stores)
             if (first || t > 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             CE_BAR
-            LNG_ISSUE_W(t + 1)
-            LNG_ISSUE_X(t + 2)
+            // the 8 DMA pieces of this step are issued one or two at a time BEHIND the MFMA groups below: a piece costs its wave
+            // 60-180 issue cycles, and with all eight up front both waves of a SIMD sat in them at the same time, the matrix pipe
+            // idle (W(t+1) first: it is needed one step from now; the two X(t+2) pieces last)
+            const int wu_ = t + 1, xu_ = t + 2;
+            const unsigned wks_ = (unsigned)(wu_ < nt ? wu_ : wu_ - nt) * 128u;
+            char* const wst_ = wring + (wu_ & 1) * LNG_W_STAGE;
+            const bool xnx_ = xu_ >= nt && has_next;
+            const unsigned xks_ = (unsigned)(xu_ < nt ? xu_ : (has_next ? xu_ - nt : nt - 1)) * 128u;
+            char* const xst_ = xring + (xu_ % 3) * LNG_X_STAGE;
+            const __amdgpu_buffer_rsrc_t xrs_ = xnx_ ? x_nxt : x_cur;
             const char* ws = wring + (t & 1) * LNG_W_STAGE + a_base;
             const char* xs = xring + (t % 3) * LNG_X_STAGE + b_base;
             half8 bh[2], bl[2];
@@ -497,27 +505,41 @@ __global__ __launch_bounds__(512) void ce_gemm_ln_kernel(const half_t* __restric
                 bh[j] = *reinterpret_cast<const half8*>(xs + j * 16 * 128 + off_hi);
                 if (TERMS & 2) bl[j] = *reinterpret_cast<const half8*>(xs + j * 16 * 128 + off_lo);
             }
+            // The wave's 12 feature blocks go through TWO fragment slots of two blocks each (32 VGPRs, as one third of them did
+            // before), refilled right behind the MFMAs that consumed them: the reads of pair p+2 fly under the 12 MFMAs of pair
+            // p+1, so a K-step exposes one LDS round trip instead of three (the waits are the compiler's counted lgkmcnt).
+            half8 ah[2][2], al[2][2];
+#define LNG_READ_PAIR(p, s)                                                                                           \
+            _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) {                                                        \
+                ah[s][ii] = *reinterpret_cast<const half8*>(ws + ((p) * 2 + ii) * 16 * 128 + off_hi);                 \
+                if (TERMS & 1) al[s][ii] = *reinterpret_cast<const half8*>(ws + ((p) * 2 + ii) * 16 * 128 + off_lo);  \
+            }
+            LNG_READ_PAIR(0, 0)
+            LNG_READ_PAIR(1, 1)
 #pragma unroll
-            for (int part = 0; part < 3; ++part) {               // 4 of the wave's 12 feature blocks at a time (32 fragment VGPRs)
-                half8 ah[4], al[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    ah[i] = *reinterpret_cast<const half8*>(ws + (part * 4 + i) * 16 * 128 + off_hi);
-                    if (TERMS & 1) al[i] = *reinterpret_cast<const half8*>(ws + (part * 4 + i) * 16 * 128 + off_lo);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int p = 0; p < 6; ++p) {
+                __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        f32x4& a = acc[part * 4 + i][j];
-                        if (TERMS & 1) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], a, 0, 0, 0);
-                        if (TERMS & 2) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], a, 0, 0, 0);
+                        f32x4& a = acc[p * 2 + ii][j];
+                        if (TERMS & 1) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[p & 1][ii], bh[j], a, 0, 0, 0);
+                        if (TERMS & 2) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p & 1][ii], bl[j], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p & 1][ii], bh[j], a, 0, 0, 0);
                     }
                 __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (p + 2 < 6) LNG_READ_PAIR(p + 2, p & 1)
+                if (p < 3) {
+                    lng_dma(w_rs, voff, (2 * p) * piece_b + wks_, wst_ + (2 * p) * 8192, wid);
+                    lng_dma(w_rs, voff, (2 * p + 1) * piece_b + wks_, wst_ + (2 * p + 1) * 8192, wid);
+                } else if (p < 5) {
+                    lng_dma(xrs_, voff, (p - 3) * piece_b + xks_, xst_ + (p - 3) * 8192, wid);
+                }
             }
+#undef LNG_READ_PAIR
         }
         // ---- epilogue. acc[i][j][r] = sum for feature wm*192 + i*16 + fq*4 + r, token m0 + wn*32 + j*16 + fr.
         // Every wave is past its reads of W stage (nt-1)&1 = 1 after this barrier; its refill (step 1 of the next tile) comes
