@@ -446,7 +446,63 @@ __global__ __launch_bounds__(512) void dense_emit_persist_kernel(int n_vblocks, 
 //          final stage: n_sorted = m; bound = +inf if the buffer ever overflowed (candidates were lost), else -inf
 // ------------------------------------------------------------------------------------------------
 #define SEL_REG 32                      // keys held in registers per lane (covers 2048 candidates)
+#define SEL_REG_SMALL 8                 // a thresholded stage usually leaves ~k x growth + k keys: 512 cover it
 #define SELECT_LDS_BYTES (4 * (RAG_CAND_CAP - SEL_REG * 64) * 8)
+// One wave, one query. NREG = registers of keys per lane: the pivot search costs 64 bit-steps x NREG ballots whatever n_in is,
+// so the common small case runs with a quarter of the registers (3 of the 4 selects of a 1M-row search: 16 -> 5 us each).
+template <int NREG>
+__device__ __forceinline__ void select_wave(uint64_t* __restrict__ c, uint64_t* __restrict__ spill, int n_in, int k, float two_eps,
+                                            float tau_in, int lane, float& tau_new, int& n_top) {
+    // keys: first NREG*64 in registers (element e*64 + lane), the rest (rare) in this wave's LDS slice
+    uint64_t kreg[NREG];
+#pragma unroll
+    for (int e = 0; e < NREG; ++e) {
+        const int i = e * 64 + lane;
+        kreg[e] = i < n_in ? c[i] : 0ull;
+    }
+    const int n_spill = max(0, n_in - NREG * 64);
+    const int n_spill_pad = (n_spill + 63) & ~63;
+    for (int i = lane; i < n_spill; i += 64) spill[i] = c[NREG * 64 + i];
+    int n_valid = 0;
+#pragma unroll
+    for (int e = 0; e < NREG; ++e) n_valid += __popcll(__ballot(kreg[e] != 0ull));
+    for (int i = lane; i < n_spill_pad; i += 64) n_valid += __popcll(__ballot(i < n_spill && spill[i] != 0ull));
+    tau_new = tau_in;
+    if (n_valid >= k) {
+        uint64_t pivot = 0ull;                               // becomes (a lower bound of) the k-th largest key
+        for (int bit = 63; bit >= 0; --bit) {
+            const uint64_t trial = pivot | (1ull << bit);
+            int ge = 0;
+#pragma unroll
+            for (int e = 0; e < NREG; ++e) ge += __popcll(__ballot(kreg[e] >= trial));
+            for (int i = lane; i < n_spill_pad; i += 64) ge += __popcll(__ballot(i < n_spill && spill[i] >= trial));
+            if (ge >= k) pivot = trial;
+            if (ge == k) break;          // exactly k keys are >= pivot; its score bits are <= the k-th best score: safe
+        }
+        tau_new = fmaxf(tau_in, key_score(pivot) - two_eps);
+    }
+    // compaction: every valid key with score >= tau_new moves to the front (all keys were loaded before any store)
+    const uint64_t cut = (uint64_t)f32_orderable(tau_new) << 32;
+    n_top = 0;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int e = 0; e < NREG; ++e) {
+        const uint64_t key = kreg[e];
+        const bool top = key != 0ull && key >= cut;
+        const uint64_t bt = __ballot(top);
+        if (top) c[n_top + __popcll(bt & lt_mask)] = key;
+        n_top += __popcll(bt);
+    }
+    for (int i0 = 0; i0 < n_spill; i0 += 64) {
+        const int i = i0 + lane;
+        const uint64_t key = i < n_spill ? spill[i] : 0ull;
+        const bool top = key != 0ull && key >= cut;
+        const uint64_t bt = __ballot(top);
+        if (top) c[n_top + __popcll(bt & lt_mask)] = key;
+        n_top += __popcll(bt);
+    }
+}
+
 __global__ __launch_bounds__(256) void select_kernel(uint64_t* __restrict__ cand, unsigned* __restrict__ cnt,
                                                       float* __restrict__ tau, float* __restrict__ bound,
                                                       int* __restrict__ n_sorted, int* __restrict__ stats, int n_queries,
@@ -463,55 +519,11 @@ __global__ __launch_bounds__(256) void select_kernel(uint64_t* __restrict__ cand
     const bool overflow = dense0_rows == 0 && emitted > RAG_CAND_CAP;
     const int n_in = dense0_rows > 0 ? dense0_rows : (int)min(emitted, (unsigned)RAG_CAND_CAP);
     if (overflow && lane == 0 && stats != nullptr) atomicAdd(&stats[4], 1);
-    // keys: first SEL_REG*64 in registers (element e*64 + lane), the rest (rare) in this wave's LDS slice
-    uint64_t kreg[SEL_REG];
-#pragma unroll
-    for (int e = 0; e < SEL_REG; ++e) {
-        const int i = e * 64 + lane;
-        kreg[e] = i < n_in ? c[i] : 0ull;
-    }
-    const int n_spill = max(0, n_in - SEL_REG * 64);
-    const int n_spill_pad = (n_spill + 63) & ~63;
-    for (int i = lane; i < n_spill; i += 64) spill[i] = c[SEL_REG * 64 + i];
-    int n_valid = 0;
-#pragma unroll
-    for (int e = 0; e < SEL_REG; ++e) n_valid += __popcll(__ballot(kreg[e] != 0ull));
-    for (int i = lane; i < n_spill_pad; i += 64) n_valid += __popcll(__ballot(i < n_spill && spill[i] != 0ull));
     const float tau_in = tau[q];
-    float tau_new = tau_in;
-    if (n_valid >= k) {
-        uint64_t pivot = 0ull;                               // becomes (a lower bound of) the k-th largest key
-        for (int bit = 63; bit >= 0; --bit) {
-            const uint64_t trial = pivot | (1ull << bit);
-            int ge = 0;
-#pragma unroll
-            for (int e = 0; e < SEL_REG; ++e) ge += __popcll(__ballot(kreg[e] >= trial));
-            for (int i = lane; i < n_spill_pad; i += 64) ge += __popcll(__ballot(i < n_spill && spill[i] >= trial));
-            if (ge >= k) pivot = trial;
-            if (ge == k) break;          // exactly k keys are >= pivot; its score bits are <= the k-th best score: safe
-        }
-        tau_new = fmaxf(tau_in, key_score(pivot) - two_eps);
-    }
-    // compaction: every valid key with score >= tau_new moves to the front (all keys were loaded before any store)
-    const uint64_t cut = (uint64_t)f32_orderable(tau_new) << 32;
-    int n_top = 0;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int e = 0; e < SEL_REG; ++e) {
-        const uint64_t key = kreg[e];
-        const bool top = key != 0ull && key >= cut;
-        const uint64_t bt = __ballot(top);
-        if (top) c[n_top + __popcll(bt & lt_mask)] = key;
-        n_top += __popcll(bt);
-    }
-    for (int i0 = 0; i0 < n_spill; i0 += 64) {
-        const int i = i0 + lane;
-        const uint64_t key = i < n_spill ? spill[i] : 0ull;
-        const bool top = key != 0ull && key >= cut;
-        const uint64_t bt = __ballot(top);
-        if (top) c[n_top + __popcll(bt & lt_mask)] = key;
-        n_top += __popcll(bt);
-    }
+    float tau_new;
+    int n_top;
+    if (n_in <= SEL_REG_SMALL * 64) select_wave<SEL_REG_SMALL>(c, spill, n_in, k, two_eps, tau_in, lane, tau_new, n_top);
+    else select_wave<SEL_REG>(c, spill, n_in, k, two_eps, tau_in, lane, tau_new, n_top);
     if (lane == 0) {
         // bound[] starts at -inf; an overflow at ANY stage lost candidates for good -> sticky +inf: the query goes to the
         // exact scan.
