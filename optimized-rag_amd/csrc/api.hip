@@ -101,6 +101,8 @@ int rag_destroy(rag_handle_t h) {
             hipEventDestroy(e.first);
             hipEventDestroy(e.second);
         }
+    if (h->side_stream) { hipStreamSynchronize(h->side_stream); hipStreamDestroy(h->side_stream); hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_join); }
+    hipFree(h->side_scores);
     hipStreamDestroy(h->stream);
     delete h;
     return RAG_OK;
@@ -434,9 +436,7 @@ int rag_hybrid_rrf_dev(rag_handle_t h, const float* q_dev, const int32_t* term_p
     ARG_CHECK(h, bm25_n_docs(h) == h->n_rows, "hybrid: the BM25 postings must be row-aligned with the index (same number of documents)");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
-    int rc = dense_search(h, q_dev, Q, pool, tenant, lists_ws_dev, nullptr, scores_ws_dev, st);
-    if (rc) return rc;
-    rc = bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, tenant, lists_ws_dev + (size_t)Q * pool, nullptr, scores_ws_dev, nullptr, st);
+    int rc = hybrid_legs(h, q_dev, term_ptr_dev, terms_dev, Q, pool, tenant, lists_ws_dev, scores_ws_dev, st);
     if (rc) return rc;
     return rrf_fuse_dev(h, lists_ws_dev, Q, 2, pool, (int64_t)Q * pool, pool, rrf_k, k, keys_out_dev, rrf_out_dev, ranks_out_dev, st);
 }

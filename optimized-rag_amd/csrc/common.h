@@ -32,6 +32,10 @@ struct rag_ctx {
     int dim = 0;
     int dim_pad = 0;             // multiple of RAG_BK
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;       // hybrid_legs: the BM25 leg of a small batch runs beside the dense leg
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    double* side_scores = nullptr;           // [side_scores_n] score scratch of that leg
+    size_t side_scores_n = 0;
     std::string err;
     bool profiling = false;
 
@@ -201,6 +205,8 @@ struct dense_fused {
 };
 int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev,
                        double* scores_dev, hipStream_t st, const dense_fused* fz);
+int hybrid_legs(rag_ctx* h, const float* q_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int pool, int tenant,
+                int64_t* lists_dev, double* scores_ws_dev, hipStream_t st);
 int linear_prepare(rag_ctx* h, const double* raw, int Q, int64_t n, const double* temporal, double beta, double gamma, double* mx,
                    float* bias, int64_t ld, hipStream_t st);
 int linear_components(rag_ctx* h, const float* q_dev, const int32_t* rows_dev, int Q, int k, const dense_fused* fz, double* sem_out,

@@ -18,6 +18,44 @@ int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_
 int64_t bm25_n_docs(const rag_ctx* h);
 int rrf_fuse_dev(rag_ctx* h, const int64_t* lists_dev, int Q, int L, int len, int64_t list_stride, int64_t query_stride, int rrf_k,
                  int top_k, int64_t* keys_dev, double* scores_dev, int32_t* ranks_dev, hipStream_t st);
+
+// The two candidate legs of the hybrid search: dense top-pool into lists[0], BM25 top-pool into lists[1] ([2][Q][pool]).
+// They are independent, and for a handful of queries both are latency-bound (one query: 0.6 ms of HBM-bound scan and 0.4 ms
+// of BM25 launches that occupy a quarter of the CUs), so up to RAG_FORK_MAX_Q queries the BM25 leg runs on a side stream,
+// forked from and joined back into the caller's stream by events; larger batches saturate the device in either leg and stay
+// in line. RAG_NO_FORK=1 (diagnostic) keeps them in line always.
+#define RAG_FORK_MAX_Q 16
+int hybrid_legs(rag_ctx* h, const float* q_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int pool, int tenant,
+                int64_t* lists_dev, double* scores_ws_dev, hipStream_t st) {
+    int64_t* const bm_ids = lists_dev + (size_t)Q * pool;
+    if (Q > RAG_FORK_MAX_Q || getenv("RAG_NO_FORK")) {
+        int rc = dense_search(h, q_dev, Q, pool, tenant, lists_dev, nullptr, scores_ws_dev, st);
+        if (rc) return rc;
+        return bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, tenant, bm_ids, nullptr, scores_ws_dev, nullptr, st);
+    }
+    if (!h->side_stream) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    const size_t need = (size_t)Q * pool;
+    if (need > h->side_scores_n) {
+        hipFree(h->side_scores);
+        h->side_scores = nullptr;
+        h->side_scores_n = 0;
+        HIP_TRY(h, hipMalloc(&h->side_scores, (size_t)RAG_FORK_MAX_Q * RAG_MAX_K * sizeof(double)));
+        h->side_scores_n = (size_t)RAG_FORK_MAX_Q * RAG_MAX_K;
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_fork, st));                    // inputs are ready wherever the caller's stream is now
+    HIP_TRY(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+    int rc = bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, tenant, bm_ids, nullptr, h->side_scores, nullptr, h->side_stream);
+    // the join is recorded and waited for even if a leg failed to launch: the caller's stream must never run ahead of the side stream
+    HIP_TRY(h, hipEventRecord(h->ev_join, h->side_stream));
+    const int rc2 = dense_search(h, q_dev, Q, pool, tenant, lists_dev, nullptr, scores_ws_dev, st);
+    HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));
+    return rc ? rc : rc2;
+}
+
 int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L, float* out, hipStream_t st,
              bool host_ptrs);
 
@@ -211,8 +249,7 @@ int retrieve_rerank_dev(rag_ctx* h, const float* q_emb_dev, const int32_t* term_
     if (mode == 0) {
         rc = dense_search(h, q_emb_dev, Q, pool, tenant, cand, nullptr, sc, st);
     } else {
-        rc = dense_search(h, q_emb_dev, Q, pool, tenant, lists, nullptr, sc, st);
-        if (!rc) rc = bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, tenant, lists + P, nullptr, sc, nullptr, st);
+        rc = hybrid_legs(h, q_emb_dev, term_ptr_dev, terms_dev, Q, pool, tenant, lists, sc, st);
         if (!rc) rc = rrf_fuse_dev(h, lists, Q, 2, pool, (int64_t)P, pool, rrf_k, pool, cand, rrf, ranks, st);
     }
     h->ids = ids_saved;

@@ -397,8 +397,10 @@ def test_batched_agent_entries_equal_the_per_query_calls(eng):
 
 
 # ---------------------------------------------------------------------------------------- fused device hybrid
-def test_hybrid_rrf_dev_matches_oracle_pipeline(eng):
-    """rag_hybrid_rrf_dev (dense top-pool + BM25 top-pool + RRF, all on device) == oracle dense + oracle BM25 + oracle RRF."""
+def test_hybrid_rrf_dev_matches_oracle_pipeline(eng, monkeypatch):
+    """rag_hybrid_rrf_dev (dense top-pool + BM25 top-pool + RRF, all on device) == oracle dense + oracle BM25 + oracle RRF.
+    12 queries <= RAG_FORK_MAX_Q: the BM25 leg runs on the side stream beside the dense leg; RAG_NO_FORK=1 (both legs in line
+    on the caller's stream) must give the same bits."""
     import torch
     from optimized_rag_amd.bm25 import Bm25Postings
     rng = np.random.default_rng(51)
@@ -416,6 +418,13 @@ def test_hybrid_rrf_dev_matches_oracle_pipeline(eng):
                                           torch.from_numpy(terms).cuda(), pool, k)
     torch.cuda.synchronize()
     keys, rrf, ranks = keys.cpu().numpy(), rrf.cpu().numpy(), ranks.cpu().numpy()
+    monkeypatch.setenv("RAG_NO_FORK", "1")
+    k2, r2, n2 = eng.hybrid_rrf_dev(torch.from_numpy(q).cuda(), torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda(), pool, k)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("RAG_NO_FORK")
+    np.testing.assert_array_equal(keys, k2.cpu().numpy())
+    np.testing.assert_array_equal(rrf, r2.cpu().numpy())
+    np.testing.assert_array_equal(ranks, n2.cpu().numpy())
     d_rows, _ = O.dense_topk(emb, q, pool)
     obm = O.BM25Okapi([O.tokenize(c) for c in corpus])
     for qi in range(Q):
