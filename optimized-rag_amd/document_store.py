@@ -90,7 +90,7 @@ class GpuDocumentIndex:
                 d = {"content": row.get("content", ""), "filename": row.get("filename"), "file_type": row.get("file_type"),
                      "score": float(scores[0][j]), "metadata": row.get("metadata") or {}}
                 if embs is not None:
-                    d["embedding"] = [float(x) for x in embs[j]]     # saves apply_mmr's re-embedding calls
+                    d["embedding"] = embs[j].tolist()                 # Python floats; saves apply_mmr's re-embedding calls
                 out.append(d)
             return out
         except Exception as e:                                       # reference: log and return [] (:483-485)
@@ -122,7 +122,7 @@ class GpuDocumentIndex:
                     d = {"content": row.get("content", ""), "filename": row.get("filename"), "file_type": row.get("file_type"),
                          "score": float(scores[i][j]), "metadata": row.get("metadata") or {}}
                     if fetched is not None:
-                        d["embedding"] = [float(x) for x in fetched[pos + j]]
+                        d["embedding"] = fetched[pos + j].tolist()
                     res.append(d)
                 pos += len(h)
                 out.append(res)

@@ -186,7 +186,7 @@ class HybridRetriever:
         if len(embeddings) == 0:
             return []
         m = as_matrix([query_embedding] + list(embeddings))
-        return [float(x) for x in self.engine.pairwise_cosine(m[:1], m[1:])[0]]
+        return self.engine.pairwise_cosine(m[:1], m[1:])[0].tolist()
 
     def _bm25_scores(self, query: str, corpus: List[str]) -> List[float]:
         if not corpus or all(len(d.split()) == 0 for d in corpus):
