@@ -5,6 +5,8 @@ import logging
 import re
 from typing import Any, Dict, List
 
+import numpy as np
+
 from .engine import as_matrix, get_engine
 
 logger = logging.getLogger(__name__)
@@ -71,15 +73,17 @@ class ConsistencyChecker:
         m = as_matrix(embeddings)
         S = self.engine.pairwise_cosine(m)                      # C x C, float64, one launch
         out = []
-        for i in range(len(claims)):
-            for j in range(i + 1, len(claims)):
-                if claims[i]["doc_idx"] == claims[j]["doc_idx"]:
-                    continue
-                sim = float(S[i, j])
-                if sim >= self.similarity_threshold and self._is_contradiction(claims[i]["text"], claims[j]["text"]):
-                    out.append({"claim_1": claims[i]["text"][:200], "claim_2": claims[j]["text"][:200],
-                                "source_1": claims[i]["source"], "source_2": claims[j]["source"],
-                                "similarity": round(sim, 3), "type": "semantic_contradiction"})
+        # the reference walks all i < j pairs in Python (:169-189); same pairs in the same order, but the same-document and
+        # threshold tests run over the whole upper triangle at once and only the survivors reach the string checks
+        doc = np.asarray([c["doc_idx"] for c in claims])
+        iu, ju = np.triu_indices(len(claims), 1)
+        keep = (doc[iu] != doc[ju]) & (S[iu, ju] >= self.similarity_threshold)
+        for i, j in zip(iu[keep].tolist(), ju[keep].tolist()):
+            sim = float(S[i, j])
+            if self._is_contradiction(claims[i]["text"], claims[j]["text"]):
+                out.append({"claim_1": claims[i]["text"][:200], "claim_2": claims[j]["text"][:200],
+                            "source_1": claims[i]["source"], "source_2": claims[j]["source"],
+                            "similarity": round(sim, 3), "type": "semantic_contradiction"})
         return out
 
     def _is_contradiction(self, text1: str, text2: str) -> bool:
