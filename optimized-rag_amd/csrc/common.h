@@ -59,6 +59,7 @@ struct rag_ctx {
     int ws_q = 0;
     float* q32 = nullptr;            // [ws_q][dim]     staging for host queries
     half_t* q16 = nullptr;           // [ws_qpad][dim_pad]
+    int q16_dirty = 0;               // rows [q16_dirty, ws_qpad) of q16 are known to be zero (pad rows of a query tile must be)
     uint64_t* cand = nullptr;        // [ws_qpad][RAG_CAND_CAP]
     unsigned* cnt = nullptr;         // [ws_qpad]   emitted candidates (may exceed cap = overflow)
     float* tau = nullptr;            // [ws_qpad]   emission threshold = k-th best fp16-pass score so far - 2 eps

@@ -1022,7 +1022,7 @@ static ce_planes planes_for(const rag_ce_model* m, int64_t Mp) {
 }
 
 template <int QB>
-static int launch_attention(rag_ctx* h, rag_ce_model* m, int P, int L, const ce_planes& pp, hipStream_t st) {
+static int launch_attention(rag_ctx* h, rag_ce_model* m, int P, int L, const ce_planes& pp, hipStream_t st, const int32_t* lens_dev) {
     const int lds = L * 256;                                           // K hi | K lo | V hi | V lo fragment planes
     int& attr_lds = h->attr_ce_attn_lds[QB];
     if (lds > attr_lds) {
@@ -1032,7 +1032,7 @@ static int launch_attention(rag_ctx* h, rag_ce_model* m, int P, int L, const ce_
     }
     const int waves = L / (16 * QB);
     hipLaunchKernelGGL((ce_attention_kernel<QB>), dim3(m->cfg.heads, P), dim3(64 * waves), lds, st, m->q16, m->kf16, m->vf16,
-                       pp.kv, m->lens, m->pair_off, L, m->cfg.hidden, m->cfg.heads, m->ctx16);
+                       pp.kv, lens_dev, m->pair_off, L, m->cfg.hidden, m->cfg.heads, m->ctx16);
     return RAG_OK;
 }
 
@@ -1042,7 +1042,9 @@ static void launch_ln(rag_ce_model* m, const float* y, const float* g, const flo
                        (float)m->cfg.ln_eps, m->x16);
 }
 
-static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t st) {
+// lens_dev / logits_dev: this chunk's lengths and logit slots (the model's staging buffers for host-pointer calls, the caller's
+// own device arrays otherwise)
+static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t st, const int32_t* lens_dev, float* logits_dev) {
     const int H = m->cfg.hidden, F = m->cfg.ffn;
     const int64_t M = (int64_t)P * L;
     const int64_t Mp = round_up((int64_t)m->ws_pairs * L, CE_BN);      // plane strides follow the ALLOCATED size
@@ -1094,7 +1096,7 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
                                     m->pos, m->type, m->emb_ln_g, m->emb_ln_b, m->m_packed, m->row_pair, m->pair_off, L, H,            \
                                     m->cfg.vocab_size, eps, m->x16)
     // packed row layout of this chunk (no host round trip: grids cover the padded worst case, kernels stop at m_packed)
-    hipLaunchKernelGGL(ce_pack_scan_kernel, dim3(1), dim3(1024), 0, st, m->lens, P, L, m->pair_off, m->m_packed);
+    hipLaunchKernelGGL(ce_pack_scan_kernel, dim3(1), dim3(1024), 0, st, lens_dev, P, L, m->pair_off, m->m_packed);
     hipLaunchKernelGGL(ce_pack_rows_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, st, m->pair_off, P, L, Mp, m->row_pair);
     CE_PER_DISPATCH(EMB)
     const dim3 blk(512);
@@ -1106,7 +1108,7 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
                 3 * H, H, ly.bqkv, (const half_t*)nullptr, (float*)nullptr, m->q16, m->kf16, m->vf16, pp.kv, H,
                 m->cfg.heads, m->m_packed, m->row_pair, m->pair_off)
         {
-            const int rc = L == 32 ? launch_attention<1>(h, m, P, L, pp, st) : launch_attention<2>(h, m, P, L, pp, st);
+            const int rc = L == 32 ? launch_attention<1>(h, m, P, L, pp, st, lens_dev) : launch_attention<2>(h, m, P, L, pp, st, lens_dev);
             if (rc != RAG_OK) return rc;
         }
 #define LN1(PER) launch_ln<PER>(m, m->y32, ly.ln1_g, ly.ln1_b, M, st)
@@ -1132,7 +1134,7 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
         }
     }
     (void)nullh;
-    hipLaunchKernelGGL(ce_pool_classify_kernel, dim3(P), dim3(256), 0, st, m->x16, m->wp, m->bp, m->wc, m->bc, m->pair_off, H, m->logits);
+    hipLaunchKernelGGL(ce_pool_classify_kernel, dim3(P), dim3(256), 0, st, m->x16, m->wp, m->bp, m->wc, m->bc, m->pair_off, H, logits_dev);
     HIP_TRY(h, hipGetLastError());
     return RAG_OK;
 }
@@ -1200,20 +1202,26 @@ int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* l
     const int chunk = std::max(1, std::min(P, (int)(chunk_tokens / L)));
     int rc = ce_ensure_ws(h, m, chunk, L, st);
     if (rc) return rc;
-    const hipMemcpyKind kin = host_ptrs ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-    const hipMemcpyKind kout = host_ptrs ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    const hipMemcpyKind kin = hipMemcpyHostToDevice, kout = hipMemcpyDeviceToHost;
     int32_t *sid = m->sid, *stt = m->stt;
     if ((rc = prof_begin(h, 2, st))) return rc;
     for (int p0 = 0; p0 < P; p0 += chunk) {
         const int pc = std::min(chunk, P - p0);
-        HIP_TRY(h, hipMemcpyAsync(sid, ids + (size_t)p0 * L_in, (size_t)pc * L_in * 4, kin, st));
-        HIP_TRY(h, hipMemcpyAsync(stt, tt + (size_t)p0 * L_in, (size_t)pc * L_in * 4, kin, st));
-        HIP_TRY(h, hipMemcpyAsync(m->lens, lens + p0, (size_t)pc * 4, kin, st));
+        // host arrays are staged chunk by chunk; device arrays are read (ids, lens) and written (logits) where they are: four
+        // small copies less per chunk, 45 us of a single-query call
+        const int32_t *src_ids = ids + (size_t)p0 * L_in, *src_tt = tt + (size_t)p0 * L_in, *lens_dev = lens + p0;
+        float* logits_dev = out + p0;
+        if (host_ptrs) {
+            HIP_TRY(h, hipMemcpyAsync(sid, src_ids, (size_t)pc * L_in * 4, kin, st));
+            HIP_TRY(h, hipMemcpyAsync(stt, src_tt, (size_t)pc * L_in * 4, kin, st));
+            HIP_TRY(h, hipMemcpyAsync(m->lens, lens_dev, (size_t)pc * 4, kin, st));
+            src_ids = sid; src_tt = stt; lens_dev = m->lens; logits_dev = m->logits;
+        }
         const int64_t n = (int64_t)pc * L;
-        hipLaunchKernelGGL(ce_pad_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sid, stt, pc, L_in, L, m->ids, m->tt);
-        rc = ce_forward_chunk(h, m, pc, L, st);
+        hipLaunchKernelGGL(ce_pad_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src_ids, src_tt, pc, L_in, L, m->ids, m->tt);
+        rc = ce_forward_chunk(h, m, pc, L, st, lens_dev, logits_dev);
         if (rc) break;
-        HIP_TRY(h, hipMemcpyAsync(out + p0, m->logits, (size_t)pc * 4, kout, st));
+        if (host_ptrs) HIP_TRY(h, hipMemcpyAsync(out + p0, m->logits, (size_t)pc * 4, kout, st));
     }
     if (!rc) rc = prof_end(h, 2, st);
     // device-pointer calls stay asynchronous on the caller's stream (all buffers belong to the model workspace);

@@ -931,6 +931,7 @@ static int ensure_workspace(rag_ctx* h, int Q, hipStream_t st) {
     if (!h->stats) HIP_TRY(h, hipMalloc(&h->stats, 8 * sizeof(int)));
     // zero fills go on the search's own stream: a null-stream hipMemset is not ordered against a non-blocking stream
     HIP_TRY(h, hipMemsetAsync(h->q16, 0, (size_t)qpad * h->dim_pad * sizeof(half_t), st));
+    h->q16_dirty = 0;
     if (!h->q16b) {      // second pass (overflowed queries): one 256-query tile, allocated once per handle
         HIP_TRY(h, hipMalloc(&h->q16b, (size_t)RAG_TILE * h->dim_pad * sizeof(half_t)));
         HIP_TRY(h, hipMalloc(&h->candb, (size_t)RAG_TILE * RAG_CAND_CAP * sizeof(uint64_t)));
@@ -1059,8 +1060,10 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
     const int force_level = fl ? atoi(fl) : 0;
 
     // queries -> fp16 unit rows (pad rows of q16 stay zero from allocation time / previous larger batch)
-    if (qpad > Q)
-        HIP_TRY(h, hipMemsetAsync(h->q16 + (size_t)Q * h->dim_pad, 0, (size_t)(qpad - Q) * h->dim_pad * sizeof(half_t), st));
+    // only rows a previous, larger batch wrote can be non-zero: same-size batches (the agent's one query after another) clear nothing
+    if (h->q16_dirty > Q)
+        HIP_TRY(h, hipMemsetAsync(h->q16 + (size_t)Q * h->dim_pad, 0, (size_t)(h->q16_dirty - Q) * h->dim_pad * sizeof(half_t), st));
+    h->q16_dirty = Q;
     hipLaunchKernelGGL(normalize_rows_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, q_dev, h->q16, (int64_t)Q, h->dim,
                        h->dim_pad, (int*)nullptr);
     hipLaunchKernelGGL(search_init_kernel, dim3((qpad + 255) / 256), dim3(256), 0, st, tau, h->bound, h->cnt, h->stats, qpad);
