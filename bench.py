@@ -263,8 +263,11 @@ def main():
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r02_g_dense_pmc.json")
     if world == 1 and args.rows == 1_000_000 and Q == 1024 and args.corpus == "iid" and os.path.exists(pmc_path):
-        with open(pmc_path) as f:
-            traffic = json.load(f)["kernels"]["dense_emit_kernel<false>"]["hbm_traffic_bytes_per_launch"]["total"]
+        try:                                        # a missing or reshaped profile file must never take the bench line down
+            with open(pmc_path) as f:
+                traffic = json.load(f)["kernels"]["dense_emit_kernel<false>"]["hbm_traffic_bytes_per_launch"]["total"]
+        except (OSError, ValueError, KeyError, TypeError):
+            traffic = None
     mfma_view = {"achieved": round(achieved_tflops, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                  "frac": round(achieved_tflops / PEAK_MFMA_TFLOPS, 4)}
     hbm_view = {"achieved": round(achieved_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -49,3 +49,14 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("the float64 oracle", "").replace("oracle's", ""), f
+
+
+def test_bench_reads_the_committed_traffic_profile():
+    """bench.py fills roofline.traffic from profiles/r02_g_dense_pmc.json: the file must carry the key it reads (a reshaped
+    file once took the default bench line down; bench.py now also tolerates it)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r02_g_dense_pmc.json")) as f:
+        total = json.load(f)["kernels"]["dense_emit_kernel<false>"]["hbm_traffic_bytes_per_launch"]["total"]
+    assert 1.0e9 < total < 3.0e9            # ~1.5 GB per launch against 1.025 GB algorithmic
