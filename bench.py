@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--mode", default="dense", choices=["dense", "hybrid", "rerank", "pipeline"],
                     help="dense = the headline metric (default); hybrid / rerank = BASELINE configs[2] / [3], single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--abi-comm", action="store_true",
+                    help="N > 1: gather through rag_comm_allgather_dev (RCCL bound behind the C-ABI) instead of torch.distributed")
     ap.add_argument("--dense-only", action="store_true", help="skip the hybrid / retrieve_rerank / agent_latency blocks")
     ap.add_argument("--corpus", default="iid", choices=["iid", "clustered", "sorted", "tenant-contiguous"],
                     help="row order / structure of the synthetic corpus (default: i.i.d. unit Gaussians, BASELINE configs[1]); "
@@ -175,6 +177,10 @@ def main():
     torch.cuda.empty_cache()
 
     from optimized_rag_amd.sharded import ShardedDenseIndex
+    if world > 1 and args.abi_comm:       # the 128-byte RCCL id travels through the process group that launched the ranks
+        uid = [eng.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(rank, world, uid[0])
     index = ShardedDenseIndex(eng, rank=rank, world=world)
 
     def step():
@@ -307,7 +313,7 @@ def main():
                                ("" if args.corpus == "iid" else f"; ROW ORDER VARIANT --corpus {args.corpus} (not the headline config)"),
                    "corpus": args.corpus,
                    "corpus_rows": args.rows, "rows_per_gpu": n_local, "batch_queries": Q, "k": k,
-                   "parallelism": f"row-sharded x{world}" + (" + RCCL all-gather merge" if world > 1 else "")},
+                   "parallelism": f"row-sharded x{world}" + ((" + RCCL all-gather (C-ABI) + merge" if args.abi_comm else " + RCCL all-gather merge") if world > 1 else "")},
         "p50_batch_latency_ms": round(p50, 4), "p50_single_query_latency_ms": None if lat1 is None else round(lat1, 4),
         "exactness": {**stats, "planted_neighbour_at_rank1": planted_hit},
         "roofline": roofline,

@@ -259,6 +259,18 @@ int rag_ce_build_pairs_dev(rag_handle_t h, const int32_t* q_tok_dev, const int32
 int rag_rerank_topk_dev(rag_handle_t h, const float* logits_dev, const int64_t* cand_dev, int n_queries, int pool, int k,
                         int64_t* ids_out_dev, double* scores_out_dev, float* logits_out_dev, void* stream);
 
+/* ---- the exchange step of the row-sharded search (the reference is single-process) bound to RCCL
+ *      directly, for hosts that do not want torch.distributed in the path: ONE all-gather of each rank's partial top-k lists
+ *      per stage, over xGMI, followed by rag_merge_topk_dev / rag_rrf_fuse_dev on every rank. librccl is opened at the first
+ *      call (dlopen; the library has no link-time dependency on it).
+ *      rag_comm_unique_id: 128 bytes created on ONE rank and handed to the others out of band (file, socket, torch store).
+ *      rag_comm_init: collective over `world` ranks, one per GPU. rag_comm_allgather_dev: recv_dev[world][bytes] <- every
+ *      rank's send_dev[bytes], asynchronous on `stream`. */
+int rag_comm_unique_id(void* id128_out);
+int rag_comm_init(rag_handle_t h, int rank, int world, const void* id128);
+int rag_comm_allgather_dev(rag_handle_t h, const void* send_dev, void* recv_dev, size_t bytes, void* stream);
+int rag_comm_destroy(rag_handle_t h);
+
 #ifdef __cplusplus
 }
 #endif

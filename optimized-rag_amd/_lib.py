@@ -61,6 +61,10 @@ _SIGS = {
     "rag_dense_kernel_ms": ([_P, C.POINTER(C.c_float), C.POINTER(C.c_int)], C.c_int),
     "rag_stage_kernel_ms": ([_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)], C.c_int),
     "rag_merge_topk_dev": ([_P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P, _P, _P], C.c_int),
+    "rag_comm_unique_id": ([_P], C.c_int),
+    "rag_comm_init": ([_P, C.c_int, C.c_int, _P], C.c_int),
+    "rag_comm_allgather_dev": ([_P, _P, _P, C.c_size_t, _P], C.c_int),
+    "rag_comm_destroy": ([_P], C.c_int),
     "rag_pairwise_cosine_host": ([_P, _P, C.c_int, _P, C.c_int, C.c_int, _P], C.c_int),
     "rag_rrf_fuse_host": ([_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P], C.c_int),
     "rag_bm25_load_host": ([_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double], C.c_int),
@@ -293,6 +297,36 @@ class RagEngine:
         self._check(self.lib.rag_merge_topk_dev(self.h, C.c_void_p(ids.data_ptr()), C.c_void_p(scores.data_ptr()),
                                                 int(n_lists), int(list_stride), Q, k, C.c_void_p(ids_out.data_ptr()),
                                                 C.c_void_p(scores_out.data_ptr()), st), "rag_merge_topk_dev")
+
+    # ---- RCCL exchange behind the C-ABI (multi-GPU, one process per GPU) -----------------------------
+    def comm_unique_id(self):
+        """128-byte RCCL id (bytes): create on ONE rank, hand to the others out of band, pass to comm_init on every rank."""
+        buf = C.create_string_buffer(128)
+        rc = self.lib.rag_comm_unique_id(buf)
+        if rc != 0:
+            raise RagError(f"rag_comm_unique_id failed ({rc}): librccl not available")
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        """Collective over `world` ranks (one per GPU). Afterwards the sharded classes gather through the library."""
+        if len(unique_id) != 128:
+            raise RagError("comm_init: unique_id must be 128 bytes")
+        self._check(self.lib.rag_comm_init(self.h, int(rank), int(world), C.c_char_p(unique_id)), "rag_comm_init")
+        self.comm_world = int(world)
+
+    def comm_allgather_dev(self, send, recv, stream=None):
+        """recv[world, ...] <- every rank's send (torch CUDA tensors, contiguous); asynchronous on `stream`."""
+        import torch
+        nbytes = send.numel() * send.element_size()
+        if not (send.is_contiguous() and recv.is_contiguous()) or recv.numel() * recv.element_size() != nbytes * getattr(self, "comm_world", 1):
+            raise RagError("comm_allgather_dev: recv must be contiguous and hold world x send")
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        self._check(self.lib.rag_comm_allgather_dev(self.h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), nbytes, st),
+                    "rag_comm_allgather_dev")
+
+    def comm_destroy(self):
+        self._check(self.lib.rag_comm_destroy(self.h), "rag_comm_destroy")
+        self.comm_world = 0
 
     # ---- small ops --------------------------------------------------------------------------------
     def pairwise_cosine(self, a, b=None):

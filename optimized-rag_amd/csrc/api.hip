@@ -88,6 +88,7 @@ int rag_destroy(rag_handle_t h) {
     { LOCK(h); }                        // wait for a call in flight on another thread; the caller must not start new ones
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    comm_free(h);
     dense_free(h);
     bm25_free(h);
     ce_free(h);

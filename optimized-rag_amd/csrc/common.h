@@ -38,6 +38,8 @@ struct rag_ctx {
     size_t side_scores_n = 0;
     std::string err;
     bool profiling = false;
+    void* comm = nullptr;                    // ncclComm_t of comm.hip (RCCL, opened with dlopen), or null
+    int comm_rank = 0, comm_world = 1;
 
     // dense index
     int64_t n_rows = 0, n_rows_pad = 0, id_base = 0;
@@ -206,6 +208,7 @@ struct dense_fused {
 };
 int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64_t* ids_dev, int32_t* rows_dev,
                        double* scores_dev, hipStream_t st, const dense_fused* fz);
+void comm_free(rag_ctx* h);
 int hybrid_legs(rag_ctx* h, const float* q_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int pool, int tenant,
                 int64_t* lists_dev, double* scores_ws_dev, hipStream_t st);
 int linear_prepare(rag_ctx* h, const double* raw, int Q, int64_t n, const double* temporal, double beta, double gamma, double* mx,

@@ -60,13 +60,15 @@ class ShardedDenseIndex:
         self.engine.dense_topk_dev(queries, k, send_ids, None, send_sc, tenant=tenant)
         if self.world == 1:
             return send_ids, send_sc
-        _gather(recv, send, self.group)
+        _gather(recv, send, self.group, self.engine)
         self.engine.merge_topk_dev(recv, recv_sc, out_ids, out_scores, n_lists=self.world, list_stride=2 * Q * k)
         return out_ids, out_scores
 
 
-def _gather(recv, send, group):
-    if dist.get_backend(group) == "nccl":                   # RCCL: one flat gather straight into the merge buffer
+def _gather(recv, send, group, engine=None):
+    if engine is not None and getattr(engine, "comm_world", 0) > 1:     # RCCL bound behind the C-ABI (engine.comm_init ran)
+        engine.comm_allgather_dev(send, recv)
+    elif dist.get_backend(group) == "nccl":                 # RCCL: one flat gather straight into the merge buffer
         dist.all_gather_into_tensor(recv, send, group=group)
     else:
         dist.all_gather(list(recv.unbind(0)), send, group=group)
@@ -135,7 +137,7 @@ class ShardedHybridIndex(ShardedDenseIndex):
         if self.world == 1:
             return self.fuse_gathered(send.unsqueeze(0), k, rrf_k)
         recv = self._hyb_buffers(queries.shape[0], pool, k, queries.device)["recv"]
-        _gather(recv, send, self.group)
+        _gather(recv, send, self.group, self.engine)
         return self.fuse_gathered(recv, k, rrf_k)
 
 
@@ -161,7 +163,7 @@ class ShardedReranker:
         if self.world == 1:
             return mine[:P]
         out = torch.empty((self.world, per), dtype=torch.float32, device=input_ids.device)
-        _gather(out, mine, self.group)
+        _gather(out, mine, self.group, self.engine)
         return out.reshape(-1)[:P]
 
 

@@ -360,3 +360,24 @@ def test_empty_index_searches_to_empty_results(eng_factory):
     eng.index_load(np.zeros((0, 128), dtype=np.float32))
     ids, rows, sc = eng.dense_topk(np.ones((3, 128), dtype=np.float32), 5)
     assert (ids == -1).all() and (rows == -1).all() and (sc == 0).all()
+
+
+def test_rccl_allgather_behind_the_c_abi_world_1():
+    """rag_comm_*: librccl opened with dlopen, a one-rank communicator on this GPU, one all-gather on the caller's stream
+    (recv[1][...] == send), destroy. More than one rank needs more than one GPU: the row-sharded composition itself is
+    covered by the world-size-2 gloo tests and by the three-shards-on-one-GPU hybrid test."""
+    import torch
+    from optimized_rag_amd import RagEngine
+    eng = RagEngine(dim=64, device=0)
+    try:
+        uid = eng.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        eng.comm_init(0, 1, uid)
+        send = torch.arange(2 * 7 * 5, dtype=torch.int64, device="cuda").reshape(2, 7, 5) * 3 - 11
+        recv = torch.full((1, 2, 7, 5), -1, dtype=torch.int64, device="cuda")
+        eng.comm_allgather_dev(send, recv)
+        torch.cuda.synchronize()
+        assert torch.equal(recv[0], send)
+        eng.comm_destroy()
+    finally:
+        eng.close()
