@@ -60,6 +60,9 @@ __global__ __launch_bounds__(256) void rrf_fuse_kernel(const int64_t* __restrict
         if (tfirst[slot] != i) continue;
         double s = 0.0;
         bool started = false;
+        // (this loop and the two below are chains of dependent LDS round trips: no early exits, so that the compiler can keep
+        // several reads in flight - one query's fusion is a single workgroup and its latency is all there is)
+#pragma unroll 8
         for (int u = i; u < T; ++u) {
             if (item[u] == key) {
                 const int rank = (u % len) + 1;
@@ -79,7 +82,8 @@ __global__ __launch_bounds__(256) void rrf_fuse_kernel(const int64_t* __restrict
         const double s = oscore[o];
         const int p = opos[o];
         int rank = 0;
-        for (int u = 0; u < U && rank < top_k; ++u) rank += (oscore[u] > s) || (oscore[u] == s && opos[u] < p);
+#pragma unroll 8
+        for (int u = 0; u < U; ++u) rank += (oscore[u] > s) || (oscore[u] == s && opos[u] < p);
         if (rank < top_k) {
             const int64_t key = item[p];
             keys_out[(size_t)q * top_k + rank] = key;
@@ -87,8 +91,9 @@ __global__ __launch_bounds__(256) void rrf_fuse_kernel(const int64_t* __restrict
             if (ranks_out) {
                 for (int l = 0; l < L; ++l) {
                     int r = 0;
-                    for (int j = 0; j < len; ++j)
-                        if (item[l * len + j] == key) { r = j + 1; break; }
+#pragma unroll 8
+                    for (int j = len - 1; j >= 0; --j)
+                        if (item[l * len + j] == key) r = j + 1;          // the lowest matching position wins
                     ranks_out[((size_t)q * top_k + rank) * L + l] = r;
                 }
             }
