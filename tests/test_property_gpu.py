@@ -1,0 +1,116 @@
+"""Property tests (hypothesis) of the HIP paths against the CPU oracle on small random inputs: shapes, duplicate rows, zero
+rows, ties, ragged lists and tenant filters chosen by the framework instead of by hand. One engine per dimension is reused
+across examples (loading an index is the expensive part), so a few dozen examples per property run in seconds."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from oracle import rag_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+_ENGINES = {}
+
+
+def _engine(dim):
+    from optimized_rag_amd import RagEngine
+    if dim not in _ENGINES:
+        _ENGINES[dim] = RagEngine(dim=dim, device=0)
+    return _ENGINES[dim]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _close_engines():
+    yield
+    for e in _ENGINES.values():
+        e.close()
+    _ENGINES.clear()
+
+
+COMMON = dict(deadline=None, max_examples=300, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+
+
+@settings(**COMMON)
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 700), q=st.integers(1, 9), k=st.integers(1, 40),
+       dim=st.sampled_from([64, 128]), dup=st.integers(0, 5), zeros=st.integers(0, 3), use_tenant=st.booleans())
+def test_dense_topk_equals_the_exact_scan(seed, n, q, k, dim, dup, zeros, use_tenant):
+    """ids / rows identical to the float64 exact scan (stable: lower row first on equal scores), scores within 1e-9, for
+    corpora with duplicated rows (exact score ties), zero rows (cosine 0.0) and an optional tenant filter."""
+    rng = np.random.default_rng(seed)
+    corpus = rng.standard_normal((n, dim)).astype(np.float32)
+    for _ in range(min(dup, n)):                                  # exact duplicates: ties that the row order must break
+        a, b = rng.integers(0, n, 2)
+        corpus[a] = corpus[b]
+    for _ in range(min(zeros, n)):
+        corpus[rng.integers(0, n)] = 0.0
+    queries = (corpus[rng.integers(0, n, q)] + 0.25 * rng.standard_normal((q, dim))).astype(np.float32)
+    if zeros:
+        queries[0] = 0.0                                          # a zero query scores 0.0 everywhere: top-k = first rows
+    eng = _engine(dim)
+    eng.index_load(corpus)
+    tenants, tenant = None, -1
+    if use_tenant:
+        tenants = rng.integers(0, 3, n).astype(np.int32)
+        tenant = int(rng.integers(0, 3))
+        eng.set_tenants(tenants)
+    got_ids, got_rows, got_sc = eng.dense_topk(queries, k, tenant=tenant)
+    oid, osc = O.dense_topk(corpus, queries, k, tenants, tenant if use_tenant else None)
+    np.testing.assert_array_equal(got_rows, oid.astype(np.int32))
+    np.testing.assert_array_equal(got_ids, oid)
+    np.testing.assert_allclose(got_sc, osc, rtol=0, atol=1e-9)
+
+
+@settings(**COMMON)
+@given(seed=st.integers(0, 2**31 - 1), n_lists=st.integers(1, 4), length=st.integers(1, 60), universe=st.integers(1, 80),
+       top_k=st.integers(1, 30), rrf_k=st.sampled_from([1, 60, 1000]))
+def test_rrf_equals_the_reference_loop(seed, n_lists, length, universe, top_k, rrf_k):
+    """Keys, bit-exact float64 scores and per-list ranks of ReciprocalRankFusion.fuse for lists with repeated keys inside a
+    list, keys shared between lists and -1 padding."""
+    rng = np.random.default_rng(seed)
+    lists = rng.integers(0, universe, (1, n_lists, length)).astype(np.int64)
+    pad = rng.integers(0, length + 1, n_lists)
+    for li in range(n_lists):
+        if pad[li]:
+            lists[0, li, length - pad[li]:] = -1                  # ragged: shorter lists are -1 padded at the tail
+    eng = _engine(64)
+    keys, scores, ranks = eng.rrf_fuse(lists, rrf_k=rrf_k, top_k=top_k)
+    okeys, oscores, oranks = O.rrf_fuse([[int(x) for x in lists[0, li] if x >= 0] for li in range(n_lists)], k=rrf_k, top_k=top_k)
+    m = len(okeys)
+    assert keys[0, :m].tolist() == okeys and (keys[0, m:] == -1).all()
+    assert scores[0, :m].tolist() == oscores                     # bit-exact float64
+    assert ranks[0, :m].tolist() == oranks
+
+
+@settings(**{**COMMON, "max_examples": 100})
+@given(seed=st.integers(0, 2**31 - 1), n_docs=st.integers(1, 300), vocab=st.integers(1, 40), k=st.integers(1, 50),
+       n_q=st.integers(1, 5))
+def test_bm25_topk_equals_rank_bm25_restated(seed, n_docs, vocab, k, n_q):
+    """All-document float64 scores bit-exact, the divisor (max if > 0 else 1.0), top-k rows (stable) and normalised scores,
+    for tiny corpora with empty documents, queries with repeated and out-of-vocabulary tokens, and k above the corpus size."""
+    from optimized_rag_amd.bm25 import Bm25Postings
+    rng = np.random.default_rng(seed)
+    docs = [[int(t) for t in rng.integers(0, vocab, int(rng.integers(0, 9)))] for _ in range(n_docs)]
+    if not any(docs):
+        docs[0] = [0]                                             # the reference warns and returns zeros for an all-empty corpus
+    corpus = [" ".join(f"t{t}" for t in d) for d in docs]
+    eng = _engine(64)
+    post = Bm25Postings.from_corpus(corpus).load(eng)
+    obm = O.BM25Okapi([O.tokenize(c) for c in corpus])
+    queries = []
+    for _ in range(n_q):
+        toks = [f"t{int(t)}" for t in rng.integers(0, vocab + 3, int(rng.integers(1, 7)))]      # ids >= vocab never occur
+        queries.append(" ".join(toks + toks[:1]))                                                # one repeated token
+    ptr, terms = post.encode_queries(queries)
+    ids, rows, scores, mx = eng.bm25_topk(ptr, terms, k)
+    dense = eng.bm25_scores(ptr, terms)
+    for qi, q in enumerate(queries):
+        raw = obm.get_scores(O.tokenize(q))
+        np.testing.assert_array_equal(dense[qi], raw)
+        m = raw.max() if raw.max() > 0 else 1.0
+        assert mx[qi] == m
+        top = O.stable_topk_desc(raw, k)
+        kk = len(top)
+        np.testing.assert_array_equal(rows[qi][:kk], top.astype(np.int32))
+        np.testing.assert_array_equal(scores[qi][:kk], raw[top] / m)
+        assert (rows[qi][kk:] == -1).all()
