@@ -32,7 +32,7 @@ COMMON = dict(deadline=None, max_examples=300, suppress_health_check=[HealthChec
 
 
 @settings(**COMMON)
-@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 700), q=st.integers(1, 9), k=st.integers(1, 40),
+@given(seed=st.integers(0, 2**31 - 1), n=st.one_of(st.integers(1, 700), st.integers(2040, 9000)), q=st.integers(1, 9), k=st.integers(1, 40),
        dim=st.sampled_from([64, 128]), dup=st.integers(0, 5), zeros=st.integers(0, 3), use_tenant=st.booleans())
 def test_dense_topk_equals_the_exact_scan(seed, n, q, k, dim, dup, zeros, use_tenant):
     """ids / rows identical to the float64 exact scan (stable: lower row first on equal scores), scores within 1e-9, for
