@@ -1120,7 +1120,8 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
         int end;
         if (stage == 0) end = stage0_tiles;
         else end = (int)std::min<int64_t>(total_tiles, (int64_t)begin * growth);
-        // avoid a tiny trailing stage
+        // avoid a tiny trailing stage (a universe of 9 tiles is ONE dense stage of 9 tiles: the select below must be told so -
+        // it was handed the nominal 2048 slots and lost the ninth tile's rows, found by tests/test_property_gpu.py)
         if (total_tiles - end < end / 4) end = total_tiles;
         const int n_rt = end - begin;
         const int grid = (int)round_up(n_rt, 8) * n_qtiles;
@@ -1154,7 +1155,7 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
         }
         const bool last = end == total_tiles;
         hipLaunchKernelGGL(select_kernel, dim3((Q + 3) / 4), dim3(256), SELECT_LDS_BYTES, st, h->cand, h->cnt, tau, h->bound,
-                           h->n_sorted, h->stats, Q, stage == 0 ? stage0_tiles * RAG_TILE : 0, k, two_eps, last ? 1 : 0,
+                           h->n_sorted, h->stats, Q, stage == 0 ? n_rt * RAG_TILE : 0, k, two_eps, last ? 1 : 0,
                            (const int*)nullptr);
         HIP_TRY(h, hipGetLastError());
         begin = end;

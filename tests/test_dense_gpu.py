@@ -53,6 +53,9 @@ def check(eng, corpus, queries, k, tenant_of_row=None, tenant=-1, ids=None):
     (9000, 384, 7, 100),         # large k -> larger shortlist
     (70000, 128, 3, 1),
     (17, 1536, 4, 20),           # fewer rows than k -> -1 padding
+    (2080, 64, 3, 1),            # 9 tiles: the one-tile trailing stage is merged into the dense stage 0 (2304 slots, not 2048)
+    (2304, 128, 5, 20),
+    (2305, 64, 4, 7),            # 10 tiles: the trailing stage stands on its own
 ])
 def test_dense_topk_matches_oracle(eng_factory, N, D, Q, k):
     rng = np.random.default_rng(N + D + Q + k)
@@ -381,3 +384,20 @@ def test_rccl_allgather_behind_the_c_abi_world_1():
         eng.comm_destroy()
     finally:
         eng.close()
+
+
+def test_tenant_with_nine_tiles_keeps_its_last_tile(eng_factory):
+    """A tenant whose rows span 9 tiles is searched as ONE dense stage of 9 tiles (regression: the select after that stage
+    was told 2048 slots and dropped the tenant's rows in its last tile; found by tests/test_property_gpu.py)."""
+    rng = np.random.default_rng(2300)
+    N, D = 6000, 64
+    corpus = rng.standard_normal((N, D)).astype(np.float32)
+    tenants = np.full(N, 1, dtype=np.int32)
+    tenants[700:3000] = 0                                          # rows 700..2999: tiles 2..11 -> 10 tiles, 2300 rows
+    tenants[700:768] = 1                                           # -> rows 768..2999: tiles 3..11 = exactly 9 tiles
+    eng = eng_factory(D)
+    eng.index_load(corpus)
+    eng.set_tenants(tenants)
+    queries = planted_queries(rng, corpus[768:3000], 12, noise=0.2)
+    st = check(eng, corpus, queries, 5, tenant_of_row=tenants, tenant=0)
+    assert st["exact_scan"] == 0

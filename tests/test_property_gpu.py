@@ -114,3 +114,35 @@ def test_bm25_topk_equals_rank_bm25_restated(seed, n_docs, vocab, k, n_q):
         np.testing.assert_array_equal(rows[qi][:kk], top.astype(np.int32))
         np.testing.assert_array_equal(scores[qi][:kk], raw[top] / m)
         assert (rows[qi][kk:] == -1).all()
+
+
+@settings(**COMMON)
+@given(seed=st.integers(0, 2**31 - 1), m=st.integers(1, 40), n=st.integers(1, 40), dim=st.sampled_from([4, 12, 64, 1536]),
+       zero_rows=st.integers(0, 2))
+def test_pairwise_cosine_equals_the_float64_formula(seed, m, n, dim, zero_rows):
+    """rag_pairwise_cosine_host (every `_cosine_similarity` copy of the reference): float64, 0.0 for a zero-norm side."""
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((m, dim)).astype(np.float32)
+    b = rng.standard_normal((n, dim)).astype(np.float32)
+    for _ in range(zero_rows):
+        a[rng.integers(0, m)] = 0.0
+        b[rng.integers(0, n)] = 0.0
+    got = _engine(64).pairwise_cosine(a, b)
+    np.testing.assert_allclose(got, O.cosine_matrix(a, b), rtol=0, atol=1e-12)
+
+
+@settings(**COMMON)
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 3000), top_k=st.integers(1, 64), decimals=st.integers(0, 3),
+       with_temporal=st.booleans())
+def test_linear_fusion_topk_is_the_stable_sort(seed, n, top_k, decimals, with_temporal):
+    """alpha*sem + beta*kw (+ gamma*temporal) in CPython's operation order, then the reference's stable descending sort: coarse
+    rounding of the inputs makes exact ties the common case."""
+    rng = np.random.default_rng(seed)
+    sem = np.round(rng.uniform(-1, 1, n), decimals)
+    kw = np.round(rng.uniform(0, 1, n), decimals)
+    tmp = np.round(rng.uniform(0, 0.15, n), decimals + 1) if with_temporal else None
+    al, be, ga = 0.55, 0.35, 0.10
+    idx, hyb = _engine(64).linear_fuse_topk(sem, kw, tmp, al, be, ga, top_k)
+    exp = [(al * sem[i] + be * kw[i]) + (ga * tmp[i] if with_temporal else 0.0) for i in range(n)]
+    assert hyb.tolist() == exp
+    assert idx.tolist() == [int(i) for i in O.stable_topk_desc(exp, min(top_k, n))]
