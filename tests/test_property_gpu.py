@@ -5,7 +5,7 @@ import os
 
 import numpy as np
 import pytest
-from hypothesis import HealthCheck, given, settings
+from hypothesis import HealthCheck, assume, given, settings
 from hypothesis import strategies as st
 
 from oracle import rag_oracle as O
@@ -35,11 +35,12 @@ COMMON = dict(deadline=None, max_examples=N_EX, suppress_health_check=[HealthChe
 
 
 @settings(**COMMON)
-@given(seed=st.integers(0, 2**31 - 1), n=st.one_of(st.integers(1, 700), st.integers(2040, 9000), st.integers(16000, 40000)), q=st.integers(1, 20),
-       k=st.one_of(st.integers(1, 40), st.integers(100, 256)), dim=st.sampled_from([64, 128]), dup=st.integers(0, 5), zeros=st.integers(0, 3), use_tenant=st.booleans())
+@given(seed=st.integers(0, 2**31 - 1), n=st.one_of(st.integers(1, 700), st.integers(2040, 9000), st.integers(16000, 40000)), q=st.one_of(st.integers(1, 20), st.integers(120, 140), st.integers(250, 270)),
+       k=st.one_of(st.integers(1, 40), st.integers(100, 256)), dim=st.sampled_from([64, 128, 384]), dup=st.integers(0, 5), zeros=st.integers(0, 3), use_tenant=st.booleans())
 def test_dense_topk_equals_the_exact_scan(seed, n, q, k, dim, dup, zeros, use_tenant):
     """ids / rows identical to the float64 exact scan (stable: lower row first on equal scores), scores within 1e-9, for
     corpora with duplicated rows (exact score ties), zero rows (cosine 0.0) and an optional tenant filter."""
+    assume(n * q <= 1_500_000)                                    # keeps the float64 exact scan of the oracle at ~50 ms per example
     rng = np.random.default_rng(seed)
     corpus = rng.standard_normal((n, dim)).astype(np.float32)
     for _ in range(min(dup, n)):                                  # exact duplicates: ties that the row order must break
@@ -219,3 +220,39 @@ def test_cross_encoder_logits_equal_the_float64_forward(seed, layers, n_pairs, l
     exp = B.forward_logits(w, cfg, ids[sel].astype(np.int64), tt[sel].astype(np.int64), lens[sel], fast_erf=True)
     assert np.isfinite(got).all()
     assert np.abs(got[sel] - exp).max() < 4e-3, (got[sel], exp)
+
+
+@settings(**COMMON)
+@given(seed=st.integers(0, 2**31 - 1), n_rows=st.integers(1, 60), ld=st.integers(1, 48), lq=st.integers(1, 40),
+       l_pair=st.integers(8, 72), q=st.integers(1, 4), pool=st.integers(1, 9), id_base=st.sampled_from([0, 1000]))
+def test_pair_assembly_is_the_tokenizers_longest_first(seed, n_rows, ld, lq, l_pair, q, pool, id_base):
+    """rag_ce_build_pairs_dev == [CLS] query [SEP] passage [SEP] with `longest_first` truncation to max_length (one token at
+    a time from the longer side, the passage on ties - oracle pinned to `tokenizers` in tests/test_pair_truncation.py), token
+    types, lengths and zero padding, for empty candidates (-1), 1-token sides and max_length below either side."""
+    import torch
+    rng = np.random.default_rng(seed)
+    tok = rng.integers(200, 5000, (n_rows, ld)).astype(np.int32)
+    tok_len = rng.integers(0, ld + 1, n_rows).astype(np.int32)
+    q_tok = rng.integers(200, 5000, (q, lq)).astype(np.int32)
+    q_len = rng.integers(1, lq + 1, q).astype(np.int32)
+    cand_rows = rng.integers(-1, n_rows, (q, pool)).astype(np.int64)             # -1 = empty slot
+    eng = _engine(64)
+    eng.index_load(np.ones((n_rows, 64), dtype=np.float32), id_base=id_base)     # the token store must be row-aligned with an index
+    eng.tokens_load(tok, tok_len)
+    cand = np.where(cand_rows >= 0, cand_rows + id_base, -1)
+    ids = torch.zeros((q * pool, l_pair), dtype=torch.int32, device="cuda")
+    tt = torch.zeros_like(ids)
+    lens = torch.zeros((q * pool,), dtype=torch.int32, device="cuda")
+    eng.ce_build_pairs_dev(torch.from_numpy(q_tok).cuda(), torch.from_numpy(q_len).cuda(), torch.from_numpy(cand).cuda(), ids, tt, lens,
+                           token_id_base=id_base)
+    torch.cuda.synchronize()
+    CLS, SEP = 101, 102
+    for qi in range(q):
+        for j in range(pool):
+            r = int(cand_rows[qi, j])
+            ql, dl = O.longest_first_lengths(int(q_len[qi]), 0 if r < 0 else int(tok_len[r]), l_pair - 3)
+            row = [CLS] + list(q_tok[qi, :ql]) + [SEP] + ([] if r < 0 else list(tok[r, :dl])) + [SEP]
+            p = qi * pool + j
+            assert int(lens[p]) == len(row)
+            assert ids[p].tolist() == row + [0] * (l_pair - len(row))
+            assert tt[p].tolist() == [0] * (ql + 2) + [1] * (len(row) - ql - 2) + [0] * (l_pair - len(row))
