@@ -256,3 +256,76 @@ def test_pair_assembly_is_the_tokenizers_longest_first(seed, n_rows, ld, lq, l_p
             assert int(lens[p]) == len(row)
             assert ids[p].tolist() == row + [0] * (l_pair - len(row))
             assert tt[p].tolist() == [0] * (ql + 2) + [1] * (len(row) - ql - 2) + [0] * (l_pair - len(row))
+
+
+@settings(**COMMON)
+@given(seed=st.integers(0, 2**31 - 1), n_lists=st.integers(1, 8), q=st.integers(1, 12), k=st.integers(1, 50), decimals=st.integers(0, 2),
+       fill=st.floats(0.0, 1.0))
+def test_merge_topk_is_score_desc_then_id_asc(seed, n_lists, q, k, decimals, fill):
+    """rag_merge_topk_dev (the merge after the all-gather of the row-sharded search): the k best (score desc, doc id asc) of
+    n_lists per-shard lists with -1 padded tails, coarse scores (exact ties across shards) and disjoint id ranges."""
+    import torch
+    rng = np.random.default_rng(seed)
+    ids = np.full((n_lists, q, k), -1, dtype=np.int64)
+    sc = np.zeros((n_lists, q, k), dtype=np.float64)
+    for l in range(n_lists):
+        for qi in range(q):
+            m = int(round(fill * k)) if rng.uniform() < 0.7 else int(rng.integers(0, k + 1))
+            s = np.sort(np.round(rng.uniform(-1, 1, m), decimals))[::-1]
+            order_ids = l * 1000 + np.sort(rng.choice(1000, m, replace=False))
+            # a shard's own list is (score desc, id asc): ids ascending inside runs of equal scores
+            for v in np.unique(s):
+                run = np.nonzero(s == v)[0]
+                order_ids[run] = np.sort(order_ids[run])
+            ids[l, qi, :m], sc[l, qi, :m] = order_ids, s
+    eng = _engine(64)
+    oi = torch.empty((q, k), dtype=torch.int64, device="cuda")
+    os_ = torch.empty((q, k), dtype=torch.float64, device="cuda")
+    eng.merge_topk_dev(torch.from_numpy(ids).cuda(), torch.from_numpy(sc).cuda(), oi, os_)
+    torch.cuda.synchronize()
+    oi, os_ = oi.cpu().numpy(), os_.cpu().numpy()
+    for qi in range(q):
+        pairs = sorted(((-float(sc[l, qi, j]), int(ids[l, qi, j])) for l in range(n_lists) for j in range(k) if ids[l, qi, j] >= 0))[:k]
+        m = len(pairs)
+        assert oi[qi, :m].tolist() == [p[1] for p in pairs] and (oi[qi, m:] == -1).all()
+        assert os_[qi, :m].tolist() == [-p[0] for p in pairs]
+
+
+@settings(**{**COMMON, "max_examples": max(20, N_EX // 6)})
+@given(seed=st.integers(0, 2**31 - 1), n_docs=st.integers(16000, 36000), vocab=st.integers(5, 200), k=st.integers(1, 120),
+       use_tenant=st.booleans())
+def test_bm25_over_several_doc_ranges_with_tenants(seed, n_docs, vocab, k, use_tenant):
+    """Two or three 16384-document ranges (staged thresholds, running merge), optional tenant filter: rows, normalised scores
+    and the divisor equal the restated rank-bm25 scores masked to the tenant."""
+    from optimized_rag_amd.bm25 import Bm25Postings
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, 6, n_docs)
+    flat = rng.integers(0, vocab, int(lens.sum()))
+    docs, p = [], 0
+    for L in lens:
+        docs.append(flat[p:p + L])
+        p += L
+    corpus = [" ".join(f"t{t}" for t in d) for d in docs]
+    eng = _engine(64)
+    eng.index_load(np.ones((n_docs, 64), dtype=np.float32))
+    tenants, tenant = None, -1
+    if use_tenant:
+        tenants = rng.integers(0, 3, n_docs).astype(np.int32)
+        tenants[n_docs - 300:] = 2
+        tenant = int(rng.integers(0, 3))
+    eng.set_tenants(tenants)
+    post = Bm25Postings.from_corpus(corpus).load(eng)
+    obm = O.BM25Okapi([O.tokenize(c) for c in corpus])
+    queries = [" ".join(f"t{int(t)}" for t in rng.integers(0, vocab + 2, int(rng.integers(1, 5)))) for _ in range(3)]
+    ptr, terms = post.encode_queries(queries)
+    ids, rows, scores, mx = eng.bm25_topk(ptr, terms, k, tenant=tenant)
+    mine = np.arange(n_docs) if not use_tenant else np.nonzero(tenants == tenant)[0]
+    for qi, q in enumerate(queries):
+        raw = obm.get_scores(O.tokenize(q))[mine]
+        m = raw.max() if raw.size and raw.max() > 0 else 1.0
+        assert mx[qi] == m
+        top = O.stable_topk_desc(raw, k)
+        kk = len(top)
+        np.testing.assert_array_equal(rows[qi][:kk], mine[top].astype(np.int32))
+        np.testing.assert_array_equal(scores[qi][:kk], raw[top] / m)
+    eng.set_tenants(None)
