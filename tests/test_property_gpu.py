@@ -329,3 +329,30 @@ def test_bm25_over_several_doc_ranges_with_tenants(seed, n_docs, vocab, k, use_t
         np.testing.assert_array_equal(rows[qi][:kk], mine[top].astype(np.int32))
         np.testing.assert_array_equal(scores[qi][:kk], raw[top] / m)
     eng.set_tenants(None)
+
+
+@settings(**{**COMMON, "max_examples": max(20, N_EX // 3)})
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 6000), cuts=st.lists(st.floats(0.0, 1.0), min_size=0, max_size=5), k=st.integers(1, 30),
+       search_midway=st.booleans())
+def test_chunked_appends_equal_the_one_shot_load(seed, n, cuts, k, search_midway):
+    """rag_index_reserve + appends of arbitrary block sizes (host and device blocks, 1-row blocks, blocks that straddle 256-row
+    tiles) give the same search results as one rag_index_load, and the part loaded so far is searchable."""
+    import torch
+    rng = np.random.default_rng(seed)
+    dim = 64
+    corpus = rng.standard_normal((n, dim)).astype(np.float32)
+    queries = (corpus[rng.integers(0, n, 4)] + 0.3 * rng.standard_normal((4, dim))).astype(np.float32)
+    bounds = sorted({0, n, *[int(c * n) for c in cuts]})
+    eng = _engine(dim)
+    eng.index_reserve(n, id_base=77)
+    for bi, (a, b) in enumerate(zip(bounds[:-1], bounds[1:])):
+        blk = corpus[a:b]
+        eng.index_append(torch.from_numpy(blk).cuda() if bi % 2 else blk)
+        if search_midway and b < n:
+            rows = eng.dense_topk(queries, k)[1]
+            np.testing.assert_array_equal(rows, O.dense_topk(corpus[:b], queries, k)[0].astype(np.int32))
+    ids, rows, sc = eng.dense_topk(queries, k)
+    oid, osc = O.dense_topk(corpus, queries, k)
+    np.testing.assert_array_equal(rows, oid.astype(np.int32))
+    np.testing.assert_array_equal(ids, np.where(oid >= 0, oid + 77, -1))
+    np.testing.assert_allclose(sc, osc, rtol=0, atol=1e-9)
