@@ -356,3 +356,33 @@ def test_chunked_appends_equal_the_one_shot_load(seed, n, cuts, k, search_midway
     np.testing.assert_array_equal(rows, oid.astype(np.int32))
     np.testing.assert_array_equal(ids, np.where(oid >= 0, oid + 77, -1))
     np.testing.assert_allclose(sc, osc, rtol=0, atol=1e-9)
+
+
+@settings(**{**COMMON, "max_examples": max(20, N_EX // 3)})
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 40), top_k=st.integers(1, 12), lam=st.sampled_from([0.0, 0.3, 0.5, 0.7, 1.0]),
+       variant=st.integers(0, 1), dup=st.integers(0, 3), zero=st.booleans())
+def test_mmr_greedy_loop_on_the_device(seed, n, top_k, lam, variant, dup, zero):
+    """rag_mmr_select_host == the reference's greedy loops (class formula and helper formula): same picks in the same order
+    for candidate sets with duplicates (exact ties: the first maximal element wins), a zero vector, lambda at both ends, and
+    fewer candidates than top_k."""
+    rng = np.random.default_rng(seed)
+    dim = 16
+    embs = rng.standard_normal((n, dim)).astype(np.float32)
+    for _ in range(dup):
+        a, b = rng.integers(0, n, 2)
+        embs[a] = embs[b]
+    if zero:
+        embs[rng.integers(0, n)] = 0.0
+    q = rng.standard_normal(dim).astype(np.float32)
+    cand = [e.astype(np.float64).tolist() for e in embs]
+    ql = q.astype(np.float64).tolist()
+    if variant == 0:
+        pos, osc = O.mmr_class(ql, cand, top_k, lam)
+    else:
+        if n <= top_k:
+            return                                                  # apply_mmr returns its input unchanged (host-side rule)
+        pos, osc = O.mmr_helper(ql, cand, top_k, lam), None
+    hs, hsc = _engine(64).mmr_select(q, embs, top_k, lam, variant)
+    assert hs.tolist() == pos
+    if osc is not None:
+        np.testing.assert_allclose(hsc, osc, rtol=0, atol=1e-12)
