@@ -386,3 +386,57 @@ def test_mmr_greedy_loop_on_the_device(seed, n, top_k, lam, variant, dup, zero):
     assert hs.tolist() == pos
     if osc is not None:
         np.testing.assert_allclose(hsc, osc, rtol=0, atol=1e-12)
+
+
+@settings(**{**COMMON, "max_examples": max(20, N_EX // 6)})
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 400), k=st.integers(1, 30), vocab=st.integers(1, 12), q=st.integers(1, 5),
+       weights=st.sampled_from([(0.55, 0.35, 0.10), (0.7, 0.2, 0.1), (0.4, 0.5, 0.1), (1.0, 0.0, 0.0)]), with_temporal=st.booleans())
+def test_index_level_linear_hybrid_equals_the_reference_formula(seed, n, k, vocab, q, weights, with_temporal):
+    """rag_hybrid_linear_dev over a tiny resident index == alpha*cos + beta*(BM25 / max) + gamma*temporal for EVERY row in the
+    reference's operation order, stable descending sort, first k: tiny vocabularies make keyword ties the common case, empty
+    documents and duplicated rows tie on every component (lower row first)."""
+    import torch
+    from optimized_rag_amd.bm25 import Bm25Postings
+    rng = np.random.default_rng(seed)
+    dim = 64
+    docs = [[int(t) for t in rng.integers(0, vocab, int(rng.integers(0, 6)))] for _ in range(n)]
+    if not any(docs):
+        docs[0] = [0]
+    emb = rng.standard_normal((n, dim)).astype(np.float32)
+    if n > 3:
+        docs[n - 1], emb[n - 1] = docs[1], emb[1]                   # an exact duplicate of row 1 at the end of the table
+    corpus = [" ".join(f"t{t}" for t in d) for d in docs]
+    temporal = np.where(rng.uniform(size=n) < 0.4, np.round(rng.uniform(0, 0.15, n), 3), 0.0) if with_temporal else None
+    if temporal is not None and n > 3:
+        temporal[n - 1] = temporal[1]
+    qe = (emb[rng.integers(0, n, q)] + 0.4 * rng.standard_normal((q, dim))).astype(np.float32)
+    queries = [" ".join(f"t{int(t)}" for t in rng.integers(0, vocab + 1, int(rng.integers(1, 5)))) for _ in range(q)]
+    a, b, g = weights
+    eng = _engine(dim)
+    eng.index_load(emb)
+    eng.set_temporal(temporal)
+    post = Bm25Postings.from_corpus(corpus).load(eng)
+    ptr, terms = post.encode_queries(queries)
+    kk = min(k, n)
+    out = eng.hybrid_linear_dev(torch.from_numpy(qe).cuda(), torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda(), kk, a, b, g)
+    torch.cuda.synchronize()
+    got = {key: v.cpu().numpy() for key, v in out.items()}
+    tmp = [0.0] * n if temporal is None else [float(x) for x in temporal]
+    for qi, query in enumerate(queries):
+        sem = [O.cosine(qe[qi].astype(np.float64).tolist(), e.astype(np.float64).tolist()) for e in emb]
+        kw = O.bm25_scores(query, corpus)
+        hyb = [a * sem[i] + b * kw[i] + g * tmp[i] for i in range(n)]
+        # candidates whose exact hybrid scores are closer than the cosine's last bits can legitimately swap: compare as sets
+        # there, exactly otherwise
+        idx = [int(i) for i in O.stable_topk_desc(hyb, kk)]
+        rows = got["rows"][qi].tolist()
+        gaps_ok = all(abs(hyb[idx[j]] - hyb[idx[j + 1]]) > 1e-12 or hyb[idx[j]] == hyb[idx[j + 1]] for j in range(len(idx) - 1))
+        if gaps_ok and (kk == n or abs(hyb[idx[-1]] - sorted(hyb, reverse=True)[min(kk, n - 1)]) > 1e-12 or kk == n):
+            assert rows == idx, (rows, idx)
+        else:
+            assert sorted(rows) == sorted(idx)
+        assert got["keyword"][qi].tolist() == [kw[i] for i in rows]
+        assert got["temporal"][qi].tolist() == [tmp[i] for i in rows]
+        np.testing.assert_allclose(got["semantic"][qi], [sem[i] for i in rows], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(got["hybrid"][qi], [hyb[i] for i in rows], rtol=0, atol=1e-12)
+    eng.set_temporal(None)
