@@ -440,3 +440,41 @@ def test_index_level_linear_hybrid_equals_the_reference_formula(seed, n, k, voca
         np.testing.assert_allclose(got["semantic"][qi], [sem[i] for i in rows], rtol=0, atol=1e-12)
         np.testing.assert_allclose(got["hybrid"][qi], [hyb[i] for i in rows], rtol=0, atol=1e-12)
     eng.set_temporal(None)
+
+
+@settings(**{**COMMON, "max_examples": max(20, N_EX // 6)})
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 5000), cuts=st.lists(st.floats(0.0, 1.0), min_size=1, max_size=3), k=st.integers(1, 25),
+       q=st.integers(1, 6))
+def test_row_sharded_dense_search_equals_the_unsharded_one(seed, n, cuts, k, q):
+    """SURVEY 8e on one GPU: 2-4 engines hold contiguous row shards of arbitrary sizes (a shard may be EMPTY), each answers
+    with its local top-k under its id_base, rag_merge_topk_dev merges: ids and scores of the unsharded exact scan."""
+    import torch
+    rng = np.random.default_rng(seed)
+    dim = 64
+    corpus = rng.standard_normal((n, dim)).astype(np.float32)
+    if n > 10:
+        corpus[n - 1] = corpus[0]                                   # an exact tie between the first and the last shard
+    queries = (corpus[rng.integers(0, n, q)] + 0.3 * rng.standard_normal((q, dim))).astype(np.float32)
+    bounds = sorted([0, n] + [int(c * n) for c in cuts])            # duplicates allowed: empty shards
+    parts_i, parts_s = [], []
+    for si, (a, b) in enumerate(zip(bounds[:-1], bounds[1:])):
+        eng = _shard_engine(si, dim)
+        eng.index_load(corpus[a:b], id_base=a)
+        i, _, s = eng.dense_topk(queries, k)
+        parts_i.append(i)
+        parts_s.append(s)
+    oi = torch.empty((q, k), dtype=torch.int64, device="cuda")
+    os_ = torch.empty((q, k), dtype=torch.float64, device="cuda")
+    _engine(dim).merge_topk_dev(torch.from_numpy(np.stack(parts_i)).cuda(), torch.from_numpy(np.stack(parts_s)).cuda(), oi, os_)
+    torch.cuda.synchronize()
+    oid, osc = O.dense_topk(corpus, queries, k)
+    np.testing.assert_array_equal(oi.cpu().numpy(), oid)
+    np.testing.assert_allclose(os_.cpu().numpy(), osc, rtol=0, atol=1e-9)
+
+
+def _shard_engine(i, dim):
+    from optimized_rag_amd import RagEngine
+    key = ("shard", i, dim)
+    if key not in _ENGINES:
+        _ENGINES[key] = RagEngine(dim=dim, device=0)
+    return _ENGINES[key]
