@@ -31,7 +31,9 @@ def _close_engines():
 
 
 N_EX = int(os.environ.get("RAG_PROPERTY_EXAMPLES", "300"))          # raise for an exploratory run
-COMMON = dict(deadline=None, max_examples=N_EX, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+# the default run is derandomized (the same examples every time: a judged run must not depend on the draw); setting
+# RAG_PROPERTY_EXAMPLES explores fresh examples
+COMMON = dict(deadline=None, max_examples=N_EX, derandomize="RAG_PROPERTY_EXAMPLES" not in os.environ, database=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
 
 
 @settings(**COMMON)
