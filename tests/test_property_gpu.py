@@ -480,3 +480,30 @@ def _shard_engine(i, dim):
     if key not in _ENGINES:
         _ENGINES[key] = RagEngine(dim=dim, device=0)
     return _ENGINES[key]
+
+
+@settings(**{**COMMON, "max_examples": max(20, N_EX // 3)})
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 1200), q=st.one_of(st.integers(1, 8), st.integers(500, 1100)), k=st.integers(1, 256),
+       dim=st.sampled_from([4, 100, 1536]), explicit_ids=st.booleans(), tenant_mode=st.sampled_from(["none", "some", "absent"]))
+def test_dense_topk_odd_dims_explicit_ids_absent_tenant(seed, n, q, k, dim, explicit_ids, tenant_mode):
+    """Dimensions that are not a multiple of the 64-wide K step (zero-padded operand rows), up to 1100 queries against a tiny
+    table (several query tiles), k up to 256, explicit primary keys, and a tenant that owns no row at all (-1 everywhere)."""
+    assume(n * q * dim <= 2.0e8)
+    rng = np.random.default_rng(seed)
+    corpus = rng.standard_normal((n, dim)).astype(np.float32)
+    queries = (corpus[rng.integers(0, n, q)] + 0.25 * rng.standard_normal((q, dim))).astype(np.float32)
+    eng = _engine(dim)
+    ids = (rng.permutation(n).astype(np.int64) * 7 + 1_000_000) if explicit_ids else None
+    eng.index_load(corpus, ids=ids)
+    tenants, tenant = None, -1
+    if tenant_mode != "none":
+        tenants = rng.integers(0, 3, n).astype(np.int32)
+        tenant = int(rng.integers(0, 3)) if tenant_mode == "some" else 9          # tenant 9 owns nothing
+        eng.set_tenants(tenants)
+    got_ids, got_rows, got_sc = eng.dense_topk(queries, k, tenant=tenant)
+    oid, osc = O.dense_topk(corpus, queries, k, tenants, tenant if tenants is not None else None)
+    np.testing.assert_array_equal(got_rows, oid.astype(np.int32))
+    exp_ids = oid if ids is None else np.where(oid >= 0, ids[np.maximum(oid, 0)], -1)
+    np.testing.assert_array_equal(got_ids, exp_ids)
+    np.testing.assert_allclose(got_sc, osc, rtol=0, atol=1e-9)
+    eng.set_tenants(None)
