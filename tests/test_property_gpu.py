@@ -507,3 +507,58 @@ def test_dense_topk_odd_dims_explicit_ids_absent_tenant(seed, n, q, k, dim, expl
     np.testing.assert_array_equal(got_ids, exp_ids)
     np.testing.assert_allclose(got_sc, osc, rtol=0, atol=1e-9)
     eng.set_tenants(None)
+
+
+@settings(**{**COMMON, "max_examples": max(8, N_EX // 25)})
+@given(seed=st.integers(0, 2**31 - 1), hidden=st.sampled_from([128, 256, 512]), ffn_mult=st.sampled_from([1, 2, 4]), n_pairs=st.integers(1, 30),
+       l_in=st.integers(2, 120))
+def test_cross_encoder_other_hidden_sizes_take_the_unfused_path(seed, hidden, ffn_mult, n_pairs, l_in):
+    """Hidden sizes other than 384 (head dim 32, multiples of 128) run the residual GEMM + stand-alone LayerNorm path instead
+    of the fused one: logits within 4e-3 of the float64 forward."""
+    from oracle import bert_oracle as B
+    from optimized_rag_amd.cross_encoder import flatten_state_dict
+    cfg = dict(vocab_size=1500, hidden=hidden, layers=2, heads=hidden // 32, ffn=hidden * ffn_mult, max_pos=128, type_vocab=2, eps=1e-12)
+    key = ("ce", hidden, ffn_mult)
+    if key not in _CE_WEIGHTS:
+        _CE_WEIGHTS[key] = B.seeded_weights(cfg, hidden + ffn_mult)
+    w = _CE_WEIGHTS[key]
+    eng = _engine(64)
+    eng.ce_load(cfg, flatten_state_dict(w, 2))
+    eng._prop_ce_layers = None                                    # the 384-wide property above reloads its own model
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(1, l_in + 1, n_pairs).astype(np.int32)
+    lens[0] = l_in
+    ids = rng.integers(5, cfg["vocab_size"], (n_pairs, l_in)).astype(np.int32)
+    ids[np.arange(l_in)[None, :] >= lens[:, None]] = 0
+    tt = ((np.arange(l_in)[None, :] >= 5) & (np.arange(l_in)[None, :] < lens[:, None])).astype(np.int32)
+    got = eng.ce_score(ids, tt, lens)
+    sel = np.unique(np.concatenate([[0, n_pairs - 1], rng.integers(0, n_pairs, 2)]))
+    exp = B.forward_logits(w, cfg, ids[sel].astype(np.int64), tt[sel].astype(np.int64), lens[sel], fast_erf=True)
+    assert np.isfinite(got).all()
+    assert np.abs(got[sel] - exp).max() < 4e-3, (got[sel], exp)
+
+
+def test_cross_encoder_unfused_layernorm_path_at_hidden_384(monkeypatch):
+    """RAG_CE_NO_FUSED_LN=1 sends the MiniLM shape through the residual GEMM + stand-alone LayerNorm kernels: same logits as
+    the fused path to rounding, both within 4e-3 of the float64 forward."""
+    from oracle import bert_oracle as B
+    from optimized_rag_amd.cross_encoder import flatten_state_dict
+    cfg = dict(vocab_size=3000, hidden=384, layers=2, heads=12, ffn=1536, max_pos=128, type_vocab=2, eps=1e-12)
+    w = B.seeded_weights(cfg, 11)
+    eng = _engine(64)
+    eng.ce_load(cfg, flatten_state_dict(w, 2))
+    eng._prop_ce_layers = None
+    rng = np.random.default_rng(5)
+    P, L = 300, 96
+    lens = rng.integers(1, L + 1, P).astype(np.int32)
+    ids = rng.integers(5, cfg["vocab_size"], (P, L)).astype(np.int32)
+    ids[np.arange(L)[None, :] >= lens[:, None]] = 0
+    tt = ((np.arange(L)[None, :] >= 9) & (np.arange(L)[None, :] < lens[:, None])).astype(np.int32)
+    fused = eng.ce_score(ids, tt, lens)
+    monkeypatch.setenv("RAG_CE_NO_FUSED_LN", "1")
+    plain = eng.ce_score(ids, tt, lens)
+    monkeypatch.delenv("RAG_CE_NO_FUSED_LN")
+    assert np.abs(fused - plain).max() < 1e-3
+    sel = [0, 1, 150, 299]
+    exp = B.forward_logits(w, cfg, ids[sel].astype(np.int64), tt[sel].astype(np.int64), lens[sel], fast_erf=True)
+    assert np.abs(plain[sel] - exp).max() < 4e-3 and np.abs(fused[sel] - exp).max() < 4e-3
