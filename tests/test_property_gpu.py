@@ -562,3 +562,76 @@ def test_cross_encoder_unfused_layernorm_path_at_hidden_384(monkeypatch):
     sel = [0, 1, 150, 299]
     exp = B.forward_logits(w, cfg, ids[sel].astype(np.int64), tt[sel].astype(np.int64), lens[sel], fast_erf=True)
     assert np.abs(plain[sel] - exp).max() < 4e-3 and np.abs(fused[sel] - exp).max() < 4e-3
+
+
+@settings(**{**COMMON, "max_examples": max(8, N_EX // 25)})
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 200), q=st.integers(1, 4), pool=st.integers(1, 12), k=st.integers(1, 8),
+       hybrid=st.booleans(), l_pair=st.integers(8, 48), id_base=st.sampled_from([0, 5000]))
+def test_one_call_retrieve_rerank_equals_the_composition(seed, n, q, pool, k, hybrid, l_pair, id_base):
+    """rag_retrieve_rerank_dev on tiny indexes (fewer rows than the pool: empty candidate slots; dense or dense + BM25 + RRF
+    candidates): candidate lists bit-exact, logits within 4e-3 and sigmoid scores within 1e-3 of the float64 forward on the
+    numpy-assembled pairs, ids a permutation-consistent top-k of the candidates."""
+    import torch
+    from oracle import bert_oracle as B
+    from optimized_rag_amd.bm25 import Bm25Postings
+    from optimized_rag_amd.cross_encoder import flatten_state_dict
+    k = min(k, pool)
+    cfg = dict(vocab_size=1500, hidden=384, layers=1, heads=12, ffn=1536, max_pos=64, type_vocab=2, eps=1e-12)
+    if "pipe" not in _CE_WEIGHTS:
+        _CE_WEIGHTS["pipe"] = B.seeded_weights(cfg, 77)
+    w = _CE_WEIGHTS["pipe"]
+    rng = np.random.default_rng(seed)
+    dim, ld, lq = 64, 20, 10
+    emb = rng.standard_normal((n, dim)).astype(np.float32)
+    qe = (emb[rng.integers(0, n, q)] + 0.4 * rng.standard_normal((q, dim))).astype(np.float32)
+    tok = rng.integers(200, cfg["vocab_size"], (n, ld)).astype(np.int32)
+    tok_len = rng.integers(1, ld + 1, n).astype(np.int32)
+    q_tok = rng.integers(200, cfg["vocab_size"], (q, lq)).astype(np.int32)
+    q_len = rng.integers(1, lq + 1, q).astype(np.int32)
+    corpus = [" ".join(f"t{t}" for t in tok[i, :tok_len[i]] % 15) for i in range(n)]
+    queries = [" ".join(f"t{t}" for t in q_tok[i, :q_len[i]] % 15) for i in range(q)]
+    eng = _engine(dim)
+    eng.index_load(emb, id_base=id_base)
+    eng.tokens_load(tok, tok_len)
+    eng.ce_load(cfg, flatten_state_dict(w, 1))
+    eng._prop_ce_layers = None
+    post = Bm25Postings.from_corpus(corpus).load(eng)
+    ptr, terms = post.encode_queries(queries)
+    args = dict(term_ptr=torch.from_numpy(ptr).cuda(), terms=torch.from_numpy(terms).cuda()) if hybrid else {}
+    ids, sc, lg, cand = eng.retrieve_rerank_dev(torch.from_numpy(qe).cuda(), torch.from_numpy(q_tok).cuda(), torch.from_numpy(q_len).cuda(),
+                                                pool, k, L_pair=l_pair, cls_id=101, sep_id=102, **args)
+    torch.cuda.synchronize()
+    ids, sc, lg, cand = ids.cpu().numpy(), sc.cpu().numpy(), lg.cpu().numpy(), cand.cpu().numpy()
+    d_rows, _ = O.dense_topk(emb, qe, pool)
+    ocand = np.full((q, pool), -1, dtype=np.int64)
+    if hybrid:
+        obm = O.BM25Okapi([O.tokenize(c) for c in corpus])
+        for qi in range(q):
+            b_rows = O.stable_topk_desc(obm.get_scores(O.tokenize(queries[qi])), pool)
+            keys, _, _ = O.rrf_fuse([[int(r) for r in d_rows[qi] if r >= 0], [int(r) for r in b_rows]], k=60, top_k=pool)
+            ocand[qi, :len(keys)] = keys
+    else:
+        ocand = d_rows.astype(np.int64)
+    np.testing.assert_array_equal(cand, np.where(ocand >= 0, ocand + id_base, -1))
+    for qi in range(q):
+        live = [j for j in range(pool) if ocand[qi, j] >= 0]
+        rows_ids, rows_tt, rows_len = [], [], []
+        for j in live:
+            r = int(ocand[qi, j])
+            ql, dl = O.longest_first_lengths(int(q_len[qi]), int(tok_len[r]), l_pair - 3)
+            row = [101] + list(q_tok[qi, :ql]) + [102] + list(tok[r, :dl]) + [102]
+            rows_ids.append(row + [0] * (l_pair - len(row)))
+            rows_tt.append([0] * (ql + 2) + [1] * (len(row) - ql - 2) + [0] * (l_pair - len(row)))
+            rows_len.append(len(row))
+        ologit = B.forward_logits(w, cfg, np.asarray(rows_ids, dtype=np.int64), np.asarray(rows_tt, dtype=np.int64), np.asarray(rows_len), fast_erf=True)
+        by_id = {int(ocand[qi, j]) + id_base: float(ologit[t]) for t, j in enumerate(live)}
+        kk = min(k, len(live))
+        assert (ids[qi, kk:] == -1).all()
+        for t in range(kk):
+            assert int(ids[qi, t]) in by_id
+            assert abs(float(lg[qi, t]) - by_id[int(ids[qi, t])]) < 4e-3
+            assert abs(float(sc[qi, t]) - O.sigmoid(by_id[int(ids[qi, t])])) < 1e-3
+        assert len(set(ids[qi, :kk].tolist())) == kk
+        assert all(sc[qi, t] >= sc[qi, t + 1] for t in range(kk - 1))
+        worst_kept = min(by_id[int(i)] for i in ids[qi, :kk]) if kk else 0.0
+        assert all(v <= worst_kept + 8e-3 for i, v in by_id.items() if i not in set(ids[qi, :kk].tolist()))
