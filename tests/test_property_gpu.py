@@ -385,9 +385,27 @@ def test_mmr_greedy_loop_on_the_device(seed, n, top_k, lam, variant, dup, zero):
             return                                                  # apply_mmr returns its input unchanged (host-side rule)
         pos, osc = O.mmr_helper(ql, cand, top_k, lam), None
     hs, hsc = _engine(64).mmr_select(q, embs, top_k, lam, variant)
-    assert hs.tolist() == pos
-    if osc is not None:
-        np.testing.assert_allclose(hsc, osc, rtol=0, atol=1e-12)
+    got = hs.tolist()
+    if got == pos:
+        if osc is not None:
+            np.testing.assert_allclose(hsc, osc, rtol=0, atol=1e-12)
+        return
+    # The picks may only part ways at a numerical tie: cos(x, x) of duplicated vectors is 1 +- 1 ulp depending on the
+    # summation order (CPython sums left to right, the kernel reduces in parallel), which decides e.g. between two candidates
+    # that both duplicate an already selected one when lambda = 0. At the first difference the device's pick must score within
+    # 1e-12 of the reference's best under the REFERENCE's arithmetic; later picks then differ legitimately.
+    assert len(got) == len(pos)
+    j = next(i for i in range(len(pos)) if got[i] != pos[i])
+    sel = pos[:j]
+
+    def ref_score(i):
+        rel = O.cosine(ql, cand[i], empty_is_zero=(variant == 0))
+        if variant == 0:
+            div = 1 - max(O.cosine(cand[i], cand[s], empty_is_zero=True) for s in sel) if sel else 1.0
+            return lam * rel + (1 - lam) * div
+        ms = max(O.cosine(cand[i], cand[s]) for s in sel) if sel else 0.0
+        return lam * rel - (1 - lam) * ms
+    assert abs(ref_score(got[j]) - ref_score(pos[j])) < 1e-12, (got, pos, j)
 
 
 @settings(**{**COMMON, "max_examples": max(20, N_EX // 6)})
