@@ -401,3 +401,24 @@ def test_tenant_with_nine_tiles_keeps_its_last_tile(eng_factory):
     queries = planted_queries(rng, corpus[768:3000], 12, noise=0.2)
     st = check(eng, corpus, queries, 5, tenant_of_row=tenants, tenant=0)
     assert st["exact_scan"] == 0
+
+
+@pytest.mark.parametrize("n_tiles", list(range(1, 21)) + [63, 64, 65, 71, 72, 73, 80])
+def test_contiguous_tenant_spanning_n_tiles(eng_factory, n_tiles):
+    """Stage boundaries of the tile schedule (8 dense tiles, then x8 growth, no tiny trailing stage) swept through a contiguous
+    tenant that owns exactly n_tiles 256-row tiles (first and last tile only partly), against the float64 scan."""
+    rng = np.random.default_rng(n_tiles)
+    D = 64
+    first = 256 * 3 + 17                                             # the tenant starts inside tile 3 ...
+    last = 256 * (3 + n_tiles) - 40                                  # ... and ends inside tile 3 + n_tiles - 1
+    N = last + 900
+    corpus = rng.standard_normal((N, D)).astype(np.float32)
+    tenants = np.ones(N, dtype=np.int32)
+    tenants[first:last] = 0
+    eng = eng_factory(D)
+    eng.index_load(corpus)
+    eng.set_tenants(tenants)
+    queries = planted_queries(rng, corpus[first:last], 9, noise=0.2)
+    st = check(eng, corpus, queries, 7, tenant_of_row=tenants, tenant=0)
+    assert st["exact_scan"] == 0
+    eng.set_tenants(None)
