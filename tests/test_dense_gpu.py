@@ -422,3 +422,17 @@ def test_contiguous_tenant_spanning_n_tiles(eng_factory, n_tiles):
     st = check(eng, corpus, queries, 7, tenant_of_row=tenants, tenant=0)
     assert st["exact_scan"] == 0
     eng.set_tenants(None)
+
+
+@pytest.mark.parametrize("N", [1, 255, 256, 257, 2047, 2048, 2049, 2303, 2304, 2305, 2559, 2560, 2561, 4095, 4096, 4097, 16383, 16384, 16385,
+                               18431, 18432, 18433, 20479, 20480, 20481, 131071, 131072, 131073, 147455, 147456, 147457])
+def test_corpus_sizes_at_tile_and_stage_boundaries(eng_factory, N):
+    rng = np.random.default_rng(N)
+    D = 64
+    corpus = rng.standard_normal((N, D)).astype(np.float32)
+    queries = planted_queries(rng, corpus, 6, noise=0.2)
+    queries[0] = corpus[N - 1]                                       # the very last row must be findable
+    eng = eng_factory(D)
+    eng.index_load(corpus)
+    st = check(eng, corpus, queries, min(5, N))
+    assert st["exact_scan"] == 0
