@@ -36,8 +36,9 @@ N_EX = int(os.environ.get("RAG_PROPERTY_EXAMPLES", "300"))          # raise for 
 COMMON = dict(deadline=None, max_examples=N_EX, derandomize="RAG_PROPERTY_EXAMPLES" not in os.environ, database=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
 
 
-@settings(**COMMON)
-@given(seed=st.integers(0, 2**31 - 1), n=st.one_of(st.integers(1, 700), st.integers(2040, 9000), st.integers(16000, 40000)), q=st.one_of(st.integers(1, 20), st.integers(120, 140), st.integers(250, 270)),
+@settings(**{**COMMON, "max_examples": max(20, N_EX // 2)})
+@given(seed=st.integers(0, 2**31 - 1), n=st.one_of(st.integers(1, 700), st.integers(2040, 9000), st.integers(16000, 40000), st.integers(130000, 150000)),
+       q=st.one_of(st.integers(1, 20), st.integers(120, 140), st.integers(250, 270)),
        k=st.one_of(st.integers(1, 40), st.integers(100, 256)), dim=st.sampled_from([64, 128, 384]), dup=st.integers(0, 5), zeros=st.integers(0, 3), use_tenant=st.booleans())
 def test_dense_topk_equals_the_exact_scan(seed, n, q, k, dim, dup, zeros, use_tenant):
     """ids / rows identical to the float64 exact scan (stable: lower row first on equal scores), scores within 1e-9, for
@@ -294,7 +295,7 @@ def test_merge_topk_is_score_desc_then_id_asc(seed, n_lists, q, k, decimals, fil
 
 
 @settings(**{**COMMON, "max_examples": max(20, N_EX // 6)})
-@given(seed=st.integers(0, 2**31 - 1), n_docs=st.integers(16000, 36000), vocab=st.integers(5, 200), k=st.integers(1, 120),
+@given(seed=st.integers(0, 2**31 - 1), n_docs=st.one_of(st.integers(16000, 36000), st.integers(66000, 100000)), vocab=st.integers(5, 200), k=st.integers(1, 120),
        use_tenant=st.booleans())
 def test_bm25_over_several_doc_ranges_with_tenants(seed, n_docs, vocab, k, use_tenant):
     """Two or three 16384-document ranges (staged thresholds, running merge), optional tenant filter: rows, normalised scores
