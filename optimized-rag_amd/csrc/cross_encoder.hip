@@ -1145,7 +1145,6 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
 static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t st) {
     if (P <= m->ws_pairs && L == m->ws_L) return RAG_OK;
     ce_free_ws(m);
-    const int H = m->cfg.hidden;
     const int64_t Mp = round_up((int64_t)P * L, CE_BN);
     m->ws_pairs = P;                                     // planes_for() uses the allocated pair count
     const ce_planes pp = planes_for(m, Mp);
