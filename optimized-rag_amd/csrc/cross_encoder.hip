@@ -9,7 +9,7 @@
 // keep the two halves INTERLEAVED per 32-element K group: [hi 32 halfs | lo 32 halfs] = 128 B, so the row piece one K-step
 // (32 elements) stages is one whole 128-B line instead of two 64-B halves of two lines (SPLIT_IDX). Residual stream / LayerNorm / softmax /
 // GELU (erf form, A&S 7.1.26) / pooler are fp32. Layout: tokens are rows, PACKED per pair (pair p owns len_p rounded up
-// to 32 rows, offsets computed on the device), feature contiguous; weights are nn.Linear [out][in] = K-contiguous, so
+// to 16 rows, offsets computed on the device), feature contiguous; weights are nn.Linear [out][in] = K-contiguous, so
 // every GEMM is the "both operands K-contiguous" form MFMA wants.
 //
 // Kernels
@@ -53,7 +53,7 @@ struct rag_ce_model {
     half_t *x16 = nullptr, *q16 = nullptr, *kf16 = nullptr, *vf16 = nullptr, *ctx16 = nullptr, *h16 = nullptr;
     int32_t *ids = nullptr, *tt = nullptr, *lens = nullptr;
     // packed (variable-length) row layout of the current chunk: pair p owns rows [pair_off[p], pair_off[p+1]) where
-    // pair_off[p+1] - pair_off[p] = len rounded up to 32; row_pair[m] = owning pair (-1 past the end); m_packed[0] = rows
+    // pair_off[p+1] - pair_off[p] = len rounded up to 16; row_pair[m] = owning pair (-1 past the end); m_packed[0] = rows
     int32_t *pair_off = nullptr, *row_pair = nullptr, *m_packed = nullptr;
     int32_t *sid = nullptr, *stt = nullptr;          // staging of one chunk's [pairs][L_in] token / type ids
     float* logits = nullptr;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
                                                        half_t* __restrict__ out16, half_t* __restrict__ kf16,
                                                        half_t* __restrict__ vf16, size_t kv_plane, int hidden, int heads,
                                                        const int32_t* __restrict__ m_packed, const int32_t* __restrict__ row_pair,
-                                                       const int32_t* __restrict__ pair_off) {
+                                                       const int32_t* __restrict__ pair_off, int m_pad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -324,37 +324,32 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
                         __builtin_nontemporal_store(v, reinterpret_cast<half8*>(o));
                     }
                 } else {
-                    // K features -> kf16[pair rows][head][key tile][lane = fq*16 + key%16][8 dims fq*8..]: the MFMA A-fragment
-                    // order the attention kernel DMAs straight into LDS. One store instruction = one whole 1 KiB fragment tile.
+                    // K features -> kf16[head][16-row tile of the PACKED row space][lane = fq*16 + key%16][8 dims fq*8..]: the MFMA
+                    // A-fragment order the attention kernel DMAs straight into LDS; a pair's keys are consecutive tiles of one head
+                    // (pairs start at multiples of 16 rows). One store instruction = one whole 1 KiB fragment tile.
                     const int head0 = (nb - hidden) >> 5;          // this wave's 64 features = heads head0, head0+1
                     const int m = mb + j * 16;
-                    const int pair = row_pair[m];                   // 16-token tiles never straddle pairs (offsets are multiples of 32)
-                    if (pair >= 0) {                                // rows past the packed end have no (pair, token) slot
-                        const int po = pair_off[pair], Lp = pair_off[pair + 1] - po, t16 = (m - po) >> 4;
 #pragma unroll
-                        for (int hl = 0; hl < 2; ++hl) {
-                            const half8 hi = *reinterpret_cast<const half8*>(wl + fr * 144 + (hl * 4 + fq) * 16);
-                            const half8 lo = *reinterpret_cast<const half8*>(wl + CE_EPI_PLANE16 + fr * 144 + (hl * 4 + fq) * 16);
-                            half_t* o = kf16 + ((size_t)po * heads + (size_t)(head0 + hl) * Lp) * 32 + ((size_t)t16 * 64 + lane) * 8;
-                            __builtin_nontemporal_store(hi, reinterpret_cast<half8*>(o));
-                            __builtin_nontemporal_store(lo, reinterpret_cast<half8*>(o + kv_plane));
-                        }
+                    for (int hl = 0; hl < 2; ++hl) {
+                        const half8 hi = *reinterpret_cast<const half8*>(wl + fr * 144 + (hl * 4 + fq) * 16);
+                        const half8 lo = *reinterpret_cast<const half8*>(wl + CE_EPI_PLANE16 + fr * 144 + (hl * 4 + fq) * 16);
+                        half_t* o = kf16 + (((size_t)(head0 + hl) * (m_pad >> 4) + (m >> 4)) * 64 + lane) * 8;
+                        __builtin_nontemporal_store(hi, reinterpret_cast<half8*>(o));
+                        __builtin_nontemporal_store(lo, reinterpret_cast<half8*>(o + kv_plane));
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         } else {
             // EPI_QKV, V features: one fp16 plane of [64 features][32 tokens] at a time (rows 80 B), then
-            // vf16[pair rows][head][32-key block][d half][lane = fq*16 + d%16][8 key slots]: slot e < 4 is key fq*4 + e of the
-            // block, slot e >= 4 is key 16 + fq*4 + e - 4 (the order in which the S^T accumulators of two adjacent key tiles sit
-            // in a lane's registers, so P never leaves registers in the attention kernel).
+            // vf16[head][16-row tile of the PACKED row space][d half][lane = fq*16 + d%16][4 key slots = rows fq*4..+4 of the
+            // tile]. The attention kernel reads a lane's 8 B of two adjacent tiles as one MFMA A fragment: 8 key slots in the
+            // order in which the S^T accumulators of the two key tiles sit in a lane's registers, so P never leaves registers.
+            // Tiles (not 32-row blocks) are the unit so that a pair may start at any multiple of 16 rows.
             const int head0 = (nb - 2 * hidden) >> 5;
 #pragma unroll
             for (int kl = 0; kl < 2; ++kl) {
                 const int m = mb + kl * 32;
-                const int pair = row_pair[m];
-                const int po = pair >= 0 ? pair_off[pair] : 0, Lp = pair >= 0 ? pair_off[pair + 1] - po : 32;
-                const int kb = pair >= 0 ? (m - po) >> 5 : 0;
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
@@ -369,16 +364,14 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
                                     pl == 0 ? hi : (half_t)(v - (float)hi);
                             }
                     __builtin_amdgcn_wave_barrier();
-                    if (pair >= 0) {
 #pragma unroll
-                        for (int it = 0; it < 4; ++it) {
-                            const int hl = it >> 1, dh = it & 1;            // head, d half
-                            const char* rowp = wl + (hl * 32 + dh * 16 + fr) * 80 + fq * 8;
-                            const half4 h0 = *reinterpret_cast<const half4*>(rowp), h1 = *reinterpret_cast<const half4*>(rowp + 32);
-                            const half8 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                            half_t* o = vf16 + ((size_t)po * heads + (size_t)(head0 + hl) * Lp) * 32 + (((size_t)kb * 2 + dh) * 64 + lane) * 8;
-                            __builtin_nontemporal_store(hv, reinterpret_cast<half8*>(o + (pl ? kv_plane : 0)));
-                        }
+                    for (int it = 0; it < 4; ++it) {
+                        const int hl = it >> 1, dh = it & 1;            // head, d half
+                        const char* rowp = wl + (hl * 32 + dh * 16 + fr) * 80 + fq * 8;
+                        const half4 h0 = *reinterpret_cast<const half4*>(rowp), h1 = *reinterpret_cast<const half4*>(rowp + 32);
+                        half_t* o = vf16 + ((((size_t)(head0 + hl) * (m_pad >> 4) + (m >> 4)) * 2 + dh) * 64 + lane) * 4 + (pl ? kv_plane : 0);
+                        __builtin_nontemporal_store(h0, reinterpret_cast<half4*>(o));
+                        __builtin_nontemporal_store(h1, reinterpret_cast<half4*>(o + 512));   // the next 16-row tile
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -672,7 +665,7 @@ __device__ __forceinline__ void wave_layernorm(float (&v)[PER], const float* __r
     }
 }
 
-// ---- packing: pair p owns len_p rounded up to 32 rows; offsets by one block-wide scan, then the row -> pair map
+// ---- packing: pair p owns len_p rounded up to 16 rows; offsets by one block-wide scan, then the row -> pair map
 __global__ __launch_bounds__(1024) void ce_pack_scan_kernel(const int32_t* __restrict__ lens, int P, int L, int32_t* __restrict__ pair_off,
                                                              int32_t* __restrict__ m_packed) {
     __shared__ int part[1024];
@@ -680,7 +673,7 @@ __global__ __launch_bounds__(1024) void ce_pack_scan_kernel(const int32_t* __res
     const int per = (P + 1023) / 1024;
     const int b = tid * per, e = min(P, b + per);
     int s = 0;
-    for (int p = b; p < e; ++p) s += (max(1, min(lens[p], L)) + 31) & ~31;
+    for (int p = b; p < e; ++p) s += (max(1, min(lens[p], L)) + 15) & ~15;
     part[tid] = s;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
@@ -692,7 +685,7 @@ __global__ __launch_bounds__(1024) void ce_pack_scan_kernel(const int32_t* __res
     int off = part[tid] - s;
     for (int p = b; p < e; ++p) {
         pair_off[p] = off;
-        off += (max(1, min(lens[p], L)) + 31) & ~31;
+        off += (max(1, min(lens[p], L)) + 15) & ~15;
     }
     if (tid == 1023) { pair_off[P] = part[1023]; m_packed[0] = part[1023]; }
 }
@@ -746,7 +739,8 @@ __global__ __launch_bounds__(256) void ce_layernorm_kernel(const float* __restri
 
 // ---- attention: d_head must be 32. One block per (head, pair); every wave owns QB consecutive 16-query blocks.
 // K and V of the (pair, head) arrive in LDS by LDS-DMA, already in MFMA fragment order (written that way by the QKV
-// epilogue), so a fragment read is one conflict-free ds_read_b128 at lane*16 and is shared by all waves of the block.
+// epilogue) as 1 KiB tiles of 16 packed rows: a K fragment is one conflict-free ds_read_b128 at lane*16, a V fragment two
+// ds_read_b64 at lane*8 (the lane's key slots of two adjacent tiles); both are shared by all waves of the block.
 // All operands are split fp16 (hi + lo plane): S and P.V are 3 MFMAs each. S is computed TRANSPOSED (A = K rows,
 // B = Q rows): the accumulator lane (fr, fq) then holds query fr x keys fq*4..+4, which IS the B-operand layout of the
 // next MFMA if the 32 k-slots of a key block are numbered (fq, e) -> key fq*4 + e (e < 4) | 16 + fq*4 + e - 4: V is
@@ -769,28 +763,28 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
                                                              const half_t* __restrict__ kf16, const half_t* __restrict__ vf16,
                                                              size_t kv_plane, const int32_t* __restrict__ lens,
                                                              const int32_t* __restrict__ pair_off, int L, int hidden,
-                                                             int heads, half_t* __restrict__ ctx16) {
+                                                             int heads, int m_pad, half_t* __restrict__ ctx16) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
     const int head = blockIdx.x, pair = blockIdx.y;
     const int len = max(1, min(lens[pair], L));
-    const int nkb = (len + 31) >> 5;                                  // 32-key blocks that hold at least one real key
     const int fr = lane & 15, fq = lane >> 4;
-    const int po = pair_off[pair], Lp = pair_off[pair + 1] - po;     // this pair's packed rows: len rounded up to 32
+    const int po = pair_off[pair], Lp = pair_off[pair + 1] - po;     // this pair's packed rows: len rounded up to 16
+    const int nt = Lp >> 4;                                           // the pair's 16-row tiles; an odd count leaves the second
+    const int nkb = (len + 31) >> 5;                                  // half of the last 32-key block outside the pair (masked)
     const size_t plane_b = (size_t)L * 64;                            // bytes of one K (or V) plane of this (pair, head)
     char* const k_hi = smem;
     char* const k_lo = smem + plane_b;
     char* const v_hi = smem + 2 * plane_b;
     char* const v_lo = smem + 3 * plane_b;
     {
-        const half_t* kg = kf16 + ((size_t)po * heads + (size_t)head * Lp) * 32 + lane * 8;
-        const half_t* vg = vf16 + ((size_t)po * heads + (size_t)head * Lp) * 32 + lane * 8;
-        for (int c = wv; c < 2 * nkb; c += nwaves) {                  // 1 KiB fragment tiles: 2 per key block and plane
-            ce_dma_at(kg + (size_t)c * 512, k_hi + c * 1024);
-            ce_dma_at(kg + kv_plane + (size_t)c * 512, k_lo + c * 1024);
-            ce_dma_at(vg + (size_t)c * 512, v_hi + c * 1024);
-            ce_dma_at(vg + kv_plane + (size_t)c * 512, v_lo + c * 1024);
+        const size_t g0 = (((size_t)head * (m_pad >> 4) + (po >> 4)) * 64 + lane) * 8;   // K and V tiles are both 1 KiB per plane
+        for (int c = wv; c < nt; c += nwaves) {
+            ce_dma_at(kf16 + g0 + (size_t)c * 512, k_hi + c * 1024);
+            ce_dma_at(kf16 + g0 + kv_plane + (size_t)c * 512, k_lo + c * 1024);
+            ce_dma_at(vf16 + g0 + (size_t)c * 512, v_hi + c * 1024);
+            ce_dma_at(vf16 + g0 + kv_plane + (size_t)c * 512, v_lo + c * 1024);
         }
     }
     const size_t row0 = (size_t)po;
@@ -801,7 +795,8 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
         // split-row layout: a head's 32 dims are one K group = [hi 32 | lo 32] halfs
-        const half_t* qp = q16 + (row0 + (qb0 + b) * 16 + fr) * (2 * hidden) + head * 64 + fq * 8;
+        const int qb = (qb0 + b) * 16 < Lp ? qb0 + b : qb0;           // a block past the pair's rows is computed but not stored
+        const half_t* qp = q16 + (row0 + qb * 16 + fr) * (2 * hidden) + head * 64 + fq * 8;
         qh[b] = *reinterpret_cast<const half8*>(qp);
         ql[b] = *reinterpret_cast<const half8*>(qp + 32);
     }
@@ -822,8 +817,18 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
         const int fo = kb * 2048 + lane * 16;
         const half8 k0h = *reinterpret_cast<const half8*>(k_hi + fo), k1h = *reinterpret_cast<const half8*>(k_hi + fo + 1024);
         const half8 k0l = *reinterpret_cast<const half8*>(k_lo + fo), k1l = *reinterpret_cast<const half8*>(k_lo + fo + 1024);
-        const half8 v0h = *reinterpret_cast<const half8*>(v_hi + fo), v1h = *reinterpret_cast<const half8*>(v_hi + fo + 1024);
-        const half8 v0l = *reinterpret_cast<const half8*>(v_lo + fo), v1l = *reinterpret_cast<const half8*>(v_lo + fo + 1024);
+        // V fragment = the lane's 4 key slots of tile 2kb | of tile 2kb+1 (tile = [d half][lane][4 slots], 512 B per half)
+        const int vo = kb * 2048 + lane * 8;
+        const half4 z4 = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
+        const bool half2 = kb * 32 + 16 < Lp;      // else tile 2kb+1 is not this pair's (never staged): P is 0 there, V must be finite
+        const half4 a0h = *reinterpret_cast<const half4*>(v_hi + vo), a1h = *reinterpret_cast<const half4*>(v_hi + vo + 512);
+        const half4 a0l = *reinterpret_cast<const half4*>(v_lo + vo), a1l = *reinterpret_cast<const half4*>(v_lo + vo + 512);
+        const half4 b0h = half2 ? *reinterpret_cast<const half4*>(v_hi + vo + 1024) : z4;
+        const half4 b1h = half2 ? *reinterpret_cast<const half4*>(v_hi + vo + 1536) : z4;
+        const half4 b0l = half2 ? *reinterpret_cast<const half4*>(v_lo + vo + 1024) : z4;
+        const half4 b1l = half2 ? *reinterpret_cast<const half4*>(v_lo + vo + 1536) : z4;
+        const half8 v0h = __builtin_shufflevector(a0h, b0h, 0, 1, 2, 3, 4, 5, 6, 7), v1h = __builtin_shufflevector(a1h, b1h, 0, 1, 2, 3, 4, 5, 6, 7);
+        const half8 v0l = __builtin_shufflevector(a0l, b0l, 0, 1, 2, 3, 4, 5, 6, 7), v1l = __builtin_shufflevector(a1l, b1l, 0, 1, 2, 3, 4, 5, 6, 7);
         const bool edge = (kb + 1) * 32 > len;
 #pragma unroll
         for (int b = 0; b < QB; ++b) {
@@ -881,6 +886,7 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
         const float inv = 1.0f / l;
+        if ((qb0 + b) * 16 >= Lp) break;
         half_t* o = ctx16 + (row0 + (qb0 + b) * 16 + fr) * (2 * hidden) + head * 64 + fq * 4;
         store_split4(o, 32, c0[b][0] * inv, c0[b][1] * inv, c0[b][2] * inv, c0[b][3] * inv);
         store_split4(o + 16, 32, c1[b][0] * inv, c1[b][1] * inv, c1[b][2] * inv, c1[b][3] * inv);
@@ -1032,7 +1038,8 @@ static int launch_attention(rag_ctx* h, rag_ce_model* m, int P, int L, const ce_
     }
     const int waves = L / (16 * QB);
     hipLaunchKernelGGL((ce_attention_kernel<QB>), dim3(m->cfg.heads, P), dim3(64 * waves), lds, st, m->q16, m->kf16, m->vf16,
-                       pp.kv, lens_dev, m->pair_off, L, m->cfg.hidden, m->cfg.heads, m->ctx16);
+                       pp.kv, lens_dev, m->pair_off, L, m->cfg.hidden, m->cfg.heads,
+                       (int)round_up((int64_t)m->ws_pairs * L, CE_BN), m->ctx16);
     return RAG_OK;
 }
 
@@ -1106,7 +1113,7 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
         auto& ly = m->layers[l];
         CE_GEMM(EPI_QKV, terms[0], ly.wqkv, m->x16,
                 3 * H, H, ly.bqkv, (const half_t*)nullptr, (float*)nullptr, m->q16, m->kf16, m->vf16, pp.kv, H,
-                m->cfg.heads, m->m_packed, m->row_pair, m->pair_off)
+                m->cfg.heads, m->m_packed, m->row_pair, m->pair_off, (int)Mp)
         {
             const int rc = L == 32 ? launch_attention<1>(h, m, P, L, pp, st, lens_dev) : launch_attention<2>(h, m, P, L, pp, st, lens_dev);
             if (rc != RAG_OK) return rc;
@@ -1117,19 +1124,19 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
         } else {
             CE_GEMM(EPI_RESID, terms[1], ly.wo, m->ctx16, H, H,
                     ly.bo, (const half_t*)m->x16, m->y32, (half_t*)nullptr, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
-                    m->row_pair, m->pair_off)
+                    m->row_pair, m->pair_off, (int)Mp)
             CE_PER_DISPATCH(LN1)
         }
         CE_GEMM(EPI_GELU, terms[2], ly.w1, m->x16, F, H,
                 ly.b1, (const half_t*)nullptr, (float*)nullptr, m->h16, (half_t*)nullptr, (half_t*)nullptr, (size_t)0,
-                H, m->cfg.heads, m->m_packed, m->row_pair, m->pair_off)
+                H, m->cfg.heads, m->m_packed, m->row_pair, m->pair_off, (int)Mp)
 #define LN2(PER) launch_ln<PER>(m, m->y32, ly.ln2_g, ly.ln2_b, M, st)
         if (fused_ln) {
             CE_GEMM_LN(terms[3], ly.w2, m->h16, F, ly.b2, ly.ln2_g, ly.ln2_b, eps, m->x16, m->m_packed)
         } else {
             CE_GEMM(EPI_RESID, terms[3], ly.w2, m->h16, H, F,
                     ly.b2, (const half_t*)m->x16, m->y32, (half_t*)nullptr, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
-                    m->row_pair, m->pair_off)
+                    m->row_pair, m->pair_off, (int)Mp)
             CE_PER_DISPATCH(LN2)
         }
     }
