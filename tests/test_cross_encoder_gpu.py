@@ -156,3 +156,27 @@ def test_reranker_from_local_dir(eng, tmp_path):
         assert abs(x["cross_encoder_score"] - sig[x["pos"]]) < SCORE_TOL
         assert abs(x["cross_encoder_raw_score"] - exp[x["pos"]]) < LOGIT_TOL
         assert x["embedding_score"] == 0.1 * x["pos"] and x["score"] == x["cross_encoder_score"]
+
+
+def test_sixteen_row_packing_edges_and_position_independence(eng):
+    """Pairs are packed to 16-row multiples, so a pair may start at an odd multiple of 16 (its 32-key attention blocks then
+    straddle two 32-row stretches of the packed space) and may own an odd number of 16-row tiles (the second half of its last
+    key block belongs to the NEXT pair, or lies past the packed end for the last pair). Lengths around every tile edge, in an
+    order that produces all four (start parity, tile-count parity) combinations, against the float64 oracle; then the same
+    pairs in reverse order and one at a time: a pair's logit must not depend on its neighbours (bit for bit)."""
+    cfg = B.minilm_config()
+    w = B.seeded_weights(cfg, 99)
+    load_model(eng, cfg, w)
+    L = 64
+    lens = np.array([1, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 2, 40, 16, 16, 20, 64, 5], dtype=np.int32)
+    P = len(lens)
+    rng = np.random.default_rng(1616)
+    ids, tt = _random_pairs(rng, cfg, P, L, lens)
+    got = eng.ce_score(ids, tt, lens)
+    exp = B.forward_logits(w, cfg, ids.astype(np.int64), tt.astype(np.int64), lens, fast_erf=True)
+    assert np.isfinite(got).all()
+    assert np.abs(got - exp).max() < LOGIT_TOL, (got, exp)
+    rev = eng.ce_score(ids[::-1].copy(), tt[::-1].copy(), lens[::-1].copy())
+    np.testing.assert_array_equal(rev[::-1], got)
+    for p in (0, 3, 6, 11, P - 1):
+        np.testing.assert_array_equal(eng.ce_score(ids[p:p + 1], tt[p:p + 1], lens[p:p + 1]), got[p:p + 1])
