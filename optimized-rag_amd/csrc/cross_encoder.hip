@@ -133,8 +133,7 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
                                                        const half_t* __restrict__ resid, float* __restrict__ out32,
                                                        half_t* __restrict__ out16, half_t* __restrict__ kf16,
                                                        half_t* __restrict__ vf16, size_t kv_plane, int hidden, int heads,
-                                                       const int32_t* __restrict__ m_packed, const int32_t* __restrict__ row_pair,
-                                                       const int32_t* __restrict__ pair_off, int m_pad) {
+                                                       const int32_t* __restrict__ m_packed, int m_pad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1113,7 +1112,7 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
         auto& ly = m->layers[l];
         CE_GEMM(EPI_QKV, terms[0], ly.wqkv, m->x16,
                 3 * H, H, ly.bqkv, (const half_t*)nullptr, (float*)nullptr, m->q16, m->kf16, m->vf16, pp.kv, H,
-                m->cfg.heads, m->m_packed, m->row_pair, m->pair_off, (int)Mp)
+                m->cfg.heads, m->m_packed, (int)Mp)
         {
             const int rc = L == 32 ? launch_attention<1>(h, m, P, L, pp, st, lens_dev) : launch_attention<2>(h, m, P, L, pp, st, lens_dev);
             if (rc != RAG_OK) return rc;
@@ -1123,20 +1122,18 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
             CE_GEMM_LN(terms[1], ly.wo, m->ctx16, H, ly.bo, ly.ln1_g, ly.ln1_b, eps, m->x16, m->m_packed)
         } else {
             CE_GEMM(EPI_RESID, terms[1], ly.wo, m->ctx16, H, H,
-                    ly.bo, (const half_t*)m->x16, m->y32, (half_t*)nullptr, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
-                    m->row_pair, m->pair_off, (int)Mp)
+                    ly.bo, (const half_t*)m->x16, m->y32, (half_t*)nullptr, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed, (int)Mp)
             CE_PER_DISPATCH(LN1)
         }
         CE_GEMM(EPI_GELU, terms[2], ly.w1, m->x16, F, H,
                 ly.b1, (const half_t*)nullptr, (float*)nullptr, m->h16, (half_t*)nullptr, (half_t*)nullptr, (size_t)0,
-                H, m->cfg.heads, m->m_packed, m->row_pair, m->pair_off, (int)Mp)
+                H, m->cfg.heads, m->m_packed, (int)Mp)
 #define LN2(PER) launch_ln<PER>(m, m->y32, ly.ln2_g, ly.ln2_b, M, st)
         if (fused_ln) {
             CE_GEMM_LN(terms[3], ly.w2, m->h16, F, ly.b2, ly.ln2_g, ly.ln2_b, eps, m->x16, m->m_packed)
         } else {
             CE_GEMM(EPI_RESID, terms[3], ly.w2, m->h16, H, F,
-                    ly.b2, (const half_t*)m->x16, m->y32, (half_t*)nullptr, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed,
-                    m->row_pair, m->pair_off, (int)Mp)
+                    ly.b2, (const half_t*)m->x16, m->y32, (half_t*)nullptr, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed, (int)Mp)
             CE_PER_DISPATCH(LN2)
         }
     }
