@@ -4,13 +4,15 @@
 // Integer/gather work, not a GEMM (89 % of the posting reads hit L2: frequent terms are shared by the batch's queries):
 //   load   : per-posting impact w = idf * tf*(k1+1) / (tf + k1*(1 - b + b*dl/avgdl)) precomputed once in float64 with
 //            rank-bm25's operation order -> postings are (doc int32, w float64): 12 B each, no doc_len gather, no multiply
-//            later. A per-term range table (first posting of each 16384-doc range, built once on the GPU) replaces the
+//            later. A per-term range table (first posting of each 8192-doc range, built once on the GPU) replaces the
 //            two 20-step dependent binary searches per (block, token) that dominated the first version (36 ms/batch).
-//   score  : one workgroup per (query, 16384-doc range). The range's float64 accumulators live in LDS (132 KiB padded);
-//            for each query token IN ORDER the block adds the term's impacts of this doc range (docs are unique inside one
-//            posting list -> one add per accumulator per token, and per-document summation order is the query-token
-//            order, exactly as `score += ...` in get_scores -> bit-identical float64). 4 consecutive postings per thread
-//            per trip, the next trip in flight across the token barrier.
+//   score  : one workgroup per (query, 8192-doc range). The range's float64 accumulators live in LDS (66 KiB padded: TWO
+//            workgroups per CU, so one's posting round trips hide behind the other's adds; 16384-doc ranges = one
+//            workgroup per CU were 5 % slower on the hybrid batch); for each query token IN ORDER the block adds the
+//            term's impacts of this doc range (docs are unique inside one posting list -> one read-add-write per
+//            accumulator per token, and per-document summation order is the query-token order, exactly as `score += ...`
+//            in get_scores -> bit-identical float64). 4 consecutive postings per thread per trip, the next trip in flight
+//            across the token barrier.
 //            Algorithmic traffic per query = sum over tokens of df*12 B; accumulators never touch HBM.
 //   select : STAGED. The first BM_FIRST_RANGES ranges get an exact per-range top-k (8-pass radix select on order-
 //            preserving keys, ties -> lower doc id, i.e. Python's stable sort); bm25_tau_kernel takes the k-th best key
@@ -20,9 +22,9 @@
 
 typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));          // posting segments start at any posting
 typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
-#define BM_RANGE 16384
+#define BM_RANGE 8192
 #define BM_THREADS 1024
-#define BM_SEG (BM_RANGE / BM_THREADS)      // 16 contiguous docs per thread
+#define BM_SEG (BM_RANGE / BM_THREADS)      // 8 contiguous docs per thread
 // accumulator i lives at LDS double i + i/32: a thread's 32 contiguous docs then start one bank-pair further than its
 // neighbour's, so the per-thread segment reads are conflict-free (unpadded: every lane on the same bank, 32-way)
 #define SC_IDX(i) ((i) + ((i) >> 5))
@@ -142,9 +144,10 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
             m_n[tid] = f == 0.0 ? 0 : n;                     // (idf or 0) * x == 0: adds nothing
         }
         __syncthreads();
-        // Docs are unique inside one posting list: exactly one add per accumulator per token, so a no-return LDS atomic
-        // (ds_add_f64) gives the same float64 result as load-add-store; tokens are separated by a barrier so that the
-        // per-document summation order is the token order (bit-identical to numpy). A (token, range) segment is only a few
+        // Docs are unique inside one posting list: exactly one add per accumulator per token, so a plain LDS read-add-write
+        // is race-free inside a token (a no-return ds_add_f64 gives the same bits and was 2 % slower on the hybrid batch:
+        // the float64 LDS atomic runs well below the rate of a b64 read + write); tokens are separated by a barrier so that
+        // the per-document summation order is the token order (bit-identical to numpy). A (token, range) segment is only a few
         // postings per thread, so the loop is bound by one global round trip per token unless the NEXT chunk (4
         // consecutive postings per thread = 4096 per block, possibly of the next token) is already in flight while the
         // current one is added: two register sets ping-pong, loads are unconditional (the arrays carry 4 postings of
@@ -165,15 +168,16 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
 #define BM_ADD(TI, C, D, W0, W1)                                                                   \
             {                                                                                      \
                 const int p_ = (C) * 4 * BM_THREADS + tid * 4, n_ = m_n[TI];                       \
-                if (p_ + 3 < n_) {                                                                 \
-                    __hip_atomic_fetch_add(&sc[SC_IDX(D[0] - (int)base)], W0[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
-                    __hip_atomic_fetch_add(&sc[SC_IDX(D[1] - (int)base)], W0[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
-                    __hip_atomic_fetch_add(&sc[SC_IDX(D[2] - (int)base)], W1[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
-                    __hip_atomic_fetch_add(&sc[SC_IDX(D[3] - (int)base)], W1[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
-                } else if (p_ < n_) {                  /* the one thread that holds the end of the segment */                      \
-                    __hip_atomic_fetch_add(&sc[SC_IDX(D[0] - (int)base)], W0[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
-                    if (p_ + 1 < n_) __hip_atomic_fetch_add(&sc[SC_IDX(D[1] - (int)base)], W0[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-                    if (p_ + 2 < n_) __hip_atomic_fetch_add(&sc[SC_IDX(D[2] - (int)base)], W1[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                if (p_ < n_) {                                                                     \
+                    double* a0_ = &sc[SC_IDX(D[0] - (int)base)];                                   \
+                    double* a1_ = p_ + 1 < n_ ? &sc[SC_IDX(D[1] - (int)base)] : &sc[BM_SC_DOUBLES - 1]; \
+                    double* a2_ = p_ + 2 < n_ ? &sc[SC_IDX(D[2] - (int)base)] : &sc[BM_SC_DOUBLES - 2]; \
+                    double* a3_ = p_ + 3 < n_ ? &sc[SC_IDX(D[3] - (int)base)] : &sc[BM_SC_DOUBLES - 3]; \
+                    const double v0_ = *a0_, v1_ = *a1_, v2_ = *a2_, v3_ = *a3_;                   \
+                    *a0_ = v0_ + W0[0];                                                            \
+                    if (p_ + 1 < n_) *a1_ = v1_ + W0[1];                                           \
+                    if (p_ + 2 < n_) *a2_ = v2_ + W1[0];                                           \
+                    if (p_ + 3 < n_) *a3_ = v3_ + W1[1];                                           \
                 }                                                                                  \
             }
 #define BM_NEXT(TI, C, NTI, NC)                                                                    \
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
     }
     // Thresholded ranges (second stage, see bm25_launch_topk): tau_key[q] is the k-th best key over the first-stage
     // ranges, a lower bound of the global k-th. Only keys >= tau can reach the global top-k; a later range holds
-    // about k * 16384 / (docs of stage one) of them, so they are compacted in doc order (the merge sorts anyway) and the
+    // about k * BM_RANGE / (docs of stage one) of them, so they are compacted in doc order (the merge sorts anyway) and the
     // 8-pass radix select — 26 us per block, three quarters of this kernel's time when run for every range — is
     // skipped. More than k survivors (possible, e.g. a tie plateau) falls through to the exact select below.
     if (tau_key != nullptr) {
@@ -382,7 +386,7 @@ __device__ __forceinline__ void bm_sort_pairs(uint64_t* k1, uint32_t* k2, int P,
     }
 }
 
-#define BM_FIRST_RANGES 2      // exact per-range top-k for these (32768 docs), thresholded compaction for the rest (measured: 1 -> 7.5 ms, 2 -> 4.87, 4 -> 5.08)
+#define BM_FIRST_RANGES 2      // exact per-range top-k for these, thresholded compaction for the rest (measured with 16384-doc ranges: 1 -> 7.5 ms, 2 -> 4.87, 4 -> 5.08)
 #define BM_STAGE_GROWTH 8      // every thresholded stage covers up to 8x the ranges seen before it
 
 // Folds the partial lists of the doc ranges [r_begin, r_end) into the query's RUNNING top-k (run_key / run_row [Q][k], key 0 =
