@@ -153,21 +153,29 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
         // current one is added: two register sets ping-pong, loads are unconditional (the arrays carry 4 postings of
         // padding) so the compiler keeps counted vmcnt waits, and the token barrier is a raw s_barrier behind
         // lgkmcnt(0) — __syncthreads would drain vmcnt and the prefetch with it.
+        // The walk over (token, chunk) is the same in every thread. Each wave keeps the batch's token metadata in one VGPR
+        // set (lane t = token t) and reads it with v_readlane at a scalar index: the three dependent LDS round trips per trip
+        // (segment length for the step, base + length for the address, length for the tail test) become scalar moves.
+        const int my_n = m_n[lane];
+        const int64_t my_a = m_a[lane];
+        const int my_a_lo = (int)(uint32_t)my_a, my_a_hi = (int)(my_a >> 32);
+#define TOK_N(TI) __builtin_amdgcn_readlane(my_n, TI)
+#define TOK_A(TI) (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(my_a_hi, TI) << 32) | (uint32_t)__builtin_amdgcn_readlane(my_a_lo, TI))
         int ti = 0, c = 0;
-        while (ti < nb && m_n[ti] == 0) ++ti;
+        while (ti < nb && TOK_N(ti) == 0) ++ti;
         if (ti < nb) {
             int4u da, db;
             double2u wa0, wa1, wb0, wb1;
 #define BM_LOAD(TI, C, D, W0, W1)                                                                  \
             {                                                                                      \
-                const int64_t o_ = m_a[TI] + min((C) * 4 * BM_THREADS + tid * 4, max(m_n[TI] - 1, 0));   \
+                const int64_t o_ = TOK_A(TI) + min((C) * 4 * BM_THREADS + tid * 4, max(TOK_N(TI) - 1, 0)); \
                 D = *reinterpret_cast<const int4u*>(doc + o_);                                     \
                 W0 = *reinterpret_cast<const double2u*>(w + o_);                                   \
                 W1 = *reinterpret_cast<const double2u*>(w + o_ + 2);                               \
             }
 #define BM_ADD(TI, C, D, W0, W1)                                                                   \
             {                                                                                      \
-                const int p_ = (C) * 4 * BM_THREADS + tid * 4, n_ = m_n[TI];                       \
+                const int p_ = (C) * 4 * BM_THREADS + tid * 4, n_ = TOK_N(TI);                     \
                 if (p_ < n_) {                                                                     \
                     double* a0_ = &sc[SC_IDX(D[0] - (int)base)];                                   \
                     double* a1_ = p_ + 1 < n_ ? &sc[SC_IDX(D[1] - (int)base)] : &sc[BM_SC_DOUBLES - 1]; \
@@ -182,10 +190,10 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
             }
 #define BM_NEXT(TI, C, NTI, NC)                                                                    \
             NTI = TI; NC = C + 1;                                                                  \
-            if (NC * 4 * BM_THREADS >= m_n[TI]) {                                                  \
+            if (NC * 4 * BM_THREADS >= TOK_N(TI)) {                                                \
                 NC = 0;                                                                            \
                 ++NTI;                                                                             \
-                while (NTI < nb && m_n[NTI] == 0) ++NTI;                                           \
+                while (NTI < nb && TOK_N(NTI) == 0) ++NTI;                                         \
             }
 #define BM_TOKEN_BARRIER asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
             BM_LOAD(ti, c, da, wa0, wa1)
@@ -210,6 +218,8 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
 #undef BM_ADD
 #undef BM_NEXT
 #undef BM_TOKEN_BARRIER
+#undef TOK_N
+#undef TOK_A
         }
         __syncthreads();                                     // adds done before the next batch's metadata / the select
     }
