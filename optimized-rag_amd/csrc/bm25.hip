@@ -4,11 +4,12 @@
 // Integer/gather work, not a GEMM (89 % of the posting reads hit L2: frequent terms are shared by the batch's queries):
 //   load   : per-posting impact w = idf * tf*(k1+1) / (tf + k1*(1 - b + b*dl/avgdl)) precomputed once in float64 with
 //            rank-bm25's operation order -> postings are (doc int32, w float64): 12 B each, no doc_len gather, no multiply
-//            later. A per-term range table (first posting of each 8192-doc range, built once on the GPU) replaces the
+//            later. A per-term range table (first posting of each 2048-doc range, built once on the GPU) replaces the
 //            two 20-step dependent binary searches per (block, token) that dominated the first version (36 ms/batch).
-//   score  : one workgroup per (query, 8192-doc range). The range's float64 accumulators live in LDS (66 KiB padded: TWO
-//            workgroups per CU, so one's posting round trips hide behind the other's adds; 16384-doc ranges = one
-//            workgroup per CU were 5 % slower on the hybrid batch); for each query token IN ORDER the block adds the
+//   score  : one 256-thread workgroup per (query, 2048-doc range). The range's float64 accumulators live in LDS (20.5 KiB
+//            with the scratch: SEVEN workgroups per CU, so one's posting round trips and token barriers hide behind the
+//            others' adds; hybrid batch of 1024 on one box: 16384 docs x 1024 threads = one workgroup per CU 132.8 k q/s,
+//            8192 x 1024 138.2 k, 4096 x 512 144.8 k, 2048 x 256 151.2 k); for each query token IN ORDER the block adds the
 //            term's impacts of this doc range (docs are unique inside one posting list -> one read-add-write per
 //            accumulator per token, and per-document summation order is the query-token order, exactly as `score += ...`
 //            in get_scores -> bit-identical float64). 4 consecutive postings per thread per trip, the next trip in flight
@@ -22,8 +23,12 @@
 
 typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));          // posting segments start at any posting
 typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
-#define BM_RANGE 8192
-#define BM_THREADS 1024
+#ifndef BM_RANGE            // -DBM_RANGE / -DBM_THREADS: variant builds for tools/bm25_ab2.sh
+#define BM_RANGE 2048
+#endif
+#ifndef BM_THREADS
+#define BM_THREADS 256
+#endif
 #define BM_SEG (BM_RANGE / BM_THREADS)      // 8 contiguous docs per thread
 // accumulator i lives at LDS double i + i/32: a thread's 32 contiguous docs then start one bank-pair further than its
 // neighbour's, so the per-thread segment reads are conflict-free (unpadded: every lane on the same bank, 32-way)
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
         // the float64 LDS atomic runs well below the rate of a b64 read + write); tokens are separated by a barrier so that
         // the per-document summation order is the token order (bit-identical to numpy). A (token, range) segment is only a few
         // postings per thread, so the loop is bound by one global round trip per token unless the NEXT chunk (4
-        // consecutive postings per thread = 4096 per block, possibly of the next token) is already in flight while the
+        // consecutive postings per thread = 4 x BM_THREADS per block, possibly of the next token) is already in flight while the
         // current one is added: two register sets ping-pong, loads are unconditional (the arrays carry 4 postings of
         // padding) so the compiler keeps counted vmcnt waits, and the token barrier is a raw s_barrier behind
         // lgkmcnt(0) — __syncthreads would drain vmcnt and the prefetch with it.
@@ -396,7 +401,8 @@ __device__ __forceinline__ void bm_sort_pairs(uint64_t* k1, uint32_t* k2, int P,
     }
 }
 
-#define BM_FIRST_RANGES 2      // exact per-range top-k for these, thresholded compaction for the rest (measured with 16384-doc ranges: 1 -> 7.5 ms, 2 -> 4.87, 4 -> 5.08)
+#define BM_FIRST_RANGES 4      // exact per-range top-k for these (8192 docs), thresholded compaction for the rest (2048-doc ranges: 2 -> 134.2 k hybrid q/s, 4 -> 151.2 k;
+                               // 4096-doc ranges: 2 -> 144.8 k, 4 -> 143.3 k; 16384-doc ranges, BM25 leg alone: 1 -> 7.5 ms, 2 -> 4.87, 4 -> 5.08)
 #define BM_STAGE_GROWTH 8      // every thresholded stage covers up to 8x the ranges seen before it
 
 // Folds the partial lists of the doc ranges [r_begin, r_end) into the query's RUNNING top-k (run_key / run_row [Q][k], key 0 =
@@ -516,7 +522,7 @@ struct bm25_topk_out {
 static void bm25_launch_topk(const rag_bm25_index* ix, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k,
                              const bm25_topk_ws& w, const bm25_topk_out& o, const int32_t* tenants, int tenant, hipStream_t st) {
     const int nr = ix->n_ranges;
-    static const int first_cfg = [] { const char* e = getenv("RAG_BM25_FIRST_RANGES"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? v : BM_FIRST_RANGES; }();
+    static const int first_cfg = [] { const char* e = getenv("RAG_BM25_FIRST_RANGES"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 16 ? v : BM_FIRST_RANGES; }();
     const bool staged = nr > 2 * first_cfg && !getenv("RAG_BM25_NO_STAGING");
     int begin = 0, stage = 0;
     while (begin < nr) {
