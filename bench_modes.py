@@ -263,6 +263,7 @@ def run_mode(args):
 # =====================================================================================================================
 PEAK_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
+PEAK_L2_GATHER_GBS = 17800.0     # L2-served row gather, chip-wide (MI355X_MICROARCH.md: 16.8-18.8 TB/s measured)
 
 
 def _term_queries(tok, doc_ptr, N, Q, seed=7):
@@ -333,13 +334,20 @@ def hybrid_block(eng, q, N, cpu_baseline=True):
         "value": round(Q / t_1024, 1), "unit": "queries/sec", "batch_queries": Q, "ms_per_batch": round(t_1024 * 1e3, 3),
         "queries_per_sec_batch256": round(256 / t_256, 1), "p50_single_query_latency_ms": round(p50_1, 4),
         "linear_fusion_queries_per_sec_batch256": round(256 / t_lin, 1),
-        "roofline": {"bound": "hbm", "kernel": "bm25_range_kernel + bm25_merge_stage_kernel (BM25 top-100 of one batch)",
-                     "achieved": round(bm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(bm_gbs / PEAK_HBM_GBS, 4),
+        # The posting stream of a batch is served by L2, not by HBM: frequent terms are shared by the batch's queries (PMC, r1:
+        # 89 % of the posting reads hit L2, HBM fetch 2.75 GB per batch against 27.2 GB algorithmic). Pricing the algorithmic
+        # bytes against the 8 TB/s HBM peak would give a fraction above 1, so the block is priced against the chip-wide rate
+        # of an L2-served gather (MI355X_MICROARCH.md, "Indexed rows: gather into LDS": 16.8-18.8 TB/s); the HBM-priced
+        # figure is kept beside it for comparison with r1/r2 lines.
+        "roofline": {"bound": "l2", "kernel": "bm25_range_kernel + bm25_merge_stage_kernel (BM25 top-100 of one batch)",
+                     "achieved": round(bm_gbs, 1), "peak": PEAK_L2_GATHER_GBS, "unit": "GB/s",
+                     "frac": round(bm_gbs / PEAK_L2_GATHER_GBS, 4),
+                     "achieved_over_hbm_peak": round(bm_gbs / PEAK_HBM_GBS, 4),
                      "traffic": None, "avg_call_ms": round(bm_ms / bm_spans, 4),
                      "algorithmic_bytes_per_call": nnz_touched * 12.0,
                      "note": "algorithmic bytes = postings of the batch's query terms x 12 B (doc id + float64 impact), SURVEY 8d; "
-                             "most posting reads are L2 hits (frequent terms are shared by the batch), so the achieved figure can "
-                             "exceed what HBM alone would deliver"},
+                             "89 % of the posting reads are L2 hits (frequent terms are shared by the batch), so the peak is the "
+                             "measured chip-wide rate of an L2-served gather (17.8 TB/s, mid-point of the guide's range), not HBM"},
         "index_build_s": round(build_s, 1),
     }
     if cpu_baseline:
