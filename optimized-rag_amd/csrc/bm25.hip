@@ -23,7 +23,7 @@
 
 typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));          // posting segments start at any posting
 typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
-#ifndef BM_RANGE            // -DBM_RANGE / -DBM_THREADS: variant builds for tools/bm25_ab2.sh
+#ifndef BM_RANGE            // -DBM_RANGE / -DBM_THREADS: variant builds by tools/bm25_variant_build.sh
 #define BM_RANGE 2048
 #endif
 #ifndef BM_THREADS
