@@ -125,7 +125,7 @@ def synthetic_postings(rng, n_docs, vocab, mean_len):
 def test_bm25_topk_vs_oracle(eng):
     from optimized_rag_amd.bm25 import Bm25Postings
     rng = np.random.default_rng(21)
-    n_docs = 40000                                               # 3 doc ranges of 16384
+    n_docs = 40000                                               # 20 doc ranges of 2048
     docs = synthetic_postings(rng, n_docs, 5000, 30)
     docs[100] = []                                               # empty doc
     corpus = [" ".join(f"t{t}" for t in d) for d in docs]
@@ -528,7 +528,7 @@ def test_bm25_staged_threshold_path_vs_oracle(eng, k):
     the top-k is the first k docs) and a score plateau far longer than k that straddles many ranges."""
     from optimized_rag_amd.bm25 import Bm25Postings
     rng = np.random.default_rng(31 + k)
-    n_docs = 180_000                                             # 11 doc ranges of 16384
+    n_docs = 180_000                                             # 88 doc ranges of 2048
     lens = rng.poisson(6, n_docs)
     toks = (rng.zipf(1.3, int(lens.sum())) - 1) % 3000
     ptr_d = np.concatenate([[0], np.cumsum(lens)])
@@ -569,13 +569,13 @@ def _sparse_postings(rng, n_docs, n_terms, per_term):
 
 
 def test_bm25_more_than_256_ranges_reuses_workspace(eng):
-    """above 256 doc ranges (> 4,194,304 docs; a 12.5M-row shard has 763) the merge must still read only the
+    """above 256 doc ranges (> 524,288 docs at 2048 per range; a 12.5M-row shard has 6104) the merge must still read only the
     COUNTED front of every partial list. The same device workspace is used by two batches with different queries (so
     stale slots of the first batch sit behind the second batch's fronts); both the host and the device entry must equal
     the exact per-range select (RAG_BM25_NO_STAGING) and the CSR oracle, bit for bit."""
     import torch
     rng = np.random.default_rng(404)
-    n_docs, k = 4_500_000, 100                                   # 275 doc ranges
+    n_docs, k = 4_500_000, 100                                   # 2198 doc ranges (nine merge groups of 256)
     post = _sparse_postings(rng, n_docs, 48, 3000).load(eng)
     batches = [[[0, 3, 7], [5], [1, 1, 2, 40], [47, 0], [-1], [9, 10, 11, 12, 13, 14]],
                [[2, 0], [6, 7, 8], [30, 31], [0], [44, 45, 46, 47], [20]]]

@@ -295,10 +295,11 @@ def test_merge_topk_is_score_desc_then_id_asc(seed, n_lists, q, k, decimals, fil
 
 
 @settings(**{**COMMON, "max_examples": max(20, N_EX // 6)})
-@given(seed=st.integers(0, 2**31 - 1), n_docs=st.one_of(st.integers(16000, 36000), st.integers(66000, 100000)), vocab=st.integers(5, 200), k=st.integers(1, 120),
+@given(seed=st.integers(0, 2**31 - 1), n_docs=st.one_of(st.integers(2049, 12000), st.integers(16000, 36000), st.integers(66000, 100000)), vocab=st.integers(5, 200), k=st.integers(1, 120),
        use_tenant=st.booleans())
 def test_bm25_over_several_doc_ranges_with_tenants(seed, n_docs, vocab, k, use_tenant):
-    """Two or three 16384-document ranges (staged thresholds, running merge), optional tenant filter: rows, normalised scores
+    """2 to 49 document ranges of 2048 (up to 8 ranges: every range selects exactly; above: opening stage of 4 exact ranges, then
+    staged thresholds with the running merge), optional tenant filter: rows, normalised scores
     and the divisor equal the restated rank-bm25 scores masked to the tenant."""
     from optimized_rag_amd.bm25 import Bm25Postings
     rng = np.random.default_rng(seed)
