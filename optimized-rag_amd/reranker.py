@@ -7,7 +7,6 @@
 Inputs are lists of dicts that are mutated in place exactly as the reference does; errors are logged and answered
 with the reference's documented fallbacks (`results[:top_k]`), never raised into the agent graph.
 """
-import json
 import logging
 import math
 import os

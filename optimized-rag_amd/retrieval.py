@@ -12,8 +12,6 @@ import logging
 from datetime import datetime
 from typing import Any, Dict, List, Optional
 
-import numpy as np
-
 from .bm25 import Bm25Postings
 from .engine import as_matrix, get_engine
 

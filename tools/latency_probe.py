@@ -2,7 +2,6 @@
 which launches the time goes to). Not part of the product or of bench.py."""
 import os
 import sys
-import time
 
 import numpy as np
 import torch

@@ -12,7 +12,6 @@ import datetime as _real_datetime
 import importlib
 import importlib.util
 import json
-import math
 import os
 import sys
 import types
