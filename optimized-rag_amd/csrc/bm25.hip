@@ -30,8 +30,9 @@ typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
 #define BM_THREADS 256
 #endif
 #define BM_SEG (BM_RANGE / BM_THREADS)      // 8 contiguous docs per thread
-// accumulator i lives at LDS double i + i/32: a thread's 32 contiguous docs then start one bank-pair further than its
-// neighbour's, so the per-thread segment reads are conflict-free (unpadded: every lane on the same bank, 32-way)
+// accumulator i lives at LDS double i + i/32 (one pad double per 32 docs). The padding dates from 32 docs per thread, where it
+// made the per-thread segment reads of the select conflict-free; with 8 docs per thread it still spreads the lanes (lane t
+// starts at bank pair 8(t%4) + t/4: at most 2-way instead of 8-way). The adds of the token loop fall on random banks either way.
 #define SC_IDX(i) ((i) + ((i) >> 5))
 #define BM_SC_DOUBLES (BM_RANGE + BM_RANGE / 32)
 #define BM_LDS_BYTES (BM_SC_DOUBLES * 8 + 4096)
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
         return;
     }
     const int seg0 = tid * BM_SEG;
-    uint64_t keys[BM_SEG];           // this thread's 32 docs, read once (conflict-free thanks to the padding)
+    uint64_t keys[BM_SEG];           // this thread's BM_SEG docs, read once
 #pragma unroll
     for (int j = 0; j < BM_SEG; ++j) keys[j] = (seg0 + j) < lim ? f64_orderable(sc[SC_IDX(seg0 + j)]) : 0ull;
     if (tenants != nullptr) {
