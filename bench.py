@@ -9,11 +9,15 @@ roofline figures and a CPU baseline timed on this box's host cores (bench_modes.
 
   python bench.py --gpus N --steps K --warmup W
   N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+       or just `python bench.py --gpus N`: with WORLD_SIZE unset the script starts that launcher itself as a child process
+       (before anything touches a GPU) and relays rank 0's JSON line.
 
 One process per GPU. The corpus is row-sharded over the N ranks (STRONG scaling: the same 1M-row corpus and the
 same 1024-query batch at every N); each rank searches its shard through the C-ABI, the per-shard top-k lists
-(ids int64 + float64 scores) are exchanged with one RCCL all-gather and merged on device (rag_merge_topk_dev).
-A "step" = one batch of 1024 queries answered against the whole corpus. Rank 0 prints ONE JSON line.
+(ids int64 + float64 scores) are exchanged with one RCCL all-gather (bound behind the C-ABI: rag_comm_allgather_dev) and
+merged on device (rag_merge_topk_dev). A "step" = one batch of 1024 queries answered against the whole corpus. For N > 1 the
+line also carries a `shard_12p5M` block: BASELINE.json configs[4] with 12.5M rows PER GPU (weak scaling: N x 12.5M rows) -
+dense, hybrid (ShardedHybridIndex) and retrieve + rerank (ShardedPipeline). Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -102,6 +106,34 @@ def gen_queries(Q, total_rows, n_chunks, chunk_rows, device, kind="iid"):
     return (q / q.norm(dim=1, keepdim=True)).contiguous(), rows
 
 
+def launcher_command(n_gpus, port, argv):
+    """The command the driver itself uses for N > 1 (one rank per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n_gpus, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE: start the N ranks as a CHILD process tree (never exec from a process that
+    may have touched the GPU - this one has not: importing torch does not initialise HIP), relay rank 0's JSON line, return
+    the child's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(launcher_command(n_gpus, port, argv), env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    else:
+        sys.stdout.write(proc.stdout)
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,8 +145,14 @@ def main():
     ap.add_argument("--mode", default="dense", choices=["dense", "hybrid", "rerank", "pipeline"],
                     help="dense = the headline metric (default); hybrid / rerank = BASELINE configs[2] / [3], single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--abi-comm", action="store_true",
-                    help="N > 1: gather through rag_comm_allgather_dev (RCCL bound behind the C-ABI) instead of torch.distributed")
+    ap.add_argument("--torch-comm", action="store_true",
+                    help="N > 1: gather through torch.distributed instead of rag_comm_allgather_dev (RCCL bound behind the C-ABI, the default)")
+    ap.add_argument("--abi-comm", action="store_true", help="(default since round 3; kept so that older command lines still parse)")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU rehearsal of the N > 1 launch path (tests/test_bench_launcher.py): the ranks join a gloo group, count "
+                         "themselves with one all-reduce, rank 0 prints a JSON line; no GPU is touched")
+    ap.add_argument("--shard-rows", type=int, default=12_500_000,
+                    help="N > 1: rows PER GPU of the configs[4] block (0 skips it)")
     ap.add_argument("--dense-only", action="store_true", help="skip the hybrid / retrieve_rerank / agent_latency blocks")
     ap.add_argument("--corpus", default="iid", choices=["iid", "clustered", "sorted", "tenant-contiguous"],
                     help="row order / structure of the synthetic corpus (default: i.i.d. unit Gaussians, BASELINE configs[1]); "
@@ -124,11 +162,21 @@ def main():
                     help="also time Q=1 searches (off by default so that every launch of the run has the bench shape and "
                          "rocprofv3's per-kernel averages match the reported ones)")
     ap.add_argument("--cpu-sample-queries", type=int, default=128)
+    ap.add_argument("--only-hybrid-calls", action="store_true",
+                    help="--mode hybrid: issue nothing but full-batch rag_hybrid_rrf_dev calls (profiling runs: rocprofv3's per-kernel "
+                         "averages are then per-batch figures of exactly the timed shape)")
+    ap.add_argument("--vocab", type=int, default=100_000, help="--mode hybrid: BM25 vocabulary size (> 100000 selects the "
+                    "truncated-Zipf generator bench_modes.zipf_postings_gpu)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.launcher_selftest:
+        return launcher_selftest(args)
     if args.mode != "dense":
         from bench_modes import run_mode
         return run_mode(args)
+    logging_quiet()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -177,10 +225,31 @@ def main():
     torch.cuda.empty_cache()
 
     from optimized_rag_amd.sharded import ShardedDenseIndex
-    if world > 1 and args.abi_comm:       # the 128-byte RCCL id travels through the process group that launched the ranks
-        uid = [eng.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(rank, world, uid[0])
+    comm = "single process"
+    if world > 1:
+        comm = "torch.distributed (%s)" % backend
+        if backend == "nccl" and not args.torch_comm:
+            # RCCL behind the C-ABI: the 128-byte id travels through the process group that launched the ranks. Every rank must
+            # agree on the path, so a failure anywhere (librccl not loadable) sends all of them back to torch.distributed.
+            ok = 1
+            try:
+                uid = [eng.comm_unique_id() if rank == 0 else None]
+            except Exception:
+                uid, ok = [None], 0
+            dist.broadcast_object_list(uid, src=0)
+            try:
+                if uid[0] is not None and ok:
+                    eng.comm_init(rank, world, uid[0])
+                else:
+                    ok = 0
+            except Exception:
+                ok = 0
+            flag = torch.tensor([ok], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                comm = "rag_comm_allgather_dev (RCCL behind the C-ABI)"
+            elif ok:
+                eng.comm_destroy()
     index = ShardedDenseIndex(eng, rank=rank, world=world)
 
     def step():
@@ -241,6 +310,23 @@ def main():
     got_ids = final_ids.cpu().numpy()
     got_sc = final_scores.cpu().numpy()
     planted_hit = float((got_ids[:, 0] == planted.numpy()).mean())
+
+    # ---- N > 1: BASELINE.json configs[4] at its real per-GPU size (12.5M rows each; weak scaling) through the sharded classes
+    shard_block = None
+    if world > 1 and args.shard_rows > 0 and args.corpus == "iid":
+        import bench_shard as BS
+        ranks_seen = torch.ones(1, device=device)
+        dist.all_reduce(ranks_seen)                                # what the collective layer itself counted
+        try:
+            del index
+            st_sh = BS.build_shard(eng, device, args.shard_rows, rank=rank, world=world, Q=256)
+            shard_block = BS.shard_blocks(eng, st_sh, device, rank=rank, world=world, steps=3)
+            shard_block.update({"rows_per_gpu": args.shard_rows, "corpus_rows": args.shard_rows * world, "scaling": "weak",
+                                "ranks_in_collective": int(ranks_seen.item()),
+                                "workload": f"{args.shard_rows * world} x {DIM}-d corpus row-sharded x{world} (BASELINE.json configs[4]): dense, "
+                                            "hybrid (BM25 over a 2M-term vocabulary) and retrieve + rerank, 256-query batches"})
+        except Exception as e:                                     # never at the cost of the headline line
+            shard_block = {"error": f"{type(e).__name__}: {e}"}
 
     if rank != 0:
         if world > 1:
@@ -313,7 +399,8 @@ def main():
                                ("" if args.corpus == "iid" else f"; ROW ORDER VARIANT --corpus {args.corpus} (not the headline config)"),
                    "corpus": args.corpus,
                    "corpus_rows": args.rows, "rows_per_gpu": n_local, "batch_queries": Q, "k": k,
-                   "parallelism": f"row-sharded x{world}" + ((" + RCCL all-gather (C-ABI) + merge" if args.abi_comm else " + RCCL all-gather merge") if world > 1 else "")},
+                   "parallelism": f"row-sharded x{world}" + (" + one all-gather per batch + device merge" if world > 1 else ""),
+                   "exchange": comm},
         "p50_batch_latency_ms": round(p50, 4), "p50_single_query_latency_ms": None if lat1 is None else round(lat1, 4),
         "exactness": {**stats, "planted_neighbour_at_rank1": planted_hit},
         "roofline": roofline,
@@ -334,9 +421,35 @@ def main():
                 out[name] = res
             except Exception as e:                      # a secondary block must never cost the headline line
                 out[name] = {"error": f"{type(e).__name__}: {e}"}
+    if shard_block is not None:
+        out["shard_12p5M"] = shard_block
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def launcher_selftest(args):
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1:
+        dist.init_process_group("gloo")
+    seen = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(seen)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks_in_collective": int(seen.item()),
+                          "master_addr": os.environ.get("MASTER_ADDR"), "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def logging_quiet():
+    """The agent-latency block drives the mirror classes, which log at WARNING ("Consistency check found 1 contradictions" per
+    call): keep the driver's stderr tail readable - only errors get through."""
+    import logging
+    logging.getLogger().setLevel(logging.ERROR)
+    logging.getLogger("optimized_rag_amd").setLevel(logging.ERROR)
 
 
 if __name__ == "__main__":

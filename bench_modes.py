@@ -30,6 +30,70 @@ def synthetic_csr(n_docs, vocab, mean_len, seed=99):
     return indptr, d, tf.astype(np.int32), lens.astype(np.int32), tok, np.concatenate([[0], np.cumsum(lens)])
 
 
+def zipf_postings_gpu(n_docs, vocab, mean_len, device, seed=99, s=1.1, chunk_docs=500_000, sample_docs=None):
+    """Synthetic postings at shard scale, generated ON THE GPU (torch is used as a data generator here, never on the measured
+    path): doc length ~ Poisson(mean_len), tokens drawn from a TRUNCATED Zipf(s) over `vocab` term ids (inverse CDF), so a
+    multi-million-term vocabulary has the long tail of rare terms a real `doc.lower().split()` corpus has
+    (rag/retrieval.py:334-335) - synthetic_csr's folded Zipf over 100k ids does not. Term-major CSR, docs ascending.
+    Returns host arrays (indptr int64 [V+1], doc int32 [nnz], tf int32 [nnz], doc_len int32 [N]) and, for every doc id in
+    `sample_docs`, that document's token list (the bench draws its query terms from documents)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    w = torch.arange(1, vocab + 1, device=device, dtype=torch.float64).pow_(-s)
+    cdf = torch.cumsum(w, 0)
+    cdf /= cdf[-1].clone()
+    del w
+    lens_all = torch.poisson(torch.full((n_docs,), float(mean_len), device=device), generator=g).to(torch.int64)
+    keys, sampled = [], {}
+    want = None if sample_docs is None else torch.as_tensor(np.asarray(sample_docs, dtype=np.int64), device=device)
+    TF_BITS = 10
+    for d0 in range(0, n_docs, chunk_docs):
+        d1 = min(n_docs, d0 + chunk_docs)
+        lens = lens_all[d0:d1]
+        total = int(lens.sum().item())
+        u = torch.rand((total,), generator=g, device=device, dtype=torch.float64)
+        tok = torch.searchsorted(cdf, u).clamp_(max=vocab - 1)
+        del u
+        doc = torch.repeat_interleave(torch.arange(d0, d1, device=device, dtype=torch.int64), lens)
+        if want is not None:
+            ptr = torch.cumsum(lens, 0) - lens
+            for dd in want[(want >= d0) & (want < d1)].tolist():
+                a = int(ptr[dd - d0].item())
+                sampled[dd] = tok[a:a + int(lens[dd - d0].item())].cpu().numpy()
+        k = torch.sort(tok * n_docs + doc).values
+        del tok, doc
+        uk, tf = torch.unique_consecutive(k, return_counts=True)
+        del k
+        keys.append((uk << TF_BITS) | tf.clamp_(max=(1 << TF_BITS) - 1))
+        del uk, tf
+    allk = torch.sort(torch.cat(keys)).values
+    del keys
+    tf = (allk & ((1 << TF_BITS) - 1)).to(torch.int32)
+    allk >>= TF_BITS
+    term = allk // n_docs
+    doc = (allk - term * n_docs).to(torch.int32)
+    del allk
+    indptr = torch.zeros(vocab + 1, dtype=torch.int64, device=device)
+    indptr[1:] = torch.cumsum(torch.bincount(term, minlength=vocab), 0)
+    del term
+    out = (indptr.cpu().numpy(), doc.cpu().numpy(), tf.cpu().numpy(), lens_all.to(torch.int32).cpu().numpy())
+    del indptr, doc, tf, lens_all, cdf
+    torch.cuda.empty_cache()
+    return out + (sampled,)
+
+
+def term_queries_from_docs(sampled, order, seed=7):
+    """4-12 tokens drawn (with replacement) from each sampled document, in `order` -> (term_ptr, terms) int32."""
+    rng = np.random.default_rng(seed)
+    ptr, terms = [0], []
+    for dd in order:
+        toks = sampled[int(dd)]
+        n = int(rng.integers(4, 13))
+        terms.extend(int(x) for x in (rng.choice(toks, n) if len(toks) else [0] * n))
+        ptr.append(len(terms))
+    return np.asarray(ptr, np.int32), np.asarray(terms, np.int32)
+
+
 def timed(fn, steps, warmup):
     for _ in range(warmup):
         fn()
@@ -92,7 +156,12 @@ def run_mode(args):
         q = corpus[rows.to(device)] + torch.randn((Q, DIM), generator=g, device=device) * (0.5 / DIM ** 0.5)
         q = (q / q.norm(dim=1, keepdim=True)).contiguous()
         t0 = time.perf_counter()
-        indptr, d, tf, dl, tok, doc_ptr = synthetic_csr(N, 100_000, 120)
+        vocab = getattr(args, "vocab", 100_000)
+        if vocab > 100_000:            # long-tailed vocabulary (millions of terms): generated on the GPU
+            qdocs = np.random.default_rng(7).integers(0, N, Q)
+            indptr, d, tf, dl, sampled = zipf_postings_gpu(N, vocab, 120, device, sample_docs=qdocs)
+        else:
+            indptr, d, tf, dl, tok, doc_ptr = synthetic_csr(N, vocab, 120)
         post = Bm25Postings(indptr, d, tf, dl, Bm25Postings.idf_table(np.diff(indptr).clip(min=0), N), float(dl.sum()) / N)
         post.idf[np.diff(indptr) == 0] = 0.0
         sharded = None
@@ -105,15 +174,10 @@ def run_mode(args):
             post.load(eng)
         del corpus
         build_s = time.perf_counter() - t0
-        rng = np.random.default_rng(7)
-        ptr, terms = [0], []
-        for i in range(Q):                                   # 4-12 tokens sampled from a random doc
-            di = int(rng.integers(0, N))
-            toks = tok[doc_ptr[di]:doc_ptr[di + 1]]
-            n = int(rng.integers(4, 13))
-            terms.extend(int(x) for x in (rng.choice(toks, n) if len(toks) else [0] * n))
-            ptr.append(len(terms))
-        ptr, terms = np.asarray(ptr, np.int32), np.asarray(terms, np.int32)
+        if vocab > 100_000:
+            ptr, terms = term_queries_from_docs(sampled, qdocs)
+        else:
+            ptr, terms = _term_queries(tok, doc_ptr, N, Q)                 # 4-12 tokens sampled from a random doc
         ptr_d, terms_d = torch.from_numpy(ptr).to(device), torch.from_numpy(terms).to(device)
         ids_d = torch.empty((Q, pool), dtype=torch.int64, device=device)
         sc_d = torch.empty((Q, pool), dtype=torch.float64, device=device)
@@ -129,11 +193,14 @@ def run_mode(args):
                 return sharded.search_hybrid(q, ptr_d, terms_d, pool, k)
             return eng.hybrid_rrf_dev(q, ptr_d, terms_d, pool, k)
 
-        t_dense = timed(dense, args.steps, args.warmup)
-        t_bm25 = timed(bm25, args.steps, 1)
+        only = getattr(args, "only_hybrid_calls", False)
+        t_dense = 0.0 if only else timed(dense, args.steps, args.warmup)
+        t_bm25 = 0.0 if only else timed(bm25, args.steps, 1)
         total = timed_all_ranks(hybrid, args.steps, 1, world)
         t_fuse = max(total - t_dense - t_bm25, 0.0)
-        nnz_touched = float(sum(int(indptr[t + 1] - indptr[t]) for t in terms if t >= 0))
+        nnz_touched = float(np.diff(indptr)[terms[terms >= 0]].sum())
+        from optimized_rag_amd._lib import bm25_index_bytes
+        idx_bytes = bm25_index_bytes(indptr, N)
         out.update({
             "metric": "queries/sec (hybrid: dense top-100 + BM25 top-100 + RRF -> top-20)", "value": round(Q / total, 1),
             "unit": "queries/sec", "ms_per_step": round(total * 1e3, 3), "higher_is_better": True,
@@ -141,8 +208,9 @@ def run_mode(args):
                                    f"batch={Q} (BASELINE.json configs[2])"},
             "stages_ms": {"dense_top100_dev": round(t_dense * 1e3, 3), "bm25_top100_dev": round(t_bm25 * 1e3, 3),
                           "rrf_fuse_dev (by difference)": round(t_fuse * 1e3, 3)},
-            "bm25": {"postings_touched_per_batch": nnz_touched,
-                     "algorithmic_GBs": round(nnz_touched * 12 / t_bm25 / 1e9, 1), "index_build_s": round(build_s, 1)},
+            "bm25": {"postings_touched_per_batch": nnz_touched, "vocab": vocab, "distinct_terms": int((np.diff(indptr) > 0).sum()),
+                     "algorithmic_GBs": None if only else round(nnz_touched * 12 / t_bm25 / 1e9, 1), "index_build_s": round(build_s, 1),
+                     "index_bytes": {"postings": idx_bytes[0], "term_metadata": idx_bytes[1], "bracket_tables": idx_bytes[2]}},
             "note": "value = one rag_hybrid_rrf_dev call per batch, inputs and outputs resident in HBM" if sharded is None else
                     "value = local dense + BM25 lists, ONE all-gather (RCCL), two merges, RRF; max over ranks",
         })

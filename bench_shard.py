@@ -1,0 +1,148 @@
+"""The per-GPU share of BASELINE.json configs[4] ("100M x 1536-d corpus sharded 8-way, hybrid + rerank, per-shard top-k
+RCCL all-gather over xGMI"): 12.5M rows per GPU with their fp32 masters, fp16 MFMA operand, doc-partitioned BM25 postings
+over a multi-million-term vocabulary, the replicated passage token store and the cross-encoder - built on ONE rank
+(world = 1: the single-GPU share, tools/r3_shard.sh and tests/test_full_size_gpu.py) or on every rank of a node
+(bench.py --gpus N). Everything synthetic is generated on the GPU with torch (data generation only, never the measured
+path) in seeded chunks, so the oracle side of a parity check can regenerate any piece.
+
+Reference path this stands for: /root/reference/rag/document_store.py:448-460 (pgvector top-k), rag/retrieval.py:324-347
+(BM25Okapi over the corpus), rag/reranker.py:224-271 (RRF) and :346-359 (cross-encoder rerank).
+"""
+import time
+
+import numpy as np
+import torch
+
+import bench as BE
+import bench_modes as BM
+
+DIM = BE.DIM
+VOCAB = 2_000_000          # distinct term ids of the synthetic text (truncated Zipf(1.1)): the tail `doc.lower().split()` has
+MEAN_LEN = 120
+TOK_L = 224                # passage tokens kept per document (~U[96, 224])
+TOK_CHUNK = 500_000
+
+
+def gen_tokens_chunk(c, rows, device, vocab_size, L=TOK_L):
+    """Rows [c*TOK_CHUNK, ...) of the passage token store: WordPiece ids ~U[1000, vocab), lengths ~U[96, L]."""
+    g = torch.Generator(device=device)
+    g.manual_seed(5000 + c)
+    tok = torch.randint(1000, vocab_size, (rows, L), generator=g, device=device, dtype=torch.int32)
+    ln = torch.randint(96, L + 1, (rows,), generator=g, device=device, dtype=torch.int32)
+    return tok, ln
+
+
+def build_shard(eng, device, rows_per_gpu, rank=0, world=1, Q=256, vocab=VOCAB, ce_seed=2024, with_rerank=True, log=None):
+    """Loads this rank's share into `eng` and returns the replicated query batch + what an oracle check needs.
+    Global doc ids: rank r owns [r * rows_per_gpu, (r + 1) * rows_per_gpu). BM25 statistics (df -> idf, avgdl) are GLOBAL:
+    summed over the ranks with one all-reduce each, as SURVEY 8e prescribes (computed at index build, replicated)."""
+    import torch.distributed as dist
+    from optimized_rag_amd.bm25 import Bm25Postings
+    from optimized_rag_amd.cross_encoder import MINILM_L6_CONFIG, random_init_tensors
+    say = log or (lambda *a: None)
+    total_rows = rows_per_gpu * world
+    chunk = BE.CHUNK_ROWS
+    assert rows_per_gpu % chunk == 0
+    n_chunks = total_rows // chunk
+    my_chunks = range(rank * (rows_per_gpu // chunk), (rank + 1) * (rows_per_gpu // chunk))
+    t0 = time.perf_counter()
+    eng.index_reserve(rows_per_gpu, id_base=rank * rows_per_gpu)
+    for c in my_chunks:
+        eng.index_append(BE.gen_chunk(c, chunk, device, "iid", total_rows))
+    queries, planted = BE.gen_queries(Q, total_rows, n_chunks, chunk, device, "iid")
+    say(f"dense index: {rows_per_gpu} rows in {time.perf_counter() - t0:.1f}s")
+    # ---- postings of this rank's documents (local doc numbers), global statistics -----------------------------------
+    t0 = time.perf_counter()
+    qdocs = np.random.default_rng(7).integers(0, rows_per_gpu, Q)              # query terms are drawn from rank 0's documents
+    indptr, d, tf, dl, sampled = BM.zipf_postings_gpu(rows_per_gpu, vocab, MEAN_LEN, device, seed=99 + rank, sample_docs=qdocs if rank == 0 else None)
+    df = torch.from_numpy(np.diff(indptr)).to(device)
+    len_sum = torch.tensor([float(dl.sum())], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(df)
+        dist.all_reduce(len_sum)
+    df_h = df.cpu().numpy()
+    idf = Bm25Postings.idf_table(df_h, total_rows)
+    idf[df_h == 0] = 0.0
+    avgdl = float(len_sum.item()) / total_rows
+    post = Bm25Postings(indptr, d, tf, dl, idf, avgdl)
+    post.load(eng)
+    if world > 1:
+        eng.bm25_set_normalize(False)                                           # shards hand out RAW scores (sharded.py)
+    if rank == 0:
+        ptr, terms = BM.term_queries_from_docs(sampled, qdocs)
+    if world > 1:
+        box = [(ptr, terms) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ptr, terms = box[0]
+    say(f"postings: nnz {int(indptr[-1])}, {int((np.diff(indptr) > 0).sum())} distinct terms locally, in {time.perf_counter() - t0:.1f}s")
+    out = dict(queries=queries, planted=planted, post=post, term_ptr=ptr, terms=terms,
+               ptr_d=torch.from_numpy(ptr).to(device), terms_d=torch.from_numpy(terms).to(device), total_rows=total_rows)
+    if with_rerank:
+        t0 = time.perf_counter()
+        cfg = MINILM_L6_CONFIG
+        tensors = random_init_tensors(cfg, ce_seed)
+        eng.ce_load(cfg, tensors)
+        # REPLICATED passage token store over all `total_rows` documents (100M x 224 x 2 B = 44.8 GB fits)
+        eng.tokens_reserve(total_rows, TOK_L)
+        for c in range((total_rows + TOK_CHUNK - 1) // TOK_CHUNK):
+            tok, ln = gen_tokens_chunk(c, min(TOK_CHUNK, total_rows - c * TOK_CHUNK), device, cfg["vocab_size"])
+            eng.tokens_append_dev(tok, ln)
+        g = torch.Generator()
+        g.manual_seed(8)
+        q_tok = torch.randint(1000, cfg["vocab_size"], (Q, 16), generator=g, dtype=torch.int32)
+        out.update(cfg=cfg, tensors=tensors, q_tok=q_tok, q_tok_d=q_tok.to(device),
+                   q_len_d=torch.full((Q,), 16, dtype=torch.int32, device=device))
+        say(f"cross-encoder + {total_rows}-passage token store in {time.perf_counter() - t0:.1f}s")
+    torch.cuda.empty_cache()
+    return out
+
+
+def hbm_used_gb(device):
+    free, total = torch.cuda.mem_get_info(device)
+    return round((total - free) / 1e9, 1), round(total / 1e9, 1)
+
+
+def shard_blocks(eng, st, device, rank=0, world=1, steps=3, pool=100, k=20, L_pair=256, with_rerank=True):
+    """Times the sharded classes on the loaded share: dense (1024 / 256 / 128 queries), hybrid (256), retrieve + rerank (256).
+    bench.py's contract per timing: barrier + synchronize on both sides, max over ranks."""
+    from optimized_rag_amd.sharded import ShardedDenseIndex, ShardedHybridIndex, ShardedPipeline
+    q = st["queries"]
+    Q = q.shape[0]
+    blocks = {}
+    dense = ShardedDenseIndex(eng, rank=rank, world=world)
+    for nq in sorted({Q, min(Q, 128)}, reverse=True):
+        qq = q[:nq].contiguous()
+        t = BM.timed_all_ranks(lambda: dense.search(qq, k), steps, 1, world)
+        ids, _ = dense.search(qq, k)
+        torch.cuda.synchronize()
+        hit = float((ids[:, 0].cpu() == st["planted"][:nq]).float().mean())
+        n_local = st["total_rows"] // world
+        blocks[f"dense_q{nq}"] = {"queries_per_sec": round(nq / t, 1), "ms_per_batch": round(t * 1e3, 3),
+                                  "planted_neighbour_at_rank1": hit,
+                                  "corpus_pass_GBs_per_gpu": round(n_local * DIM * 2 / t / 1e9, 1),
+                                  "hbm_roof_frac": round(n_local * DIM * 2 / t / 1e9 / BE.PEAK_HBM_GBS, 4),
+                                  "mfma_roof_frac": round(2.0 * nq * n_local * DIM / t / 1e12 / BE.PEAK_MFMA_TFLOPS, 4)}
+    # one GPU: the one-call entries (rag_hybrid_rrf_dev / rag_retrieve_rerank_dev); several: the sharded classes around them
+    hyb = ShardedHybridIndex(eng, rank=rank, world=world)
+    hybrid = (lambda: eng.hybrid_rrf_dev(q, st["ptr_d"], st["terms_d"], pool, k)) if world == 1 else \
+             (lambda: hyb.search_hybrid(q, st["ptr_d"], st["terms_d"], pool, k))
+    t = BM.timed_all_ranks(hybrid, steps, 1, world)
+    blocks["hybrid_q%d" % Q] = {"queries_per_sec": round(Q / t, 1), "ms_per_batch": round(t * 1e3, 3),
+                                "workload": f"dense top-{pool} + BM25 top-{pool} + RRF -> top-{k}" +
+                                            ("" if world == 1 else ", one all-gather of both lists")}
+    if with_rerank:
+        pipe = ShardedPipeline(eng, rank=rank, world=world)
+
+        def run():
+            if world == 1:
+                return eng.retrieve_rerank_dev(q, st["q_tok_d"], st["q_len_d"], pool, k, term_ptr=st["ptr_d"], terms=st["terms_d"], L_pair=L_pair)
+            return pipe.retrieve_rerank(q, st["ptr_d"], st["terms_d"], st["q_tok_d"], st["q_len_d"], pool, k, L_pair=L_pair)
+
+        t = BM.timed_all_ranks(run, max(1, steps - 1), 1, world)
+        blocks["retrieve_rerank_q%d" % Q] = {"queries_per_sec": round(Q / t, 2), "ms_per_batch": round(t * 1e3, 2),
+                                             "workload": f"hybrid top-{pool} -> MiniLM-L-6 cross-encoder (L={L_pair}, pairs split over the "
+                                                         f"ranks) -> top-{k}"}
+    used, total = hbm_used_gb(device)
+    blocks["hbm_used_gb"] = used
+    blocks["hbm_total_gb"] = total
+    return blocks

@@ -46,6 +46,11 @@ int rag_create(int device_id, int dim, rag_handle_t* out);
 int rag_destroy(rag_handle_t h);
 const char* rag_last_error(rag_handle_t h);
 int rag_synchronize(rag_handle_t h);
+/* Diagnostic / tuning switch of one handle (no reference counterpart). Every switch <name> takes its default from the
+ * environment variable RAG_<NAME> ONCE, when rag_create runs; afterwards only this call changes it. Names: force_level,
+ * stage_growth, no_smallq, no_second_pass, dense_linear_order, bm25_first_ranges, bm25_no_staging, no_fork,
+ * ce_no_fused_ln, ce_no_fused_ffn, ce_chunk_tokens. Unknown name: RAG_ERR_ARG. */
+int rag_set_option(rag_handle_t h, const char* name, int value);
 
 /* ---- dense index: replaces the pgvector tables behind
  *      `ORDER BY dc.embedding <=> %s::vector LIMIT %s`  (rag/document_store.py:448-460)
@@ -116,6 +121,18 @@ int rag_merge_topk_dev(rag_handle_t h, const int64_t* ids_dev, const double* sco
                        int64_t list_stride, int n_queries, int k, int64_t* ids_out_dev, double* scores_out_dev,
                        void* stream);
 
+/* The fuse step of the row-sharded HYBRID search on every rank, after the one all-gather:
+ * gathered_dev = [world][4][Q][pool] int64 = every rank's dense ids | dense cosines (float64 bits) | BM25 ids | RAW BM25
+ * scores (float64 bits; rag_bm25_set_normalize(h, 0) on the shards). Merges the dense lists and the BM25 lists (score desc,
+ * id asc), divides the merged BM25 scores by their GLOBAL maximum (when > 0, else 1.0: rag/retrieval.py:343-345 - the
+ * shards cannot know it), then fuses the two MERGED lists with RRF (rag/reranker.py:224-271; RRF needs global ranks).
+ * lists_out_dev [2][Q][pool] int64 = merged dense ids | merged BM25 ids, scores_out_dev [2][Q][pool] float64 = cosines |
+ * normalised BM25; keys / rrf / ranks as rag_rrf_fuse_dev with n_lists = 2. Bit-identical to rag_hybrid_rrf_dev on the
+ * unsharded index. */
+int rag_hybrid_fuse_gathered_dev(rag_handle_t h, const int64_t* gathered_dev, int world, int n_queries, int pool, int k,
+                                 int rrf_k, int64_t* lists_out_dev, double* scores_out_dev, int64_t* keys_out_dev,
+                                 double* rrf_out_dev, int32_t* ranks_out_dev, void* stream);
+
 /* ---- small pairwise cosine in float64: replaces the Python loops
  *      rag/consistency_checker.py:169-176, rag/context_compressor.py:227-228, rag/reranker.py:167-175,
  *      rag/nodes/helpers.py:232-243, rag/retrieval.py:253-256.  out[m*n] row-major, 0.0 on zero norm. */
@@ -175,6 +192,14 @@ int rag_bm25_load_host(rag_handle_t h, const int64_t* indptr_host /*V+1*/, const
                        const int32_t* tf_host /*nnz*/, const int32_t* doc_len_host /*N*/,
                        const double* idf_host /*V*/, int64_t n_docs, int64_t n_terms, double avgdl,
                        double k1, double b);
+/* HBM bytes rag_bm25_load_host will take for a CSR with these offsets, computed on the host from indptr alone (no GPU call):
+ * postings (doc id + float64 impact, 12 B each), per-term metadata (32 B each) and the per-term bracket tables that replace
+ * a binary search of the posting list per (query token, 2048-document range). A term's table is sized by its document
+ * frequency, so table bytes <= postings/12 for ANY vocabulary - the reference tokeniser (`doc.lower().split()`,
+ * rag/retrieval.py:334-335) produces millions of distinct terms on a large shard. Lets a loader budget a shard before
+ * uploading it. Any of the outputs may be NULL. */
+int rag_bm25_index_bytes(const int64_t* indptr_host, int64_t n_docs, int64_t n_terms, int64_t* postings_bytes_out,
+                         int64_t* meta_bytes_out, int64_t* table_bytes_out);
 /* term_ptr[Q+1], terms[term_ptr[Q]] (query tokens WITH repeats; -1 = out-of-vocabulary).
  * scores_out are max-normalised as the reference does; raw_max_out[Q] (may be NULL) is the divisor.
  * tenant >= 0 (needs rag_index_set_tenants_host and postings row-aligned with the index): only that tenant's documents
@@ -208,7 +233,8 @@ int rag_linear_fuse_topk_host(rag_handle_t h, const double* semantic_host, const
 /* Index-level linear fusion (SURVEY.md section 8b `rag_hybrid_linear`): HybridRetriever.hybrid_search
  * (rag/retrieval.py:214-322) with the WHOLE resident index as its corpus. Per query and row:
  *   hybrid = (alpha * cosine + beta * keyword) + gamma * temporal      (:302, CPython's operation order, float64)
- * keyword = BM25Okapi score / max over all documents (1.0 when that max is <= 0, :343-345); temporal = the per-row vector
+ * keyword = BM25Okapi score / max over all documents - under a tenant filter over the tenant's documents, the corpus the
+ * reference would have been handed - (1.0 when that max is <= 0, :343-345); temporal = the per-row vector
  * of rag_index_set_temporal_host (RECENCY_WEIGHT * 0.5 ** (days_old / half_life), computed by the host as :266-292 does;
  * NULL = zeros). Result: stable sort descending (lower row first on ties), first k; rows_out are index rows, ids_out doc
  * ids, hybrid_out the float64 hybrid scores; semantic / keyword / temporal_out (each [Q*k], may be NULL) are the
@@ -245,6 +271,11 @@ int rag_ce_score_dev(rag_handle_t h, const int32_t* input_ids_dev, const int32_t
  *      ids_out[k] doc ids (-1 padded), scores_out[k] = sigmoid(logit) as float64, logits_out[k] raw logits,
  *      cand_out[pool] (may be NULL) the candidate list that was reranked. */
 int rag_tokens_load_host(rag_handle_t h, const int32_t* tokens_host, const int32_t* lens_host, int64_t n_rows, int L);
+/* Chunked form for stores that should not exist as one host array (a replicated 100M-passage store, SURVEY.md section 8e, is
+ * 45 GB resident as uint16 and would be 90 GB as one int32 host array): reserve once, then append row blocks in order from
+ * DEVICE memory (tokens_dev[n][L] int32, lens_dev[n]); each append returns after its rows are resident and checked. */
+int rag_tokens_reserve(rag_handle_t h, int64_t n_rows_total, int L);
+int rag_tokens_append_dev(rag_handle_t h, const int32_t* tokens_dev, const int32_t* lens_dev, int64_t n_rows, void* stream);
 int rag_retrieve_rerank_dev(rag_handle_t h, const float* q_emb_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev,
                             const int32_t* q_tok_dev, const int32_t* q_len_dev, int Lq, int n_queries, int pool, int k,
                             int rrf_k, int tenant, int mode, int cls_id, int sep_id, int L_pair, int64_t* ids_out_dev,

@@ -46,6 +46,8 @@ _SIGS = {
     "rag_last_error": ([_P], C.c_char_p),
     "rag_synchronize": ([_P], C.c_int),
     "rag_set_profiling": ([_P, C.c_int], C.c_int),
+    "rag_set_option": ([_P, C.c_char_p, C.c_int], C.c_int),
+    "rag_bm25_index_bytes": ([_P, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)], C.c_int),
     "rag_index_load_host": ([_P, _P, _P, C.c_int64, C.c_int64], C.c_int),
     "rag_index_load_dev": ([_P, _P, _P, C.c_int64, C.c_int64, _P], C.c_int),
     "rag_index_reserve": ([_P, C.c_int64, C.c_int64], C.c_int),
@@ -86,6 +88,9 @@ _SIGS = {
     "rag_ce_load_host": ([_P, C.POINTER(CeConfig), C.POINTER(_P), C.c_int], C.c_int),
     "rag_ce_score_host": ([_P, _P, _P, _P, C.c_int, C.c_int, _P], C.c_int),
     "rag_tokens_load_host": ([_P, _P, _P, C.c_int64, C.c_int], C.c_int),
+    "rag_tokens_reserve": ([_P, C.c_int64, C.c_int], C.c_int),
+    "rag_tokens_append_dev": ([_P, _P, _P, C.c_int64, _P], C.c_int),
+    "rag_hybrid_fuse_gathered_dev": ([_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P], C.c_int),
     "rag_retrieve_rerank_dev": ([_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, _P, _P, _P, _P, _P], C.c_int),
     "rag_ce_build_pairs_dev": ([_P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
@@ -135,6 +140,16 @@ def load_library(path=None):
     return lib
 
 
+def bm25_index_bytes(indptr, n_docs):
+    """(postings, metadata, bracket-table) bytes of HBM a CSR with these offsets takes once loaded; host-only, no GPU."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+    rc = load_library().rag_bm25_index_bytes(C.c_void_p(indptr.ctypes.data), int(n_docs), int(indptr.shape[0] - 1), C.byref(a), C.byref(b), C.byref(c))
+    if rc != 0:
+        raise RagError(f"rag_bm25_index_bytes failed ({rc})")
+    return int(a.value), int(b.value), int(c.value)
+
+
 def _np(a, dtype):
     a = np.ascontiguousarray(a, dtype=dtype)
     return a
@@ -181,6 +196,10 @@ class RagEngine:
 
     def synchronize(self):
         self._check(self.lib.rag_synchronize(self.h), "rag_synchronize")
+
+    def set_option(self, name, value):
+        """Diagnostic / tuning switch of this handle (include/rag_hip.h rag_set_option); defaults come from RAG_<NAME> at creation."""
+        self._check(self.lib.rag_set_option(self.h, name.encode(), int(value)), f"rag_set_option({name})")
 
     def set_profiling(self, on):
         self._check(self.lib.rag_set_profiling(self.h, 1 if on else 0), "rag_set_profiling")
@@ -533,6 +552,28 @@ class RagEngine:
         lens = _np(lens, np.int32)
         self._check(self.lib.rag_tokens_load_host(self.h, _ptr(tokens), _ptr(lens), tokens.shape[0], tokens.shape[1]),
                     "rag_tokens_load_host")
+
+    def tokens_reserve(self, n_rows_total, L):
+        self._check(self.lib.rag_tokens_reserve(self.h, int(n_rows_total), int(L)), "rag_tokens_reserve")
+
+    def tokens_append_dev(self, tokens, lens, stream=None):
+        """Append a row block of the passage token store from device memory: tokens [n, L] int32, lens [n] int32 CUDA tensors."""
+        import torch
+        assert tokens.is_cuda and tokens.dtype == torch.int32 and tokens.is_contiguous() and lens.dtype == torch.int32
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        self._check(self.lib.rag_tokens_append_dev(self.h, C.c_void_p(tokens.data_ptr()), C.c_void_p(lens.data_ptr()), tokens.shape[0], st),
+                    "rag_tokens_append_dev")
+
+    def hybrid_fuse_gathered_dev(self, gathered, k, lists_out, scores_out, keys_out, rrf_out, ranks_out, rrf_k=60, stream=None):
+        """gathered [world, 4, Q, pool] int64 (every rank's dense ids | cosine bits | BM25 ids | raw BM25 bits) -> merged lists
+        [2, Q, pool], scores [2, Q, pool] (BM25 / global max), RRF keys / scores [Q, k], ranks [Q, k, 2]. CUDA tensors."""
+        import torch
+        world, _, Q, pool = gathered.shape
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        self._check(self.lib.rag_hybrid_fuse_gathered_dev(
+            self.h, C.c_void_p(gathered.data_ptr()), int(world), int(Q), int(pool), int(k), int(rrf_k), C.c_void_p(lists_out.data_ptr()),
+            C.c_void_p(scores_out.data_ptr()), C.c_void_p(keys_out.data_ptr()), C.c_void_p(rrf_out.data_ptr()),
+            C.c_void_p(ranks_out.data_ptr()), st), "rag_hybrid_fuse_gathered_dev")
 
     def retrieve_rerank_dev(self, q_emb, q_tok, q_len, pool, k, term_ptr=None, terms=None, rrf_k=60, tenant=-1, L_pair=512,
                             cls_id=101, sep_id=102, stream=None):

@@ -40,8 +40,9 @@ class Bm25Postings:
         if 0 <= int(df.min()) and int(df.max()) <= n_docs and n_docs + 1 <= 2 * df.size:
             half_log = np.array([math.log(j + 0.5) for j in range(n_docs + 1)], dtype=np.float64)
             idf = half_log[n_docs - df] - half_log[df]
-        else:
-            idf = np.array([math.log(n_docs - int(d) + 0.5) - math.log(int(d) + 0.5) for d in df], dtype=np.float64)
+        else:           # large corpus: one pair of logarithms per DISTINCT document frequency (millions of terms share a few thousand)
+            udf, inv = np.unique(df, return_inverse=True)
+            idf = np.array([math.log(n_docs - int(d) + 0.5) - math.log(int(d) + 0.5) for d in udf], dtype=np.float64)[inv]
         avg = float(np.cumsum(idf)[-1]) / idf.size
         return np.where(idf < 0, epsilon * avg, idf)
 

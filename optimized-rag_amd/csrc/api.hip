@@ -2,6 +2,8 @@
 // staging for the *_host variants, dispatch to the kernels' host drivers.
 #include "common.h"
 
+#include <cctype>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -18,6 +20,7 @@ int bm25_scores_adhoc_host(rag_ctx* h, const int64_t* indptr, const int32_t* doc
                            const double* idf, int64_t n_docs, int64_t n_terms, double avgdl, double k1, double b,
                            const int32_t* term_ptr, const int32_t* terms, int Q, double* out);
 int64_t bm25_n_docs(const rag_ctx* h);
+int bm25_index_bytes(const int64_t* indptr, int64_t n_docs, int64_t n_terms, int64_t* postings_out, int64_t* meta_out, int64_t* table_out);
 int bm25_scores_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, double* out_dev, hipStream_t st);
 int bm25_scores_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, double* out);
 int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int tenant, int64_t* ids_dev,
@@ -43,12 +46,31 @@ int ce_build_pairs_dev(rag_ctx* h, const int32_t* q_tok_dev, const int32_t* q_le
 int rerank_topk_dev(rag_ctx* h, const float* logits_dev, const int64_t* cand_dev, int Q, int pool, int k, int64_t* ids_out, double* scores_out,
                     float* logits_out, hipStream_t st);
 int tokens_load_host(rag_ctx* h, const int32_t* tokens, const int32_t* lens, int64_t n_rows, int L);
+int tokens_reserve(rag_ctx* h, int64_t n_rows, int L);
+int tokens_append_dev(rag_ctx* h, const int32_t* tokens_dev, const int32_t* lens_dev, int64_t n_rows, hipStream_t st);
 int retrieve_rerank_dev(rag_ctx* h, const float* q_emb_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev,
                         const int32_t* q_tok_dev, const int32_t* q_len_dev, int Lq, int Q, int pool, int k, int rrf_k, int tenant,
                         int mode, int cls_id, int sep_id, int L_pair, int64_t* ids_out, double* scores_out, float* logits_out,
                         int64_t* cand_out, hipStream_t st);
 
 static thread_local std::string g_null_err = "null handle";
+
+// name -> member of rag_options; the environment default of option <name> is RAG_<NAME>
+static const struct { const char* name; int rag_options::*field; } g_options[] = {
+    {"force_level", &rag_options::force_level},         {"stage_growth", &rag_options::stage_growth},
+    {"no_smallq", &rag_options::no_smallq},             {"no_second_pass", &rag_options::no_second_pass},
+    {"dense_linear_order", &rag_options::dense_linear_order},
+    {"bm25_first_ranges", &rag_options::bm25_first_ranges}, {"bm25_no_staging", &rag_options::bm25_no_staging},
+    {"no_fork", &rag_options::no_fork},                 {"ce_no_fused_ln", &rag_options::ce_no_fused_ln},
+    {"ce_no_fused_ffn", &rag_options::ce_no_fused_ffn}, {"ce_chunk_tokens", &rag_options::ce_chunk_tokens},
+};
+static void options_from_env(rag_options* o) {
+    for (const auto& e : g_options) {
+        std::string env = "RAG_";
+        for (const char* c = e.name; *c; ++c) env += (char)toupper(*c);
+        if (const char* v = getenv(env.c_str())) o->*(e.field) = atoi(v);
+    }
+}
 #define LOCK(h) std::lock_guard<std::mutex> lock_((h)->mu)
 
 extern "C" {
@@ -75,6 +97,7 @@ int rag_create(int device_id, int dim, rag_handle_t* out) {
     h->device = device_id;
     h->dim = dim;
     h->dim_pad = (int)round_up(dim, RAG_BK);
+    options_from_env(&h->opt);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return RAG_ERR_HIP;
@@ -116,6 +139,19 @@ int rag_synchronize(rag_handle_t h) {
     LOCK(h);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return RAG_OK;
+}
+
+int rag_set_option(rag_handle_t h, const char* name, int value) {
+    if (!h) return RAG_ERR_ARG;
+    LOCK(h);
+    ARG_CHECK(h, name != nullptr, "set_option: null name");
+    for (const auto& e : g_options)
+        if (strcmp(e.name, name) == 0) {
+            h->opt.*(e.field) = value;
+            return RAG_OK;
+        }
+    h->err = std::string("bad argument: unknown option ") + name;
+    return RAG_ERR_ARG;
 }
 
 int rag_set_profiling(rag_handle_t h, int enable) {
@@ -350,6 +386,24 @@ int rag_merge_topk_dev(rag_handle_t h, const int64_t* ids_dev, const double* sco
                       (hipStream_t)stream);
 }
 
+// The fuse step of the row-sharded hybrid search on every rank, after the ONE all-gather of the shards' lists.
+int rag_hybrid_fuse_gathered_dev(rag_handle_t h, const int64_t* gathered_dev, int world, int Q, int pool, int k, int rrf_k,
+                                 int64_t* lists_out_dev, double* scores_out_dev, int64_t* keys_out_dev, double* rrf_out_dev,
+                                 int32_t* ranks_out_dev, void* stream) {
+    if (!h) return RAG_ERR_ARG;
+    LOCK(h);
+    ARG_CHECK(h, gathered_dev && lists_out_dev && scores_out_dev && keys_out_dev && rrf_out_dev, "hybrid_fuse_gathered: null pointer");
+    ARG_CHECK(h, world > 0 && Q > 0 && pool > 0 && pool <= RAG_MAX_K && k > 0, "hybrid_fuse_gathered: bad sizes (0 < pool <= 256)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t P = (int64_t)Q * pool, stride = 4 * P;
+    const double* gs = reinterpret_cast<const double*>(gathered_dev);
+    int rc = merge_topk(h, gathered_dev, gs + P, world, stride, Q, pool, lists_out_dev, scores_out_dev, st, 0);
+    if (rc) return rc;
+    if ((rc = merge_topk(h, gathered_dev + 2 * P, gs + 3 * P, world, stride, Q, pool, lists_out_dev + P, scores_out_dev + P, st, 1))) return rc;
+    return rrf_fuse_dev(h, lists_out_dev, Q, 2, pool, P, pool, rrf_k, k, keys_out_dev, rrf_out_dev, ranks_out_dev, st);
+}
+
 int rag_pairwise_cosine_host(rag_handle_t h, const float* a, int m, const float* b, int n, int dim, double* out) {
     if (!h) return RAG_ERR_ARG;
     LOCK(h);
@@ -396,6 +450,11 @@ int rag_bm25_load_host(rag_handle_t h, const int64_t* indptr, const int32_t* doc
     LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return bm25_load_host(h, indptr, doc, tf, doc_len, idf, n_docs, n_terms, avgdl, k1, b);
+}
+
+int rag_bm25_index_bytes(const int64_t* indptr_host, int64_t n_docs, int64_t n_terms, int64_t* postings_bytes_out,
+                         int64_t* meta_bytes_out, int64_t* table_bytes_out) {
+    return bm25_index_bytes(indptr_host, n_docs, n_terms, postings_bytes_out, meta_bytes_out, table_bytes_out);
 }
 
 int rag_bm25_topk_host(rag_handle_t h, const int32_t* term_ptr, const int32_t* terms, int Q, int k, int tenant, int64_t* ids_out,
@@ -451,7 +510,10 @@ int rag_index_set_temporal_host(rag_handle_t h, const double* temporal, int64_t 
     HIP_TRY(h, hipSetDevice(h->device));
     hipFree(h->temporal);
     h->temporal = nullptr;
+    h->temporal_absmax = 0.0;
     if (temporal == nullptr || n_rows == 0) return RAG_OK;
+    for (int64_t i = 0; i < n_rows; ++i) h->temporal_absmax = std::max(h->temporal_absmax, std::fabs(temporal[i]));
+    ARG_CHECK(h, std::isfinite(h->temporal_absmax), "temporal scores must be finite");
     HIP_TRY(h, hipMalloc(&h->temporal, (size_t)n_rows * sizeof(double)));
     HIP_TRY(h, hipMemcpy(h->temporal, temporal, (size_t)n_rows * sizeof(double), hipMemcpyHostToDevice));
     return RAG_OK;
@@ -471,6 +533,8 @@ int rag_hybrid_linear_dev(rag_handle_t h, const float* q_dev, const int32_t* ter
     ARG_CHECK(h, q_dev && term_ptr_dev && ids_out_dev && rows_out_dev && hybrid_out_dev, "hybrid_linear: null pointer");
     ARG_CHECK(h, Q > 0 && k > 0 && k <= RAG_MAX_K, "hybrid_linear: need Q > 0 and 0 < k <= 256");
     ARG_CHECK(h, alpha > 0.0, "hybrid_linear: alpha must be positive (the cosine drives the candidate search)");
+    ARG_CHECK(h, std::isfinite(alpha) && std::isfinite(beta) && std::isfinite(gamma), "hybrid_linear: weights must be finite");
+    ARG_CHECK(h, tenant < 0 || h->tenants != nullptr, "hybrid_linear: tenant filter requested but no tenants loaded");
     ARG_CHECK(h, bm25_n_docs(h) == h->n_rows && h->n_rows > 0, "hybrid_linear: needs BM25 postings row-aligned with a non-empty index");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
@@ -494,7 +558,7 @@ int rag_hybrid_linear_dev(rag_handle_t h, const float* q_dev, const int32_t* ter
         const int qc = std::min(QB, Q - q0);
         int rc = bm25_scores_dev(h, term_ptr_dev + q0, terms_dev, qc, raw, st);
         if (rc) return rc;
-        if ((rc = linear_prepare(h, raw, qc, n, h->temporal, beta, gamma, mx, bias, ld, st))) return rc;
+        if ((rc = linear_prepare(h, raw, qc, n, h->temporal, beta, gamma, mx, bias, ld, tenant, st))) return rc;
         const dense_fused fz = {bias, ld, raw, n, mx, h->temporal, alpha, beta, gamma};
         rc = dense_search_fused(h, q_dev + (size_t)q0 * h->dim, qc, k, tenant, ids_out_dev + (size_t)q0 * k, rows_out_dev + (size_t)q0 * k,
                                 hybrid_out_dev + (size_t)q0 * k, st, &fz);
@@ -586,6 +650,20 @@ int rag_tokens_load_host(rag_handle_t h, const int32_t* tokens, const int32_t* l
     LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return tokens_load_host(h, tokens, lens, n_rows, L);
+}
+
+int rag_tokens_reserve(rag_handle_t h, int64_t n_rows_total, int L) {
+    if (!h) return RAG_ERR_ARG;
+    LOCK(h);
+    HIP_TRY(h, hipSetDevice(h->device));
+    return tokens_reserve(h, n_rows_total, L);
+}
+
+int rag_tokens_append_dev(rag_handle_t h, const int32_t* tokens_dev, const int32_t* lens_dev, int64_t n_rows, void* stream) {
+    if (!h) return RAG_ERR_ARG;
+    LOCK(h);
+    HIP_TRY(h, hipSetDevice(h->device));
+    return tokens_append_dev(h, tokens_dev, lens_dev, n_rows, (hipStream_t)stream);
 }
 
 int rag_retrieve_rerank_dev(rag_handle_t h, const float* q_emb_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev,

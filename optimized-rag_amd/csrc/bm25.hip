@@ -4,8 +4,14 @@
 // Integer/gather work, not a GEMM (89 % of the posting reads hit L2: frequent terms are shared by the batch's queries):
 //   load   : per-posting impact w = idf * tf*(k1+1) / (tf + k1*(1 - b + b*dl/avgdl)) precomputed once in float64 with
 //            rank-bm25's operation order -> postings are (doc int32, w float64): 12 B each, no doc_len gather, no multiply
-//            later. A per-term range table (first posting of each 2048-doc range, built once on the GPU) replaces the
-//            two 20-step dependent binary searches per (block, token) that dominated the first version (36 ms/batch).
+//            later. A per-term BRACKET table (first posting at every 2^shift-th document, built once on the GPU) replaces
+//            the two 20-step dependent binary searches per (block, token) that dominated the first version (36 ms/batch).
+//            The table is two-level in the vocabulary: a term's bracket width is the smallest power of two >= the
+//            2048-document range for which the table stays under df/4 entries, so long posting lists get the direct
+//            per-range row (zero search steps, as before), the middle of the distribution coarser rows (a 1-3 step
+//            search inside one bracket), and terms with fewer than 8 postings no row at all (a <= 3 step search of the
+//            whole list). Table bytes <= nnz bytes = 1/12 of the postings for ANY vocabulary (r2's dense
+//            V x n_ranges table was 122 GB for 5M terms on a 12.5M-document shard).
 //   score  : one 256-thread workgroup per (query, 2048-doc range). The range's float64 accumulators live in LDS (20.5 KiB
 //            with the scratch: SEVEN workgroups per CU, so one's posting round trips and token barriers hide behind the
 //            others' adds; hybrid batch of 1024 on one box: 16384 docs x 1024 threads = one workgroup per CU 132.8 k q/s,
@@ -37,13 +43,29 @@ typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
 #define BM_SC_DOUBLES (BM_RANGE + BM_RANGE / 32)
 #define BM_LDS_BYTES (BM_SC_DOUBLES * 8 + 4096)
 
+// everything a (workgroup, token) needs to know about the token's term: ONE 32-byte load
+struct __attribute__((aligned(32))) bm_term_meta {
+    int64_t post;       // first posting of the term (indptr[t])
+    int64_t tab;        // first entry of the term's bracket table in range_tab
+    double idf;
+    int32_t df;         // number of postings
+    int32_t shift;      // log2(documents per bracket); BM_NO_TAB: no table, the bracket is the whole list
+};
+#define BM_NO_TAB 63
+#define BM_TAB_DIV 4    // a term's table may take df / 4 entries (4 B each): table bytes <= nnz bytes = 1/12 of the postings
+#define BM_RANGE_LOG2 (31 - __builtin_clz(BM_RANGE))
+static_assert((BM_RANGE & (BM_RANGE - 1)) == 0, "BM_RANGE must be a power of two");
+
+struct bm_plan_meta;
 struct rag_bm25_index {
     int64_t n_docs = 0, n_terms = 0, nnz = 0;
     int64_t* indptr = nullptr;
     int32_t* doc = nullptr;
     double* w = nullptr;
     double* idf = nullptr;
-    int32_t* range_off = nullptr;      // [n_terms][n_ranges+1]: first posting of term t with doc >= r*BM_RANGE (rel. to indptr[t])
+    bm_term_meta* meta = nullptr;      // [n_terms]
+    int32_t* range_tab = nullptr;      // concatenated per-term tables: entry c = first posting (rel. to meta.post) with doc >= c << shift
+    int64_t tab_entries = 0;
     int n_ranges = 0;
     uint64_t* ws_key = nullptr;        // per-range partial top-k workspace for the device entry point
     uint32_t* ws_row = nullptr;
@@ -55,6 +77,10 @@ struct rag_bm25_index {
     uint64_t* ws_run_key = nullptr;    // [ws_run_n] running top-k of every query across the threshold stages
     uint32_t* ws_run_row = nullptr;
     size_t ws_run_n = 0;
+    int32_t* ws_plan_off = nullptr;    // per-call plan of the device entry points (bm25_plan_kernel), grown on demand
+    bm_plan_meta* ws_plan_meta = nullptr;
+    size_t ws_plan_entries = 0;
+    int ws_plan_q = 0;
     double avgdl = 0, k1 = 1.5, b = 0.75;
     int normalize = 1;                 // 0: top-k scores stay raw (row-sharded search divides by the GLOBAL max after the merge)
 };
@@ -91,39 +117,123 @@ __device__ __forceinline__ int64_t lower_bound_doc(const int32_t* __restrict__ d
     return lo;
 }
 
-__global__ void bm25_range_table_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ doc, int64_t n_terms,
-                                        int n_ranges, int32_t* __restrict__ range_off) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = n_terms * (int64_t)(n_ranges + 1);
-    if (i >= total) return;
-    const int64_t t = i / (n_ranges + 1);
-    const int r = (int)(i % (n_ranges + 1));
-    const int64_t lo = indptr[t], hi = indptr[t + 1];
-    const int64_t target = (int64_t)r * BM_RANGE;
-    range_off[i] = target > 0x7fffffff ? (int32_t)(hi - lo) : (int32_t)(lower_bound_doc(doc, lo, hi, (int)target) - lo);
+// Host-side plan of the bracket tables: shift and entry count per term (see the header comment). n_pad = documents rounded
+// up to a whole range; a table with shift g has ceil(n_pad / 2^g) + 1 entries (the last one = df).
+static inline int64_t bm_tab_entries(int64_t n_pad, int g) { return ((n_pad + ((int64_t)1 << g) - 1) >> g) + 1; }
+static inline int bm_plan_term(int64_t df, int64_t n_pad, int64_t* entries_out) {
+    const int64_t budget = df / BM_TAB_DIV;
+    int g = BM_RANGE_LOG2;
+    while (bm_tab_entries(n_pad, g) > budget && bm_tab_entries(n_pad, g) > 2) ++g;
+    const int64_t e = bm_tab_entries(n_pad, g);
+    if (e > budget || e <= 2) { *entries_out = 0; return BM_NO_TAB; }      // one bracket = the whole list: no table needed
+    *entries_out = e;
+    return g;
 }
 
+// one thread per table entry: term = last t whose table starts at or before entry i (terms without a table share their
+// start with the next term, so the LAST such t is the owner)
+__global__ void bm25_range_table_kernel(const bm_term_meta* __restrict__ meta, const int32_t* __restrict__ doc, int64_t n_terms,
+                                        int64_t n_entries, int32_t* __restrict__ range_tab) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_entries) return;
+    int64_t lo = 0, hi = n_terms;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (meta[mid].tab <= i) lo = mid; else hi = mid;
+    }
+    const bm_term_meta m = meta[lo];
+    const int64_t target = (i - m.tab) << m.shift;
+    range_tab[i] = target > 0x7fffffff ? m.df : (int32_t)(lower_bound_doc(doc, m.post, m.post + m.df, (int)target) - m.post);
+}
+
+// lower bound of `tg` in the ascending doc list dl[lo, hi): binary steps while the bracket is longer than 8 postings, then ONE
+// round trip: the (up to) 8 remaining doc ids come as two 16-byte loads and are counted (the arrays carry 8 postings of padding)
+__device__ __forceinline__ int bm_search(const int32_t* __restrict__ dl, int lo, int hi, int64_t tg) {
+    while (hi - lo > 8) {
+        const int mid = (lo + hi) >> 1;
+        if (dl[mid] < tg) lo = mid + 1; else hi = mid;
+    }
+    if (hi > lo) {
+        const int4u v0 = *reinterpret_cast<const int4u*>(dl + lo), v1 = *reinterpret_cast<const int4u*>(dl + lo + 4);
+        const int n = hi - lo;
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            c += (j < n) && (v0[j] < tg);
+            c += (j + 4 < n) && (v1[j] < tg);
+        }
+        lo += c;
+    }
+    return lo;
+}
+
+// bracket [lo, hi] of the term's table that holds lower_bound(tg); a target ON a bracket edge is the entry itself (always the
+// case for the direct per-range rows of long lists); no table: the whole list
+__device__ __forceinline__ void bm_bracket(const bm_term_meta& m, const int32_t* __restrict__ range_tab, int64_t tg, int& lo, int& hi) {
+    lo = 0;
+    hi = m.df;
+    if (m.shift != BM_NO_TAB) {
+        const int32_t* tb = range_tab + m.tab;
+        const int64_t c = tg >> m.shift;
+        lo = tb[c];
+        hi = (tg & (((int64_t)1 << m.shift) - 1)) ? tb[c + 1] : lo;
+    }
+}
+
+// ---- per-call PLAN: the posting offsets of every (query token, doc range) ------------------------------------------------
+// plan_off[q][slot][r] = first posting (relative to the term's list) with doc >= r * BM_RANGE, r = 0 .. n_ranges, for the first
+// BM_PLAN_T tokens of query q; plan_meta[q][slot] = the term's first posting and idf (idf 0: unknown token). One thread per
+// (query, range edge), looping over the query's tokens: bracket lookup + in-bracket search, all independent - the searches the
+// two-level table needs run here, massively parallel, instead of at the head of every scoring workgroup's dependent chain.
+// The scoring kernel then reads two adjacent plan entries per token, exactly as it read r2's dense per-term table.
+#define BM_PLAN_T 64
+struct __attribute__((aligned(16))) bm_plan_meta { int64_t post; double idf; };
+
+__global__ __launch_bounds__(256) void bm25_plan_kernel(const bm_term_meta* __restrict__ meta, const int32_t* __restrict__ doc,
+                                                         const int32_t* __restrict__ range_tab, int n_ranges, int64_t n_terms,
+                                                         const int32_t* __restrict__ term_ptr, const int32_t* __restrict__ terms,
+                                                         int32_t* __restrict__ plan_off, bm_plan_meta* __restrict__ plan_meta) {
+    const int q = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
+    const int t0 = term_ptr[q], nt = min(BM_PLAN_T, term_ptr[q + 1] - t0);
+    const int64_t tg = (int64_t)r * BM_RANGE;
+    for (int s = 0; s < nt; ++s) {
+        const int t = terms[t0 + s];
+        const bool ok = t >= 0 && t < n_terms;               // out-of-vocabulary token: idf.get(q) is None -> 0
+        bm_term_meta m = {0, 0, 0.0, 0, BM_NO_TAB};
+        if (ok) m = meta[t];
+        if (r == 0) plan_meta[(size_t)q * BM_PLAN_T + s] = {m.post, ok ? m.idf : 0.0};
+        if (r <= n_ranges) {
+            int lo, hi;
+            bm_bracket(m, range_tab, tg, lo, hi);
+            plan_off[((size_t)q * BM_PLAN_T + s) * (n_ranges + 1) + r] = bm_search(doc + m.post, lo, hi, tg);
+        }
+    }
+}
+
+// One workgroup per (query, doc range).
 // mode 0: per-range top-k partials; mode 1: dense scores out[q][doc]
-__global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ doc,
-                                                                 const double* __restrict__ w, const double* __restrict__ idf,
-                                                                 const int32_t* __restrict__ range_off, int n_ranges,
+__global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const bm_term_meta* __restrict__ meta, const int32_t* __restrict__ doc,
+                                                                 const double* __restrict__ w,
+                                                                 const int32_t* __restrict__ range_tab, int n_ranges,
                                                                  const int32_t* __restrict__ term_ptr, const int32_t* __restrict__ terms,
                                                                  int64_t n_docs, int64_t n_terms, int k, int mode,
                                                                  double* __restrict__ dense_out, uint64_t* __restrict__ part_key,
                                                                  uint32_t* __restrict__ part_row, int range_begin,
                                                                  const uint64_t* __restrict__ tau_key, int* __restrict__ part_cnt,
-                                                                 const int32_t* __restrict__ tenants, int tenant) {
+                                                                 const int32_t* __restrict__ tenants, int tenant,
+                                                                 const int32_t* __restrict__ plan_off, const bm_plan_meta* __restrict__ plan_meta) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int r = range_begin + blockIdx.x;
+    // the query's threshold (thresholded stages) is fetched up front: at the compaction step it would be an exposed global
+    // round trip for every workgroup
+    const uint64_t tk = tau_key != nullptr ? tau_key[blockIdx.y] : 0ull;
     double* sc = reinterpret_cast<double*>(smem);                       // [BM_RANGE]
     int* hist = reinterpret_cast<int*>(smem + BM_SC_DOUBLES * 8);       // [256]
     int* wsum = hist + 256;                                             // [16] scratch
-    const int q = blockIdx.y, r = range_begin + blockIdx.x, tid = threadIdx.x;
+    const int q = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int64_t base = (int64_t)r * BM_RANGE;
     const int lim = (int)min((int64_t)BM_RANGE, n_docs - base);
-    // the query's threshold (second-stage launches) is fetched up front: at the compaction step it would be an exposed
-    // global round trip for every workgroup
-    const uint64_t tk = tau_key != nullptr ? tau_key[q] : 0ull;
     for (int i = tid; i < BM_SC_DOUBLES; i += BM_THREADS) sc[i] = 0.0;
     __syncthreads();
     // per-token metadata (idf, posting sub-range of this doc range) is fetched for up to 64 tokens IN PARALLEL into
@@ -135,15 +245,29 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const int64_t* _
     for (int tb = t0; tb < t1; tb += 64) {
         const int nb = min(64, t1 - tb);
         if (tid < nb) {
-            const int t = terms[tb + tid];
             double f = 0.0;
             int64_t a = 0;
             int n = 0;
-            if (t >= 0 && t < n_terms) {                     // out-of-vocabulary token: idf.get(q) is None -> 0
-                f = idf[t];
-                const int32_t* ro = range_off + (size_t)t * (n_ranges + 1) + r;
-                a = indptr[t] + ro[0];
-                n = ro[1] - ro[0];
+            if (tb == t0) {                                  // planned tokens (BM_PLAN_T = one batch): two adjacent plan entries
+                const bm_plan_meta pm = plan_meta[(size_t)q * BM_PLAN_T + tid];
+                const int32_t* po = plan_off + ((size_t)q * BM_PLAN_T + tid) * (n_ranges + 1) + r;
+                const int o0 = po[0], o1 = po[1];
+                f = pm.idf;
+                a = pm.post + o0;
+                n = o1 - o0;
+            } else {                                         // tokens past the plan (a query of more than 64 tokens): search here
+                const int t = terms[tb + tid];
+                if (t >= 0 && t < n_terms) {
+                    const bm_term_meta m = meta[t];
+                    int lo0, hi0, lo1, hi1;
+                    bm_bracket(m, range_tab, base, lo0, hi0);
+                    bm_bracket(m, range_tab, base + BM_RANGE, lo1, hi1);
+                    const int s0 = bm_search(doc + m.post, lo0, hi0, base);
+                    const int e0 = bm_search(doc + m.post, max(lo1, s0), hi1, base + BM_RANGE);
+                    f = m.idf;
+                    a = m.post + s0;
+                    n = e0 - s0;
+                }
             }
             m_idf[tid] = f;
             m_a[tid] = a;
@@ -509,8 +633,11 @@ __global__ __launch_bounds__(256) void bm25_merge_stage_kernel(const uint64_t* _
 }
 
 // per-call device buffers of a top-k search: partial lists [Q][n_ranges][k], counts [Q][n_ranges], running list, threshold
+// + the per-call plan (see bm25_plan_kernel): plan.off [Q][BM_PLAN_T][n_ranges + 1] int32, plan.meta [Q][BM_PLAN_T]
+struct bm25_plan_ws { int32_t* off; bm_plan_meta* meta; };
 struct bm25_topk_ws {
     uint64_t* part_key; uint32_t* part_row; int* part_cnt; uint64_t* run_key; uint32_t* run_row; uint64_t* tau;
+    bm25_plan_ws plan;
 };
 struct bm25_topk_out {
     const int64_t* idmap; int64_t id_base; int64_t* ids; int32_t* rows; double* scores; double* raw_max; int normalize;
@@ -520,19 +647,27 @@ struct bm25_topk_out {
 // of the query gives tau (k-th best so far), and the next stage - up to BM_STAGE_GROWTH x the ranges seen so far - only
 // compacts keys >= tau. Expected survivors per stage ~ k * growth per query however large the shard is (a single
 // threshold from 32768 docs left ~k/2 per range: 38 k entries per query to merge on a 12.5M-doc shard).
-static void bm25_launch_topk(const rag_bm25_index* ix, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k,
+static size_t bm25_plan_off_entries(const rag_bm25_index* ix, int Q) { return (size_t)Q * BM_PLAN_T * (ix->n_ranges + 1); }
+static void bm25_launch_plan(const rag_bm25_index* ix, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, const bm25_plan_ws& p,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(bm25_plan_kernel, dim3((ix->n_ranges + 1 + 255) / 256, Q), dim3(256), 0, st, ix->meta, ix->doc, ix->range_tab,
+                       ix->n_ranges, ix->n_terms, term_ptr_dev, terms_dev, p.off, p.meta);
+}
+
+static void bm25_launch_topk(const rag_ctx* h, const rag_bm25_index* ix, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k,
                              const bm25_topk_ws& w, const bm25_topk_out& o, const int32_t* tenants, int tenant, hipStream_t st) {
     const int nr = ix->n_ranges;
-    static const int first_cfg = [] { const char* e = getenv("RAG_BM25_FIRST_RANGES"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 16 ? v : BM_FIRST_RANGES; }();
-    const bool staged = nr > 2 * first_cfg && !getenv("RAG_BM25_NO_STAGING");
+    bm25_launch_plan(ix, term_ptr_dev, terms_dev, Q, w.plan, st);
+    const int first_cfg = h->opt.bm25_first_ranges >= 1 && h->opt.bm25_first_ranges <= 16 ? h->opt.bm25_first_ranges : BM_FIRST_RANGES;
+    const bool staged = nr > 2 * first_cfg && !h->opt.bm25_no_staging;
     int begin = 0, stage = 0;
     while (begin < nr) {
         int end = !staged ? nr : (stage == 0 ? first_cfg : (int)std::min<int64_t>(nr, (int64_t)begin * BM_STAGE_GROWTH));
         if (staged && nr - end < end / 4) end = nr;                   // no tiny trailing stage
-        hipLaunchKernelGGL(bm25_range_kernel, dim3(end - begin, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc, ix->w,
-                           ix->idf, ix->range_off, nr, term_ptr_dev, terms_dev, ix->n_docs, ix->n_terms, k, 0, (double*)nullptr,
+        hipLaunchKernelGGL(bm25_range_kernel, dim3(end - begin, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->meta, ix->doc, ix->w,
+                           ix->range_tab, nr, term_ptr_dev, terms_dev, ix->n_docs, ix->n_terms, k, 0, (double*)nullptr,
                            w.part_key, w.part_row, begin, stage == 0 ? (const uint64_t*)nullptr : (const uint64_t*)w.tau, w.part_cnt,
-                           tenants, tenant);
+                           tenants, tenant, (const int32_t*)w.plan.off, (const bm_plan_meta*)w.plan.meta);
         const int last = end == nr;
         hipLaunchKernelGGL(bm25_merge_stage_kernel, dim3(Q), dim3(256), 0, st, w.part_key, w.part_row, w.part_cnt, nr, begin, end, k,
                            w.run_key, w.run_row, stage == 0 ? 1 : 0, w.tau, last, o.idmap, o.id_base, o.ids, o.rows, o.scores,
@@ -545,8 +680,9 @@ static void bm25_launch_topk(const rag_bm25_index* ix, const int32_t* term_ptr_d
 // ------------------------------------------------------------------------------------------------
 static void bm25_index_free(rag_bm25_index* ix) {
     if (!ix) return;
-    hipFree(ix->indptr); hipFree(ix->doc); hipFree(ix->w); hipFree(ix->idf); hipFree(ix->range_off);
+    hipFree(ix->indptr); hipFree(ix->doc); hipFree(ix->w); hipFree(ix->idf); hipFree(ix->meta); hipFree(ix->range_tab);
     hipFree(ix->ws_key); hipFree(ix->ws_row); hipFree(ix->ws_tau); hipFree(ix->ws_cnt); hipFree(ix->ws_run_key); hipFree(ix->ws_run_row);
+    hipFree(ix->ws_plan_off); hipFree(ix->ws_plan_meta);
     delete ix;
 }
 
@@ -568,21 +704,40 @@ static int bm25_build(rag_ctx* h, const int64_t* indptr, const int32_t* doc, con
     hipStream_t st = h->stream;
     int32_t *tfd = nullptr, *dld = nullptr;
     ix->n_ranges = (int)((n_docs + BM_RANGE - 1) / BM_RANGE);
-    const int64_t n_tab = n_terms * (int64_t)(ix->n_ranges + 1);
-    // + 4 postings of padding: the scoring kernel reads 4 consecutive postings per thread without a bounds branch
+    // per-term metadata + the plan of the bracket tables (host: one pass over indptr)
+    const int64_t n_pad = (int64_t)ix->n_ranges * BM_RANGE;
+    std::vector<bm_term_meta> meta_h((size_t)std::max<int64_t>(1, n_terms));
+    int64_t n_tab = 0;
+    for (int64_t t = 0; t < n_terms; ++t) {
+        const int64_t df = indptr[t + 1] - indptr[t];
+        if (df < 0 || df > n_docs) {
+            delete ix;
+            h->err = "bad argument: bm25_load: indptr must be non-decreasing with at most n_docs postings per term";
+            return RAG_ERR_ARG;
+        }
+        int64_t e_t = 0;
+        const int g = bm_plan_term(df, n_pad, &e_t);
+        meta_h[(size_t)t] = {indptr[t], n_tab, idf[t], (int32_t)df, g};
+        n_tab += e_t;
+    }
+    ix->tab_entries = n_tab;
+    // + 8 postings of padding: the scoring kernel reads 4 consecutive postings per thread, the bracket search 8 doc ids, without
+    // a bounds branch
     hipError_t e = hipMalloc(&ix->indptr, (size_t)(n_terms + 1) * sizeof(int64_t));
-    if (e == hipSuccess) e = hipMalloc(&ix->doc, (size_t)(nnz + 4) * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&ix->w, (size_t)(nnz + 4) * sizeof(double));
-    if (e == hipSuccess) e = hipMemsetAsync(ix->doc + nnz, 0, 4 * sizeof(int32_t), st);
-    if (e == hipSuccess) e = hipMemsetAsync(ix->w + nnz, 0, 4 * sizeof(double), st);
+    if (e == hipSuccess) e = hipMalloc(&ix->doc, (size_t)(nnz + 8) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&ix->w, (size_t)(nnz + 8) * sizeof(double));
+    if (e == hipSuccess) e = hipMemsetAsync(ix->doc + nnz, 0, 8 * sizeof(int32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(ix->w + nnz, 0, 8 * sizeof(double), st);
     if (e == hipSuccess) e = hipMalloc(&ix->idf, std::max<size_t>(1, n_terms) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&ix->meta, meta_h.size() * sizeof(bm_term_meta));
     if (e == hipSuccess) e = hipMalloc(&tfd, std::max<size_t>(1, nnz) * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc(&dld, (size_t)n_docs * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&ix->range_off, std::max<size_t>(1, (size_t)n_tab) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&ix->range_tab, std::max<size_t>(1, (size_t)n_tab) * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemcpyAsync(ix->indptr, indptr, (size_t)(n_terms + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess && nnz) e = hipMemcpyAsync(ix->doc, doc, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess && nnz) e = hipMemcpyAsync(tfd, tf, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess && n_terms) e = hipMemcpyAsync(ix->idf, idf, (size_t)n_terms * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_terms) e = hipMemcpyAsync(ix->meta, meta_h.data(), (size_t)n_terms * sizeof(bm_term_meta), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(dld, doc_len, (size_t)n_docs * sizeof(int32_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess && nnz) {
         hipLaunchKernelGGL(bm25_weights_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, ix->indptr, ix->doc, tfd,
@@ -590,12 +745,14 @@ static int bm25_build(rag_ctx* h, const int64_t* indptr, const int32_t* doc, con
         e = hipGetLastError();
     }
     if (e == hipSuccess && n_tab) {
-        hipLaunchKernelGGL(bm25_range_table_kernel, dim3((unsigned)((n_tab + 255) / 256)), dim3(256), 0, st, ix->indptr, ix->doc,
-                           n_terms, ix->n_ranges, ix->range_off);
+        hipLaunchKernelGGL(bm25_range_table_kernel, dim3((unsigned)((n_tab + 255) / 256)), dim3(256), 0, st, ix->meta, ix->doc,
+                           n_terms, n_tab, ix->range_tab);
         e = hipGetLastError();
     }
-    const hipError_t e2 = hipStreamSynchronize(st);
+    const hipError_t e2 = hipStreamSynchronize(st);               // (also keeps meta_h alive until its copy has been read)
     hipFree(tfd); hipFree(dld);
+    hipFree(ix->indptr); hipFree(ix->idf);                         // only the builders above read them: the metadata carries both
+    ix->indptr = nullptr; ix->idf = nullptr;
     if (e != hipSuccess || e2 != hipSuccess) {
         bm25_index_free(ix);
         h->err = std::string("bm25_load: ") + hipGetErrorString(e != hipSuccess ? e : e2);
@@ -652,7 +809,8 @@ static int bm25_run(rag_ctx* h, rag_bm25_index* ix, const int32_t* term_ptr, con
     const size_t n_dense = mode == 1 ? (size_t)Q * ix->n_docs : 0;
     size_t total = stage_size(Q + 1, 4) + stage_size(std::max(1, n_terms_q), 4) + stage_size(n_part, 8) + stage_size(n_part, 4) +
                    stage_size((size_t)Q * nr, 4) + 2 * stage_size(n_out, 8) + 2 * stage_size(n_out, 4) + 2 * stage_size(Q, 8) +
-                   stage_size(n_out, 8) + stage_size(n_dense, 8);
+                   stage_size(n_out, 8) + stage_size(n_dense, 8) + stage_size(bm25_plan_off_entries(ix, Q), 4) +
+                   stage_size((size_t)Q * BM_PLAN_T, sizeof(bm_plan_meta));
     if ((rc = stage_reserve(h, total))) return rc;
     char* p = (char*)h->stage;
     int32_t* tp = stage_take<int32_t>(p, Q + 1);
@@ -669,26 +827,49 @@ static int bm25_run(rag_ctx* h, rag_bm25_index* ix, const int32_t* term_ptr, con
     double* mxd = stage_take<double>(p, Q);
     double* scd = stage_take<double>(p, n_out);
     double* dd = stage_take<double>(p, n_dense);
+    w.plan.off = stage_take<int32_t>(p, bm25_plan_off_entries(ix, Q));
+    w.plan.meta = stage_take<bm_plan_meta>(p, (size_t)Q * BM_PLAN_T);
     HIP_TRY(h, hipMemcpyAsync(tp, term_ptr, (size_t)(Q + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
     if (n_terms_q) HIP_TRY(h, hipMemcpyAsync(tm, terms, (size_t)n_terms_q * sizeof(int32_t), hipMemcpyHostToDevice, st));
     if (mode == 0) {
         const bool aligned = ix == h->bm25 && h->n_rows == ix->n_docs;
         const bm25_topk_out o = {aligned ? h->ids : (const int64_t*)nullptr, aligned ? h->id_base : (int64_t)0, idd, rwd, scd, mxd,
                                  ix->normalize};
-        bm25_launch_topk(ix, tp, tm, Q, k, w, o, tenants, tenant, st);
+        bm25_launch_topk(h, ix, tp, tm, Q, k, w, o, tenants, tenant, st);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipMemcpyAsync(ids_out, idd, n_out * sizeof(int64_t), hipMemcpyDeviceToHost, st));
         if (rows_out) HIP_TRY(h, hipMemcpyAsync(rows_out, rwd, n_out * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(h, hipMemcpyAsync(scores_out, scd, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
         if (raw_max_out) HIP_TRY(h, hipMemcpyAsync(raw_max_out, mxd, (size_t)Q * sizeof(double), hipMemcpyDeviceToHost, st));
     } else {
-        hipLaunchKernelGGL(bm25_range_kernel, dim3(nr, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc, ix->w, ix->idf,
-                           ix->range_off, nr, tp, tm, ix->n_docs, ix->n_terms, k, 1, dd, (uint64_t*)nullptr, (uint32_t*)nullptr, 0,
-                           (const uint64_t*)nullptr, (int*)nullptr, (const int32_t*)nullptr, -1);
+        bm25_launch_plan(ix, tp, tm, Q, w.plan, st);
+        hipLaunchKernelGGL(bm25_range_kernel, dim3(nr, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->meta, ix->doc, ix->w,
+                           ix->range_tab, nr, tp, tm, ix->n_docs, ix->n_terms, k, 1, dd, (uint64_t*)nullptr, (uint32_t*)nullptr, 0,
+                           (const uint64_t*)nullptr, (int*)nullptr, (const int32_t*)nullptr, -1, (const int32_t*)w.plan.off,
+                           (const bm_plan_meta*)w.plan.meta);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipMemcpyAsync(dense_out, dd, n_dense * sizeof(double), hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(h, hipStreamSynchronize(st));
+    return RAG_OK;
+}
+
+static int bm25_ensure_plan(rag_ctx* h, rag_bm25_index* ix, int Q) {
+    const size_t need = bm25_plan_off_entries(ix, Q);
+    if (need > ix->ws_plan_entries) {
+        hipFree(ix->ws_plan_off);
+        ix->ws_plan_off = nullptr;
+        ix->ws_plan_entries = 0;
+        HIP_TRY(h, hipMalloc(&ix->ws_plan_off, need * sizeof(int32_t)));
+        ix->ws_plan_entries = need;
+    }
+    if (Q > ix->ws_plan_q) {
+        hipFree(ix->ws_plan_meta);
+        ix->ws_plan_meta = nullptr;
+        ix->ws_plan_q = 0;
+        HIP_TRY(h, hipMalloc(&ix->ws_plan_meta, (size_t)Q * BM_PLAN_T * sizeof(bm_plan_meta)));
+        ix->ws_plan_q = Q;
+    }
     return RAG_OK;
 }
 
@@ -734,13 +915,14 @@ int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_
         HIP_TRY(h, hipMalloc(&ix->ws_run_row, need_run * sizeof(uint32_t)));
         ix->ws_run_n = need_run;
     }
+    if ((rc = bm25_ensure_plan(h, ix, Q))) return rc;
     // doc ids follow the dense index's mapping when both indexes cover the same rows (hybrid fusion needs one id space)
     const bool aligned = h->n_rows == ix->n_docs;
-    const bm25_topk_ws w = {ix->ws_key, ix->ws_row, ix->ws_cnt, ix->ws_run_key, ix->ws_run_row, ix->ws_tau};
+    const bm25_topk_ws w = {ix->ws_key, ix->ws_row, ix->ws_cnt, ix->ws_run_key, ix->ws_run_row, ix->ws_tau, {ix->ws_plan_off, ix->ws_plan_meta}};
     const bm25_topk_out o = {aligned ? h->ids : (const int64_t*)nullptr, aligned ? h->id_base : (int64_t)0, ids_dev, rows_dev, scores_dev,
                              raw_max_dev, ix->normalize};
     if ((rc = prof_begin(h, 1, st))) return rc;
-    bm25_launch_topk(ix, term_ptr_dev, terms_dev, Q, k, w, o, tenants, tenant, st);
+    bm25_launch_topk(h, ix, term_ptr_dev, terms_dev, Q, k, w, o, tenants, tenant, st);
     HIP_TRY(h, hipGetLastError());
     return prof_end(h, 1, st);
 }
@@ -751,11 +933,15 @@ int bm25_scores_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* term
     ARG_CHECK(h, h->bm25 != nullptr, "no BM25 index loaded");
     ARG_CHECK(h, Q > 0 && Q <= 65535 && term_ptr_dev && out_dev, "bm25_scores_dev: bad arguments");
     rag_bm25_index* ix = h->bm25;
-    const int rc = bm25_set_attr(h);
+    int rc = bm25_set_attr(h);
     if (rc) return rc;
-    hipLaunchKernelGGL(bm25_range_kernel, dim3(ix->n_ranges, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->indptr, ix->doc, ix->w, ix->idf,
-                       ix->range_off, ix->n_ranges, term_ptr_dev, terms_dev, ix->n_docs, ix->n_terms, 1, 1, out_dev, (uint64_t*)nullptr,
-                       (uint32_t*)nullptr, 0, (const uint64_t*)nullptr, (int*)nullptr, (const int32_t*)nullptr, -1);
+    if ((rc = bm25_ensure_plan(h, ix, Q))) return rc;
+    const bm25_plan_ws pw = {ix->ws_plan_off, ix->ws_plan_meta};
+    bm25_launch_plan(ix, term_ptr_dev, terms_dev, Q, pw, st);
+    hipLaunchKernelGGL(bm25_range_kernel, dim3(ix->n_ranges, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->meta, ix->doc, ix->w,
+                       ix->range_tab, ix->n_ranges, term_ptr_dev, terms_dev, ix->n_docs, ix->n_terms, 1, 1, out_dev, (uint64_t*)nullptr,
+                       (uint32_t*)nullptr, 0, (const uint64_t*)nullptr, (int*)nullptr, (const int32_t*)nullptr, -1,
+                       (const int32_t*)pw.off, (const bm_plan_meta*)pw.meta);
     HIP_TRY(h, hipGetLastError());
     return RAG_OK;
 }
@@ -767,6 +953,25 @@ int bm25_set_normalize(rag_ctx* h, int on) {
 }
 
 int64_t bm25_n_docs(const rag_ctx* h) { return h->bm25 ? h->bm25->n_docs : -1; }
+
+// HBM bytes of an index built from these postings, from the host CSR offsets alone (no device call): postings (doc + impact,
+// 12 B each), per-term metadata (32 B each) and the bracket tables (4 B per entry, <= nnz bytes by construction).
+int bm25_index_bytes(const int64_t* indptr, int64_t n_docs, int64_t n_terms, int64_t* postings_out, int64_t* meta_out, int64_t* table_out) {
+    if (!indptr || n_docs <= 0 || n_terms < 0) return RAG_ERR_ARG;
+    const int64_t n_pad = (n_docs + BM_RANGE - 1) / BM_RANGE * BM_RANGE;
+    int64_t n_tab = 0;
+    for (int64_t t = 0; t < n_terms; ++t) {
+        const int64_t df = indptr[t + 1] - indptr[t];
+        if (df < 0) return RAG_ERR_ARG;
+        int64_t e_t = 0;
+        bm_plan_term(df, n_pad, &e_t);
+        n_tab += e_t;
+    }
+    if (postings_out) *postings_out = ((n_terms ? indptr[n_terms] - indptr[0] : 0) + 8) * 12;
+    if (meta_out) *meta_out = n_terms * (int64_t)sizeof(bm_term_meta);
+    if (table_out) *table_out = n_tab * 4;
+    return RAG_OK;
+}
 
 int bm25_topk_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, int k, int tenant, int64_t* ids_out,
                    int32_t* rows_out, double* scores_out, double* raw_max_out) {

@@ -27,6 +27,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct rag_ce_model;             // cross_encoder.hip
 struct rag_bm25_index;           // bm25.hip
 
+// Diagnostic / tuning switches of one handle. The defaults come from the environment (RAG_<NAME>) ONCE, in rag_create;
+// rag_set_option(h, "<name>", value) changes them afterwards (tests flip them between calls on one handle). Nothing on a
+// search path calls getenv.
+struct rag_options {
+    int force_level = 0;          // 1 / 2: every dense query through the wide ranking / the float64 exact scan
+    int stage_growth = 0;         // dense stage growth (0 = the built-in schedule)
+    int no_smallq = 0;            // disable the small-batch dense kernel variant
+    int no_second_pass = 0;       // overflowed dense queries go straight to the float64 scan
+    int dense_linear_order = 0;   // walk the tiles in table order (r1 behaviour, for A/B)
+    int bm25_first_ranges = 0;    // exact first-stage BM25 ranges (0 = BM_FIRST_RANGES)
+    int bm25_no_staging = 0;      // exact per-range select for every BM25 range
+    int no_fork = 0;              // keep the BM25 leg of a small hybrid batch in line on the caller's stream
+    int ce_no_fused_ln = 0;       // unfused residual + LayerNorm path of the cross-encoder
+    int ce_no_fused_ffn = 0;      // FFN as two GEMM launches (up-projection, then the fused-LN down-projection)
+    int ce_chunk_tokens = 0;      // activation chunk size in tokens (0 = sized from the model)
+};
+
 struct rag_ctx {
     int device = 0;
     int dim = 0;
@@ -37,6 +54,7 @@ struct rag_ctx {
     double* side_scores = nullptr;           // [side_scores_n] score scratch of that leg
     size_t side_scores_n = 0;
     std::string err;
+    rag_options opt;
     bool profiling = false;
     void* comm = nullptr;                    // ncclComm_t of comm.hip (RCCL, opened with dlopen), or null
     int comm_rank = 0, comm_world = 1;
@@ -50,6 +68,7 @@ struct rag_ctx {
     int64_t* ids = nullptr;      // [n_rows] or null
     int32_t* tenants = nullptr;  // [n_rows] or null
     double* temporal = nullptr;                                        // [n_rows] per-row temporal score (linear fusion) or null
+    double temporal_absmax = 0.0;                                      // max |temporal[i]| (sizes the fused emission margin)
     void* lin_ws = nullptr;                                            // rag_hybrid_linear_dev: raw BM25 + bias + max of one sub-batch
     size_t lin_ws_bytes = 0;
     int32_t* tenant_tiles = nullptr;                                   // concatenated per-tenant lists of 256-row tiles
@@ -102,7 +121,8 @@ struct rag_ctx {
     // passage token store (pipeline.hip): [tok_rows][tok_L] uint16 WordPiece ids + lengths, row-aligned with the index
     uint16_t* tok = nullptr;
     int32_t* tok_len = nullptr;
-    int64_t tok_rows = 0;
+    int64_t tok_rows = 0, tok_cap = 0;       // rows loaded / rows reserved (rag_tokens_reserve + rag_tokens_append_dev)
+    int* tok_bad = nullptr;                  // device counter of out-of-range token ids seen by the appends
     int tok_L = 0;
     void* pipe_ws = nullptr;
     size_t pipe_ws_bytes = 0;
@@ -212,12 +232,12 @@ void comm_free(rag_ctx* h);
 int hybrid_legs(rag_ctx* h, const float* q_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int pool, int tenant,
                 int64_t* lists_dev, double* scores_ws_dev, hipStream_t st);
 int linear_prepare(rag_ctx* h, const double* raw, int Q, int64_t n, const double* temporal, double beta, double gamma, double* mx,
-                   float* bias, int64_t ld, hipStream_t st);
+                   float* bias, int64_t ld, int tenant, hipStream_t st);
 int linear_components(rag_ctx* h, const float* q_dev, const int32_t* rows_dev, int Q, int k, const dense_fused* fz, double* sem_out,
                       double* kw_out, double* tmp_out, hipStream_t st);
 int dense_free(rag_ctx* h);
 int dense_build_tenant_tiles(rag_ctx* h, const int32_t* tenants_host, int64_t n_rows);
 int merge_topk(rag_ctx* h, const int64_t* ids, const double* scores, int n_lists, int64_t list_stride, int Q, int k,
-               int64_t* ids_out, double* scores_out, hipStream_t st);
+               int64_t* ids_out, double* scores_out, hipStream_t st, int normalize = 0);
 int pairwise_cosine(rag_ctx* h, const float* a_dev, int m, const float* b_dev, int n, int dim, double* out_dev,
                     hipStream_t st);

@@ -1061,12 +1061,20 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     const size_t lds = CE_GEMM_LDS;
     if (!attr) {
 #define CE_ATTR(E, T) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_kernel<E, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#ifdef RAG_CE_ABLATION
 #define CE_ATTR4(E) CE_ATTR(E, 0) CE_ATTR(E, 1) CE_ATTR(E, 2) CE_ATTR(E, 3)
+#else
+#define CE_ATTR4(E) CE_ATTR(E, 3)
+#endif
         CE_ATTR4(EPI_QKV) CE_ATTR4(EPI_GELU) CE_ATTR4(EPI_RESID)
         attr = true;
     }
-    // correction terms per GEMM site (qkv, out-proj, ffn-up, ffn-down), each 0..3; RAG_CE_TERMS="3333" is the default
+    // Correction terms per GEMM site (qkv, out-proj, ffn-up, ffn-down). The product library ships ONLY the full form (both
+    // terms everywhere: profiles/r02_b shows that dropping any one of them spends the whole logit-error budget). The reduced
+    // instances and the RAG_CE_TERMS switch exist only in diagnostic builds (-DRAG_CE_ABLATION, tools/ce_probe_build.sh),
+    // loaded through RAG_HIP_LIB by tools/ce_ablation.py.
     int terms[4] = {3, 3, 3, 3};
+#ifdef RAG_CE_ABLATION
     if (const char* te = getenv("RAG_CE_TERMS"))
         for (int i = 0; i < 4 && te[i] >= '0' && te[i] <= '3'; ++i) terms[i] = te[i] - '0';
 #define CE_GEMM(E, T, ...)                                                                                        \
@@ -1076,15 +1084,23 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
         case 2: hipLaunchKernelGGL((ce_gemm_kernel<E, 2>), dim3(n_cu), blk, lds, st, __VA_ARGS__); break;        \
         default: hipLaunchKernelGGL((ce_gemm_kernel<E, 3>), dim3(n_cu), blk, lds, st, __VA_ARGS__); break;       \
     }
+#else
+#define CE_GEMM(E, T, ...) hipLaunchKernelGGL((ce_gemm_kernel<E, 3>), dim3(n_cu), blk, lds, st, __VA_ARGS__);
+#endif
+    (void)terms;
  // bias + residual + LayerNorm in the GEMM epilogue when the geometry allows (hidden = 384, K a multiple of 192: the
     // MiniLM-L-6 shape); RAG_CE_NO_FUSED_LN=1 forces the stand-alone path (parity test of both)
-    const bool fused_ln = H == 384 && F % 192 == 0 && !getenv("RAG_CE_NO_FUSED_LN");
+    const bool fused_ln = H == 384 && F % 192 == 0 && !h->opt.ce_no_fused_ln;
     if (!fused_ln && !m->y32) HIP_TRY(h, hipMalloc(&m->y32, (size_t)Mp * H * 4));
     if (fused_ln && !h->attr_ce_gemm_ln) {
 #define CE_ATTR_LN(T) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_ln_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LNG_LDS));
-        CE_ATTR_LN(0) CE_ATTR_LN(1) CE_ATTR_LN(2) CE_ATTR_LN(3)
+#ifdef RAG_CE_ABLATION
+        CE_ATTR_LN(0) CE_ATTR_LN(1) CE_ATTR_LN(2)
+#endif
+        CE_ATTR_LN(3)
         h->attr_ce_gemm_ln = true;
     }
+#ifdef RAG_CE_ABLATION
 #define CE_GEMM_LN(T, ...)                                                                                        \
     switch (T) {                                                                                                  \
         case 0: hipLaunchKernelGGL((ce_gemm_ln_kernel<0>), dim3(n_cu), blk, LNG_LDS, st, __VA_ARGS__); break;    \
@@ -1092,6 +1108,9 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
         case 2: hipLaunchKernelGGL((ce_gemm_ln_kernel<2>), dim3(n_cu), blk, LNG_LDS, st, __VA_ARGS__); break;    \
         default: hipLaunchKernelGGL((ce_gemm_ln_kernel<3>), dim3(n_cu), blk, LNG_LDS, st, __VA_ARGS__); break;   \
     }
+#else
+#define CE_GEMM_LN(T, ...) hipLaunchKernelGGL((ce_gemm_ln_kernel<3>), dim3(n_cu), blk, LNG_LDS, st, __VA_ARGS__);
+#endif
 #define CE_PER_DISPATCH(CALL)                                                                 \
     switch (per) {                                                                            \
         case 2: CALL(2); break; case 4: CALL(4); break; case 6: CALL(6); break;               \
@@ -1198,10 +1217,9 @@ int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* l
     ARG_CHECK(h, L_in <= m->cfg.max_pos && L_in <= 512, "ce_score: sequence longer than max_position_embeddings/512");
     int L = 0;
     for (int c : kAttnL) if (c >= L_in) { L = c; break; }
-    // ~2M tokens of activations per chunk (~30 GB). RAG_CE_CHUNK_TOKENS (diagnostic) shrinks it so that parity tests can run
+    // ~2M tokens of activations per chunk (~30 GB). Option ce_chunk_tokens (diagnostic) shrinks it so that parity tests can run
     // the multi-chunk loop on small inputs.
-    const char* ct = getenv("RAG_CE_CHUNK_TOKENS");
-    const int64_t chunk_tokens = ct && atoll(ct) >= 32 ? atoll(ct) : 2'000'000;
+    const int64_t chunk_tokens = h->opt.ce_chunk_tokens >= 32 ? h->opt.ce_chunk_tokens : 2'000'000;
     const int chunk = std::max(1, std::min(P, (int)(chunk_tokens / L)));
     int rc = ce_ensure_ws(h, m, chunk, L, st);
     if (rc) return rc;

@@ -681,7 +681,9 @@ __device__ __forceinline__ void bitonic_sort_pairs(uint64_t* k1, uint32_t* k2, i
     }
 }
 
-// queries with flag == want -> list (in query order is not required), count. One workgroup.
+// queries with flag == want -> list (in query order is not required), count. One workgroup. Slots [count, cap) are set to
+// query 0: the list is read as a query MAP by the fused re-emission (bias row of slot f), and a dead slot (threshold +inf, never
+// emits) must still index inside the bias buffer - a stale entry of an earlier, larger batch would not.
 __global__ __launch_bounds__(256) void flag_list_kernel(const int* __restrict__ flag, const float* __restrict__ bound, int Q,
                                                          int want, int cap, int* __restrict__ list, int* __restrict__ count) {
     __shared__ int n;
@@ -695,6 +697,7 @@ __global__ __launch_bounds__(256) void flag_list_kernel(const int* __restrict__ 
         }
     }
     __syncthreads();
+    for (int o = min(n, cap) + threadIdx.x; o < cap; o += 256) list[o] = 0;
     if (threadIdx.x == 0) *count = min(n, cap);
 }
 
@@ -830,11 +833,15 @@ __global__ __launch_bounds__(256) void overflow_scatter_kernel(const int* __rest
 // rag/retrieval.py:294-322 evaluated over ALL rows: hybrid = (alpha * cosine + beta * keyword) + gamma * temporal, keyword =
 // raw BM25 / max over the corpus (1.0 when that max is <= 0), stable sort descending, [:top_k].
 // raw[Q][N] are the float64 BM25 scores of every document (bm25_range_kernel, mode 1).
-__global__ __launch_bounds__(256) void linear_max_kernel(const double* __restrict__ raw, int64_t n, double* __restrict__ mx) {
+// Under a tenant filter the corpus hybrid_search was handed is the tenant's own documents (`WHERE agent_id = %s`,
+// rag/document_store.py:457), so the max is taken over the tenant's rows only - as rag_bm25_topk_* do.
+__global__ __launch_bounds__(256) void linear_max_kernel(const double* __restrict__ raw, int64_t n, double* __restrict__ mx,
+                                                          const int32_t* __restrict__ tenants, int tenant) {
     __shared__ double part[4];
     const double* r = raw + (size_t)blockIdx.x * n;
     double m = -INFINITY;
-    for (int64_t i = threadIdx.x; i < n; i += 256) m = fmax(m, r[i]);
+    for (int64_t i = threadIdx.x; i < n; i += 256)
+        if (tenants == nullptr || tenants[i] == tenant) m = fmax(m, r[i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
@@ -940,6 +947,7 @@ static int ensure_workspace(rag_ctx* h, int Q, hipStream_t st) {
         HIP_TRY(h, hipMalloc(&h->boundb, RAG_TILE * sizeof(float)));
         HIP_TRY(h, hipMalloc(&h->n_sortedb, RAG_TILE * sizeof(int)));
         HIP_TRY(h, hipMalloc(&h->ovf_list, (RAG_TILE + 1) * sizeof(int)));
+        HIP_TRY(h, hipMemsetAsync(h->ovf_list, 0, (RAG_TILE + 1) * sizeof(int), st));
         HIP_TRY(h, hipMemsetAsync(h->q16b, 0, (size_t)RAG_TILE * h->dim_pad * sizeof(half_t), st));
     }
     h->ws_q = Q;
@@ -1047,8 +1055,13 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
     int rc = ensure_workspace(h, Q, st);
     if (rc) return rc;
     const int32_t* tenants = tenant >= 0 ? h->tenants : nullptr;
-    // fused: |alpha| * (fp16-pass error of the cosine) + float32 rounding of the bias and of the fma (values are O(1))
-    const double eps = fz ? fabs(fz->alpha) * fp16_pass_eps(h->dim_pad) + 4e-7 : fp16_pass_eps(h->dim_pad);
+    // fused: |alpha| * (fp16-pass error of the cosine) + the float32 roundings of the emitted score alpha_f * S + bias:
+    // bias = float(beta * kw + gamma * t) (2^-24 relative), alpha_f = float(alpha) (2^-24 |alpha| |S|), the fma's own rounding
+    // (2^-24 of the result) - together <= 2^-23 * (|alpha| + |beta| * max|kw| + |gamma| * max|t|). The keyword score is
+    // raw / max (in [0, 1] whenever the max is positive; the raw scores themselves, all <= 0, in the `else 1.0` case of
+    // rag/retrieval.py:344, where 8 covers any realistic BM25 magnitude); max|t| is tracked by rag_index_set_temporal_host.
+    const double f32_mag = fz ? fabs(fz->alpha) + 8.0 * fabs(fz->beta) + fabs(fz->gamma) * h->temporal_absmax : 0.0;
+    const double eps = fz ? fabs(fz->alpha) * fp16_pass_eps(h->dim_pad) + f32_mag / 8388608.0 + 1e-7 : fp16_pass_eps(h->dim_pad);
     const float two_eps = (float)(2.0 * eps * 1.0001 + 1e-7);        // float subtraction in the select kernel: round up
     const float* bias = fz ? fz->bias : nullptr;
     const int64_t bias_ld = fz ? fz->bias_ld : 0;
@@ -1056,8 +1069,7 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
     const int qpad = (int)round_up(Q, RAG_TILE);
     const int n_qtiles = qpad / RAG_TILE;
     float* tau = h->tau;
-    const char* fl = getenv("RAG_FORCE_LEVEL");
-    const int force_level = fl ? atoi(fl) : 0;
+    const int force_level = h->opt.force_level;
 
     // queries -> fp16 unit rows (pad rows of q16 stay zero from allocation time / previous larger batch)
     // only rows a previous, larger batch wrote can be non-zero: same-size batches (the agent's one query after another) clear nothing
@@ -1103,16 +1115,15 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
     }
     const int n_tiles = total_tiles;
     // RAG_DENSE_LINEAR_ORDER=1 (diagnostic): r1's table order, to price the permutation on one box
-    const int tile_mul = getenv("RAG_DENSE_LINEAR_ORDER") ? 1 : tile_multiplier(n_tiles), tile_mod = std::max(1, n_tiles);
-    const bool smallq = Q <= 128 && !getenv("RAG_NO_SMALLQ");
+    const int tile_mul = h->opt.dense_linear_order ? 1 : tile_multiplier(n_tiles), tile_mod = std::max(1, n_tiles);
+    const bool smallq = Q <= 128 && !h->opt.no_smallq;
 
     // ---- stage schedule over tile POSITIONS: 8 tiles (2048 rows) scored densely, then ~8x growth each. The expected
     // emission of a stage is ~k x growth keys per query (tau = k-th best of everything seen so far), so the growth is
     // capped by k: it must stay well inside the 4096-entry buffer (r1 used 32x for small batches at any k; at k = 100
     // that sat at the edge of the buffer and a single query could fall into the exact scan).
     const int stage0_tiles = std::min(n_tiles, RAG_STAGE0_ROWS / RAG_TILE);
-    const char* growth_s = getenv("RAG_STAGE_GROWTH");                 // diagnostic: read per call so tests can set it
-    const int growth_env = growth_s && atoi(growth_s) >= 2 ? atoi(growth_s) : 0;
+    const int growth_env = h->opt.stage_growth >= 2 ? h->opt.stage_growth : 0;       // diagnostic (rag_set_option)
     const int growth = growth_env ? growth_env
                                   : std::max(3, std::min(Q <= 64 ? 4 * RAG_STAGE_GROWTH : RAG_STAGE_GROWTH, (Q <= 64 ? 1024 : 1536) / k));
     int begin = 0, stage = 0;
@@ -1167,7 +1178,7 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
     }
 
     // ---- second pass for overflowed queries (device-side early exit when there are none) ---------------------------
-    if (total_tiles > 0 && !getenv("RAG_NO_SECOND_PASS")) {
+    if (total_tiles > 0 && !h->opt.no_second_pass) {
         int* ovf_count = h->ovf_list + RAG_TILE;
         hipLaunchKernelGGL(flag_list_kernel, dim3(1), dim3(256), 0, st, (const int*)nullptr, h->bound, Q, 0, RAG_TILE, h->ovf_list, ovf_count);
         hipLaunchKernelGGL(overflow_gather_kernel, dim3(RAG_TILE), dim3(256), 0, st, h->ovf_list, ovf_count, h->q16, tau, h->dim_pad,
@@ -1240,8 +1251,8 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
 
 // bias / max / components of the linear fusion (called by rag_hybrid_linear_dev around dense_search_fused)
 int linear_prepare(rag_ctx* h, const double* raw, int Q, int64_t n, const double* temporal, double beta, double gamma, double* mx,
-                   float* bias, int64_t ld, hipStream_t st) {
-    hipLaunchKernelGGL(linear_max_kernel, dim3(Q), dim3(256), 0, st, raw, n, mx);
+                   float* bias, int64_t ld, int tenant, hipStream_t st) {
+    hipLaunchKernelGGL(linear_max_kernel, dim3(Q), dim3(256), 0, st, raw, n, mx, tenant >= 0 ? (const int32_t*)h->tenants : (const int32_t*)nullptr, tenant);
     hipLaunchKernelGGL(linear_bias_kernel, dim3((unsigned)((ld + 255) / 256), Q), dim3(256), 0, st, raw, mx, temporal, n, ld, beta, gamma, bias);
     HIP_TRY(h, hipGetLastError());
     return RAG_OK;
@@ -1258,24 +1269,34 @@ int linear_components(rag_ctx* h, const float* q_dev, const int32_t* rows_dev, i
 // ------------------------------------------------------------------------------------------------
 // merge of per-shard partial lists (multi-GPU exchange step): [L][Q][k] -> [Q][k], score desc, id asc
 // ------------------------------------------------------------------------------------------------
+// normalize != 0: the merged scores are divided by the largest one when it is positive (else by 1.0) - rag/retrieval.py:343-345
+// with the GLOBAL maximum, for the shards' raw BM25 lists (the head of the merged list is that maximum).
 __global__ __launch_bounds__(256) void merge_topk_kernel(const int64_t* __restrict__ ids, const double* __restrict__ scores,
                                                           int n_lists, int64_t list_stride, int Q, int k,
-                                                          int64_t* __restrict__ ids_out, double* __restrict__ scores_out) {
+                                                          int64_t* __restrict__ ids_out, double* __restrict__ scores_out, int normalize) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double wmax[4];
     const int total = n_lists * k;
     double* sc = reinterpret_cast<double*>(smem);
     int64_t* id = reinterpret_cast<int64_t*>(smem + (size_t)total * 8);
     const int q = blockIdx.x, tid = threadIdx.x;
+    double mx = -INFINITY;
     for (int i = tid; i < total; i += 256) {
         const int l = i / k, j = i % k;
         sc[i] = scores[(size_t)l * list_stride + (size_t)q * k + j];
         id[i] = ids[(size_t)l * list_stride + (size_t)q * k + j];
+        if (id[i] >= 0) mx = fmax(mx, sc[i]);
     }
     for (int i = tid; i < k; i += 256) {
         ids_out[(size_t)q * k + i] = -1;
         scores_out[(size_t)q * k + i] = 0.0;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) wmax[tid >> 6] = mx;
     __syncthreads();
+    mx = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+    const double div = normalize && mx > 0.0 ? mx : 1.0;
     for (int i = tid; i < total; i += 256) {
         const int64_t me = id[i];
         if (me < 0) continue;
@@ -1287,19 +1308,19 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const int64_t* __restri
         }
         if (rank < k) {
             ids_out[(size_t)q * k + rank] = me;
-            scores_out[(size_t)q * k + rank] = e;
+            scores_out[(size_t)q * k + rank] = normalize ? e / div : e;
         }
     }
 }
 
 int merge_topk(rag_ctx* h, const int64_t* ids, const double* scores, int n_lists, int64_t list_stride, int Q, int k,
-               int64_t* ids_out, double* scores_out, hipStream_t st) {
+               int64_t* ids_out, double* scores_out, hipStream_t st, int normalize) {
     ARG_CHECK(h, n_lists > 0 && Q > 0 && k > 0, "merge: sizes must be positive");
     const size_t lds = (size_t)n_lists * k * 16;
     ARG_CHECK(h, lds <= 64 * 1024, "merge: n_lists*k too large (max 4096 entries)");
     ARG_CHECK(h, list_stride >= (int64_t)Q * k, "merge: list_stride < Q*k");
     hipLaunchKernelGGL(merge_topk_kernel, dim3(Q), dim3(256), lds, st, ids, scores, n_lists, list_stride, Q, k, ids_out,
-                       scores_out);
+                       scores_out, normalize);
     HIP_TRY(h, hipGetLastError());
     return RAG_OK;
 }

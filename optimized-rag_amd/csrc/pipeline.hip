@@ -28,7 +28,7 @@ int rrf_fuse_dev(rag_ctx* h, const int64_t* lists_dev, int Q, int L, int len, in
 int hybrid_legs(rag_ctx* h, const float* q_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int pool, int tenant,
                 int64_t* lists_dev, double* scores_ws_dev, hipStream_t st) {
     int64_t* const bm_ids = lists_dev + (size_t)Q * pool;
-    if (Q > RAG_FORK_MAX_Q || getenv("RAG_NO_FORK")) {
+    if (Q > RAG_FORK_MAX_Q || h->opt.no_fork) {
         int rc = dense_search(h, q_dev, Q, pool, tenant, lists_dev, nullptr, scores_ws_dev, st);
         if (rc) return rc;
         return bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, tenant, bm_ids, nullptr, scores_ws_dev, nullptr, st);
@@ -60,9 +60,9 @@ int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* l
              bool host_ptrs);
 
 void pipeline_free(rag_ctx* h) {
-    hipFree(h->tok); hipFree(h->tok_len); hipFree(h->pipe_ws);
-    h->tok = nullptr; h->tok_len = nullptr; h->pipe_ws = nullptr;
-    h->tok_rows = 0; h->tok_L = 0; h->pipe_ws_bytes = 0;
+    hipFree(h->tok); hipFree(h->tok_len); hipFree(h->pipe_ws); hipFree(h->tok_bad);
+    h->tok = nullptr; h->tok_len = nullptr; h->pipe_ws = nullptr; h->tok_bad = nullptr;
+    h->tok_rows = 0; h->tok_cap = 0; h->tok_L = 0; h->pipe_ws_bytes = 0;
 }
 
 // int32 token ids -> the 16-bit resident store (WordPiece vocabularies have < 65536 entries: 30522 for the MiniLM
@@ -81,7 +81,7 @@ __global__ void tokens_narrow_kernel(const int32_t* __restrict__ in, uint16_t* _
 int tokens_load_host(rag_ctx* h, const int32_t* tokens, const int32_t* lens, int64_t n_rows, int L) {
     ARG_CHECK(h, tokens && lens && n_rows > 0 && L > 0 && L <= 512, "tokens_load: bad arguments (passage length <= 512)");
     hipFree(h->tok); hipFree(h->tok_len);
-    h->tok = nullptr; h->tok_len = nullptr; h->tok_rows = 0;
+    h->tok = nullptr; h->tok_len = nullptr; h->tok_rows = 0; h->tok_cap = 0;
     const int64_t total = n_rows * (int64_t)L, piece = (int64_t)64 << 20;
     HIP_TRY(h, hipMalloc(&h->tok, (size_t)total * sizeof(uint16_t)));
     HIP_TRY(h, hipMalloc(&h->tok_len, (size_t)n_rows * sizeof(int32_t)));
@@ -101,7 +101,40 @@ int tokens_load_host(rag_ctx* h, const int32_t* tokens, const int32_t* lens, int
     ARG_CHECK(h, n_bad == 0, "tokens_load: token ids must be in [0, 65535]");
     HIP_TRY(h, hipMemcpy(h->tok_len, lens, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice));
     h->tok_rows = n_rows;
+    h->tok_cap = n_rows;
     h->tok_L = L;
+    return RAG_OK;
+}
+
+// Chunked fill from device memory (a replicated 100M-passage store is 45 GB as uint16 and would be 90 GB as one int32 host
+// array): reserve once, append row blocks in order. tok_rows counts the rows appended so far; tok_cap the reservation.
+int tokens_reserve(rag_ctx* h, int64_t n_rows, int L) {
+    ARG_CHECK(h, n_rows > 0 && L > 0 && L <= 512, "tokens_reserve: bad arguments (passage length <= 512)");
+    hipFree(h->tok); hipFree(h->tok_len);
+    h->tok = nullptr; h->tok_len = nullptr; h->tok_rows = 0; h->tok_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->tok, (size_t)n_rows * L * sizeof(uint16_t)));
+    HIP_TRY(h, hipMalloc(&h->tok_len, (size_t)n_rows * sizeof(int32_t)));
+    if (!h->tok_bad) HIP_TRY(h, hipMalloc(&h->tok_bad, sizeof(int)));
+    HIP_TRY(h, hipMemset(h->tok_bad, 0, sizeof(int)));
+    h->tok_cap = n_rows;
+    h->tok_L = L;
+    return RAG_OK;
+}
+
+int tokens_append_dev(rag_ctx* h, const int32_t* tokens_dev, const int32_t* lens_dev, int64_t n, hipStream_t st) {
+    ARG_CHECK(h, h->tok_cap > 0, "tokens_append: rag_tokens_reserve first");
+    ARG_CHECK(h, n >= 0 && h->tok_rows + n <= h->tok_cap && (n == 0 || (tokens_dev && lens_dev)), "tokens_append: exceeds the reservation");
+    if (n == 0) return RAG_OK;
+    const int64_t total = n * (int64_t)h->tok_L;
+    hipLaunchKernelGGL(tokens_narrow_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tokens_dev,
+                       h->tok + (size_t)h->tok_rows * h->tok_L, total, h->tok_bad);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(h->tok_len + h->tok_rows, lens_dev, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    int n_bad = 0;                                                   // synchronous check: a load path, not a search path
+    HIP_TRY(h, hipMemcpyAsync(&n_bad, h->tok_bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    ARG_CHECK(h, n_bad == 0, "tokens_append: token ids must be in [0, 65535]");
+    h->tok_rows += n;
     return RAG_OK;
 }
 

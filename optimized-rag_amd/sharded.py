@@ -3,13 +3,14 @@ postings, token ids) partitioned contiguously, ONE small collective per stage.
 
     dense :  local top-k (rag_dense_topk_dev)  ->  all_gather of [ids | float64 score bits]  ->  rag_merge_topk_dev
     hybrid:  local dense top-pool + local RAW BM25 top-pool (global idf / avgdl replicated)  ->  ONE all_gather of both
-             lists  ->  two merges  ->  BM25 / global max  ->  rag_rrf_fuse_dev on the merged lists (RRF needs GLOBAL
-             ranks, so the lists are merged before fusing)
+             lists  ->  rag_hybrid_fuse_gathered_dev: two merges, BM25 / global max, RRF on the MERGED lists (RRF needs
+             GLOBAL ranks, so the lists are merged before fusing) - all inside the library
     rerank:  the Q x pool pairs are independent: each rank scores a contiguous slice (rag_ce_score_dev), one all_gather
              of the logits
 
 The reference is single-process (no collective to mirror). torch.distributed (backend "nccl" = RCCL over xGMI on
-the GPU box, "gloo" in CPU tests) is plumbing only; the merge is the HIP kernel. The payload is Q*k*16 B per rank
+the GPU box, "gloo" in CPU tests) is plumbing only (buffers, process group, the gather itself unless engine.comm_init
+bound RCCL behind the C-ABI); every piece of arithmetic on the gathered lists is a HIP kernel of the library. The payload is Q*k*16 B per rank
 (327 KB at Q=1024, k=20): latency-bound, so one fused gather of both arrays rather than two collectives.
 """
 import torch
@@ -94,11 +95,8 @@ class ShardedHybridIndex(ShardedDenseIndex):
             self._bufs[key] = dict(
                 send=torch.empty((4, Q, pool), dtype=i64, device=device),          # dense ids | dense score bits | bm25 ids | bm25 raw bits
                 recv=torch.empty((self.world, 4, Q, pool), dtype=i64, device=device),
-                lists=torch.empty((Q, 2, pool), dtype=i64, device=device),
-                dense_sc=torch.empty((Q, pool), dtype=f64, device=device),
-                bm_ids=torch.empty((Q, pool), dtype=i64, device=device),
-                dense_ids=torch.empty((Q, pool), dtype=i64, device=device),
-                bm_sc=torch.empty((Q, pool), dtype=f64, device=device),
+                lists=torch.empty((2, Q, pool), dtype=i64, device=device),         # merged dense ids | merged BM25 ids
+                scores=torch.empty((2, Q, pool), dtype=f64, device=device),        # cosines | BM25 / global max
                 keys=torch.empty((Q, k), dtype=i64, device=device),
                 rrf=torch.empty((Q, k), dtype=f64, device=device),
                 ranks=torch.empty((Q, k, 2), dtype=torch.int32, device=device))
@@ -116,18 +114,10 @@ class ShardedHybridIndex(ShardedDenseIndex):
         """recv: [world, 4, Q, pool] int64, every rank's local_lists() -> the global result (see search_hybrid)."""
         world, _, Q, pool = recv.shape
         b = self._hyb_buffers(Q, pool, k, recv.device)
-        stride = 4 * Q * pool
-        rf = recv.view(torch.float64)
-        self.engine.merge_topk_dev(recv, rf[:, 1], b["dense_ids"], b["dense_sc"], n_lists=world, list_stride=stride)
-        self.engine.merge_topk_dev(recv[:, 2], rf[:, 3], b["bm_ids"], b["bm_sc"], n_lists=world, list_stride=stride)
-        # rag/retrieval.py:343-345 with the global maximum: the merged list is sorted, so its head is the max
-        top = b["bm_sc"][:, :1]
-        b["bm_sc"] /= torch.where(top > 0, top, torch.ones_like(top))
-        b["lists"][:, 0] = b["dense_ids"]
-        b["lists"][:, 1] = b["bm_ids"]
-        self.engine.rrf_fuse_dev(b["lists"], b["keys"], b["rrf"], b["ranks"], rrf_k=rrf_k)
-        return dict(keys=b["keys"], rrf=b["rrf"], ranks=b["ranks"], dense_ids=b["dense_ids"], dense_scores=b["dense_sc"],
-                    bm25_ids=b["bm_ids"], bm25_scores=b["bm_sc"])
+        # two merges, BM25 / global max (rag/retrieval.py:343-345), RRF on the merged lists: one library call, no torch arithmetic
+        self.engine.hybrid_fuse_gathered_dev(recv, k, b["lists"], b["scores"], b["keys"], b["rrf"], b["ranks"], rrf_k=rrf_k)
+        return dict(keys=b["keys"], rrf=b["rrf"], ranks=b["ranks"], dense_ids=b["lists"][0], dense_scores=b["scores"][0],
+                    bm25_ids=b["lists"][1], bm25_scores=b["scores"][1])
 
     def search_hybrid(self, queries, term_ptr, terms, pool, k, rrf_k=60, tenant=-1):
         """queries [Q, dim] float32, term_ptr [Q+1] / terms int32 (global term ids, -1 = unknown), all replicated.

@@ -1,0 +1,142 @@
+"""GPU: BM25 through the two-level bracket tables (csrc/bm25.hip) against the CSR oracle, bit for bit. Replaces
+BM25Okapi.get_scores + /max of /root/reference/rag/retrieval.py:324-347. Every term class of the table plan is hit: direct
+per-range rows (long lists), coarse rows with an in-bracket search (middle of the distribution), no row at all (rare terms),
+lists that sit inside ONE bracket, postings exactly on bracket / range edges, the last partial range, empty terms."""
+import numpy as np
+import pytest
+
+from oracle import rag_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from optimized_rag_amd import RagEngine
+    e = RagEngine(dim=64, device=0)
+    yield e
+    e.close()
+
+
+def _postings(n_docs, doc_lists, rng):
+    from optimized_rag_amd.bm25 import Bm25Postings
+    docs = [np.unique(np.asarray(d, dtype=np.int64)).astype(np.int32) for d in doc_lists]
+    indptr = np.concatenate([[0], np.cumsum([d.shape[0] for d in docs])]).astype(np.int64)
+    doc = np.concatenate(docs) if docs else np.zeros(0, np.int32)
+    tf = rng.integers(1, 5, doc.shape[0]).astype(np.int32)
+    doc_len = rng.integers(5, 60, n_docs).astype(np.int32)
+    idf = Bm25Postings.idf_table(np.diff(indptr), n_docs)
+    return Bm25Postings(indptr, doc, tf, doc_len, idf, float(doc_len.sum()) / n_docs)
+
+
+def _check(eng, post, terms_of, k):
+    ptr = np.cumsum([0] + [len(t) for t in terms_of]).astype(np.int32)
+    terms = np.asarray([x for t in terms_of for x in t], dtype=np.int32)
+    ids, rows, scores, mx = eng.bm25_topk(ptr, terms, k)
+    eng.set_option("bm25_no_staging", 1)
+    try:
+        _, rows_x, scores_x, _ = eng.bm25_topk(ptr, terms, k)
+    finally:
+        eng.set_option("bm25_no_staging", 0)
+    np.testing.assert_array_equal(rows, rows_x)
+    np.testing.assert_array_equal(scores, scores_x)
+    for qi, t in enumerate(terms_of):
+        raw = O.bm25_scores_csr(post.indptr, post.doc, post.tf, post.doc_len, post.idf, post.avgdl, t)
+        m = raw.max() if raw.max() > 0 else 1.0
+        top = O.stable_topk_desc(raw, k)
+        np.testing.assert_array_equal(rows[qi], top.astype(np.int32), err_msg=str(t))
+        np.testing.assert_array_equal(scores[qi], raw[top] / m, err_msg=str(t))
+        assert mx[qi] == m
+
+
+def test_every_table_class_against_the_csr_oracle(eng):
+    rng = np.random.default_rng(2048)
+    n_docs = 700_000                                             # 342 ranges of 2048 documents, the last one partial
+    lists = [
+        rng.integers(0, n_docs, 260_000),                        # 0  long list: direct per-range row
+        rng.choice(n_docs, 1372, replace=False),                 # 1  exactly 4 x 343 postings: the shortest list with a direct row
+        rng.choice(n_docs, 1371, replace=False),                 # 2  one posting fewer: 4096-document brackets
+        rng.choice(n_docs, 300, replace=False),                  # 3  16384-document brackets
+        5 * 16384 + rng.choice(16384, 300, replace=False),       # 4  the whole list inside ONE bracket (long in-bracket search)
+        np.arange(0, n_docs, 16384),                             # 5  postings exactly on bracket edges
+        np.arange(2048, n_docs, 2048 * 7),                       # 6  ... and on range edges
+        rng.choice(n_docs, 7, replace=False),                    # 7  7 postings: no table
+        rng.choice(n_docs, 12, replace=False),                   # 8  12 postings: three entries of 2^19 documents
+        699_000 + rng.choice(1000, 400, replace=False),          # 9  only in the last (partial) range and its neighbour
+        np.arange(n_docs),                                       # 10 every document
+        [],                                                      # 11 a term of the vocabulary without postings
+        [n_docs - 1],                                            # 12 the very last document
+        [0],                                                     # 13 the very first one
+    ]
+    for _ in range(30):                                          # + document frequencies log-uniform in [1, 50k]
+        lists.append(rng.choice(n_docs, int(np.exp(rng.uniform(0, np.log(50_000)))), replace=False))
+    post = _postings(n_docs, lists, rng).load(eng)
+    queries = [[0, 3, 7], [1, 2], [4], [4, 5, 6], [7, 8], [9, 12, 13], [10, 3], [11], [11, 4, -1], [12], [13], [8, 8, 8, 2],
+               [5], [6, 9], [14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25], [30, 31, 32, 33], [40, 41, 42, 43, 0], [2, 4, 6, 8]]
+    for k in (20, 100):
+        _check(eng, post, queries, k)
+
+
+def test_all_document_scores_through_the_tables(eng):
+    """mode 1 of the range kernel (rag_bm25_scores_host: BM25Okapi.get_scores for every document, the input of hybrid_search's
+    linear fusion) on an ad-hoc sized corpus: 9,000 documents (5 ranges), every table class again, raw float64 bit-exact."""
+    rng = np.random.default_rng(9)
+    n_docs = 9_000
+    lists = [rng.choice(n_docs, n, replace=False) for n in (9000, 4000, 24, 23, 9, 8, 7, 1)] + [[], np.arange(2048, 4096), [8999]]
+    post = _postings(n_docs, lists, rng).load(eng)
+    terms_of = [[0, 1, 2], [3, 4, 5, 6, 7], [8], [9, 10], [2, 2, 10, -1, 7]]
+    ptr = np.cumsum([0] + [len(t) for t in terms_of]).astype(np.int32)
+    terms = np.asarray([x for t in terms_of for x in t], dtype=np.int32)
+    got = eng.bm25_scores(ptr, terms)
+    adhoc = eng.bm25_scores_adhoc(post.indptr, post.doc, post.tf, post.doc_len, post.idf, post.avgdl, ptr, terms)
+    for qi, t in enumerate(terms_of):
+        raw = O.bm25_scores_csr(post.indptr, post.doc, post.tf, post.doc_len, post.idf, post.avgdl, t)
+        np.testing.assert_array_equal(got[qi], raw)
+        np.testing.assert_array_equal(adhoc[qi], raw)
+
+
+def test_two_million_term_zipf_vocabulary(eng):
+    """The vocabulary size that broke the dense table: 1M documents, 2,000,000 term ids with a truncated
+    Zipf(1.1) tail (bench_modes.zipf_postings_gpu): the table is a small fraction of the postings, and batch queries drawn
+    from documents (mostly frequent terms, some rare) agree with the CSR oracle on sampled queries and, for the whole
+    batch, with the exhaustive per-range select."""
+    import torch
+    import bench_modes as BM
+    from optimized_rag_amd._lib import bm25_index_bytes
+    from optimized_rag_amd.bm25 import Bm25Postings
+    N, V, Q, k = 1_000_000, 2_000_000, 256, 100
+    qdocs = np.random.default_rng(3).integers(0, N, Q)
+    indptr, d, tf, dl, sampled = BM.zipf_postings_gpu(N, V, 120, torch.device("cuda", 0), sample_docs=qdocs)
+    df = np.diff(indptr)
+    assert (df > 0).sum() > 1_500_000                             # the tail is populated: >= 1.5M distinct terms occur
+    post_b, meta_b, tab_b = bm25_index_bytes(indptr, N)
+    assert tab_b <= indptr[-1] and tab_b < 0.09 * post_b           # dense table: 2M x 490 x 4 B = 3.9 GB
+    post = Bm25Postings(indptr, d, tf, dl, Bm25Postings.idf_table(df, N), float(dl.sum()) / N)
+    post.idf[df == 0] = 0.0
+    post.load(eng)
+    ptr, terms = BM.term_queries_from_docs(sampled, qdocs)
+    rare = np.nonzero((df > 0) & (df < 8))[0][:3]                  # make sure table-less terms are queried too
+    terms[ptr[5]:ptr[5] + 3] = rare
+    ptr_d, terms_d = torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda()
+
+    def run():
+        ids = torch.empty((Q, k), dtype=torch.int64, device="cuda")
+        rows = torch.empty((Q, k), dtype=torch.int32, device="cuda")
+        sc = torch.empty((Q, k), dtype=torch.float64, device="cuda")
+        eng.bm25_topk_dev(ptr_d, terms_d, k, ids, rows, sc)
+        torch.cuda.synchronize()
+        return rows.cpu().numpy(), sc.cpu().numpy()
+
+    rows, sc = run()
+    eng.set_option("bm25_no_staging", 1)
+    try:
+        rows_x, sc_x = run()
+    finally:
+        eng.set_option("bm25_no_staging", 0)
+    np.testing.assert_array_equal(rows, rows_x)
+    np.testing.assert_array_equal(sc, sc_x)
+    for qi in (0, 5, 100, 255):
+        raw = O.bm25_scores_csr(indptr, d, tf, dl, post.idf, post.avgdl, terms[ptr[qi]:ptr[qi + 1]].tolist())
+        top = O.stable_topk_desc(raw, k)
+        np.testing.assert_array_equal(rows[qi], top.astype(np.int32))
+        np.testing.assert_array_equal(sc[qi], raw[top] / (raw.max() if raw.max() > 0 else 1.0))

@@ -103,7 +103,7 @@ def test_bench_path_persistent_handover_and_two_chunks(eng):
 
 
 def test_small_multi_chunk_loop(eng, monkeypatch):
-    """RAG_CE_CHUNK_TOKENS shrinks the activation chunk: 300 pairs at L = 64 in chunks of 64 pairs (5 chunks, the last one
+    """Option ce_chunk_tokens shrinks the activation chunk: 300 pairs at L = 64 in chunks of 64 pairs (5 chunks, the last one
     short) must give the same logits, bit for bit, as one chunk (pairs are independent; every output element sums its K
     range in the same order whatever tile it lands in), and match the float64 oracle."""
     cfg = dict(vocab_size=5000, hidden=384, layers=2, heads=12, ffn=1536, max_pos=64, type_vocab=2, eps=1e-12)
@@ -114,9 +114,11 @@ def test_small_multi_chunk_loop(eng, monkeypatch):
     lens = rng.integers(2, L + 1, P).astype(np.int32)
     ids, tt = _random_pairs(rng, cfg, P, L, lens)
     one = eng.ce_score(ids, tt, lens)
-    monkeypatch.setenv("RAG_CE_CHUNK_TOKENS", "4096")
-    many = eng.ce_score(ids, tt, lens)
-    monkeypatch.delenv("RAG_CE_CHUNK_TOKENS")
+    eng.set_option("ce_chunk_tokens", 4096)
+    try:
+        many = eng.ce_score(ids, tt, lens)
+    finally:
+        eng.set_option("ce_chunk_tokens", 0)
     np.testing.assert_array_equal(one, many)
     sel = [0, 63, 64, 65, 255, 256, 299]
     exp = B.forward_logits(w, cfg, ids[sel].astype(np.int64), tt[sel].astype(np.int64), lens[sel])

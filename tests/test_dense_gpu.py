@@ -125,7 +125,7 @@ def test_forced_fallback_levels_give_identical_results(eng_factory, level, monke
     queries = planted_queries(rng, corpus, 6)
     eng = eng_factory(D)
     eng.index_load(corpus)
-    monkeypatch.setenv("RAG_FORCE_LEVEL", level)
+    eng.set_option("force_level", int(level))
     st = check(eng, corpus, queries, 20)
     assert st["proven_fast"] == 0
     if level == "2":
@@ -326,7 +326,7 @@ def test_contiguous_tenants_walk_only_their_tiles(eng_factory):
 
 
 def test_second_pass_replaces_the_exact_scan(eng_factory, monkeypatch):
-    """Forced overflow: one threshold stage over 300k rows with a threshold drawn from 2048 (RAG_STAGE_GROWTH) emits ~15k
+    """Forced overflow: one threshold stage over 300k rows with a threshold drawn from 2048 (option stage_growth) emits ~15k
     keys per query into the 4096-entry buffer. The select that follows still tightens tau from what was kept, and the second
     MFMA pass at that tau recovers every query - no float64 scan - with the oracle's result. With the second pass switched
     off the same queries take the scan path (in rounds of 256 flagged queries) and give the same answer."""
@@ -336,10 +336,10 @@ def test_second_pass_replaces_the_exact_scan(eng_factory, monkeypatch):
     queries = planted_queries(rng, corpus, Q)
     eng = eng_factory(D)
     eng.index_load(corpus)
-    monkeypatch.setenv("RAG_STAGE_GROWTH", "100000")
+    eng.set_option("stage_growth", 100000)
     st = check(eng, corpus, queries, k)
     assert st["overflowed"] >= Q and st["second_pass"] == Q and st["exact_scan"] == 0, st
-    monkeypatch.setenv("RAG_NO_SECOND_PASS", "1")
+    eng.set_option("no_second_pass", 1)
     st = check(eng, corpus, queries[:40], k)
     assert st["exact_scan"] == 40 and st["second_pass"] == 0, st
 
@@ -351,7 +351,7 @@ def test_exact_scan_rounds_beyond_256_flagged_queries(eng_factory, monkeypatch):
     queries = planted_queries(rng, corpus, 300)
     eng = eng_factory(128)
     eng.index_load(corpus)
-    monkeypatch.setenv("RAG_FORCE_LEVEL", "2")
+    eng.set_option("force_level", 2)
     st = check(eng, corpus, queries, 20)
     assert st["exact_scan"] == 300, st
 

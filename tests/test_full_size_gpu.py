@@ -131,9 +131,11 @@ def test_bm25_full_size_staged_equals_exhaustive_select(world, monkeypatch):
         return ids.cpu().numpy(), sc.cpu().numpy(), mx.cpu().numpy()
 
     ids_s, sc_s, mx_s = run(eng)                                   # staged threshold (default)
-    monkeypatch.setenv("RAG_BM25_NO_STAGING", "1")
-    ids_e, sc_e, mx_e = run(eng)                                   # exact select on all 62 ranges
-    monkeypatch.delenv("RAG_BM25_NO_STAGING")
+    eng.set_option("bm25_no_staging", 1)
+    try:
+        ids_e, sc_e, mx_e = run(eng)                               # exact select on all 489 ranges
+    finally:
+        eng.set_option("bm25_no_staging", 0)
     np.testing.assert_array_equal(ids_s, ids_e)
     np.testing.assert_array_equal(sc_s, sc_e)
     np.testing.assert_array_equal(mx_s, mx_e)

@@ -399,7 +399,7 @@ def test_batched_agent_entries_equal_the_per_query_calls(eng):
 # ---------------------------------------------------------------------------------------- fused device hybrid
 def test_hybrid_rrf_dev_matches_oracle_pipeline(eng, monkeypatch):
     """rag_hybrid_rrf_dev (dense top-pool + BM25 top-pool + RRF, all on device) == oracle dense + oracle BM25 + oracle RRF.
-    12 queries <= RAG_FORK_MAX_Q: the BM25 leg runs on the side stream beside the dense leg; RAG_NO_FORK=1 (both legs in line
+    12 queries <= RAG_FORK_MAX_Q: the BM25 leg runs on the side stream beside the dense leg; option no_fork (both legs in line
     on the caller's stream) must give the same bits."""
     import torch
     from optimized_rag_amd.bm25 import Bm25Postings
@@ -418,10 +418,12 @@ def test_hybrid_rrf_dev_matches_oracle_pipeline(eng, monkeypatch):
                                           torch.from_numpy(terms).cuda(), pool, k)
     torch.cuda.synchronize()
     keys, rrf, ranks = keys.cpu().numpy(), rrf.cpu().numpy(), ranks.cpu().numpy()
-    monkeypatch.setenv("RAG_NO_FORK", "1")
-    k2, r2, n2 = eng.hybrid_rrf_dev(torch.from_numpy(q).cuda(), torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda(), pool, k)
-    torch.cuda.synchronize()
-    monkeypatch.delenv("RAG_NO_FORK")
+    eng.set_option("no_fork", 1)
+    try:
+        k2, r2, n2 = eng.hybrid_rrf_dev(torch.from_numpy(q).cuda(), torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda(), pool, k)
+        torch.cuda.synchronize()
+    finally:
+        eng.set_option("no_fork", 0)
     np.testing.assert_array_equal(keys, k2.cpu().numpy())
     np.testing.assert_array_equal(rrf, r2.cpu().numpy())
     np.testing.assert_array_equal(ranks, n2.cpu().numpy())
@@ -572,7 +574,7 @@ def test_bm25_more_than_256_ranges_reuses_workspace(eng):
     """above 256 doc ranges (> 524,288 docs at 2048 per range; a 12.5M-row shard has 6104) the merge must still read only the
     COUNTED front of every partial list. The same device workspace is used by two batches with different queries (so
     stale slots of the first batch sit behind the second batch's fronts); both the host and the device entry must equal
-    the exact per-range select (RAG_BM25_NO_STAGING) and the CSR oracle, bit for bit."""
+    the exact per-range select (option bm25_no_staging) and the CSR oracle, bit for bit."""
     import torch
     rng = np.random.default_rng(404)
     n_docs, k = 4_500_000, 100                                   # 2198 doc ranges (nine merge groups of 256)
@@ -589,11 +591,11 @@ def test_bm25_more_than_256_ranges_reuses_workspace(eng):
         ds = torch.empty((Q, k), dtype=torch.float64, device="cuda")
         eng.bm25_topk_dev(torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda(), k, di, dr, ds)
         torch.cuda.synchronize()
-        os.environ["RAG_BM25_NO_STAGING"] = "1"
+        eng.set_option("bm25_no_staging", 1)
         try:
             _, rows_x, scores_x, mx_x = eng.bm25_topk(ptr, terms, k)
         finally:
-            del os.environ["RAG_BM25_NO_STAGING"]
+            eng.set_option("bm25_no_staging", 0)
         np.testing.assert_array_equal(rows, rows_x)
         np.testing.assert_array_equal(scores, scores_x)
         np.testing.assert_array_equal(dr.cpu().numpy(), rows_x)
@@ -725,3 +727,96 @@ def test_index_level_linear_hybrid_equals_hybrid_search(eng, intent):
         assert got["temporal"][qi].tolist() == [r["temporal_score"] for r in rows]
         np.testing.assert_allclose(got["hybrid"][qi], [r["hybrid_score"] for r in rows], atol=1e-12)
     eng.set_temporal(None)
+
+
+def test_index_level_linear_hybrid_tenant_filter(eng):
+    """under a tenant filter the keyword score of rag_hybrid_linear_dev is raw / max over the TENANT's documents
+    (the corpus hybrid_search would have been handed behind `WHERE agent_id = %s`, rag/document_store.py:457), as
+    rag_bm25_topk_* normalise; idf / avgdl stay the loaded corpus's. Oracle: the CSR BM25 scores, float64 cosines and the
+    reference's operation order (rag/retrieval.py:302), stable sort over the tenant's rows."""
+    import torch
+    rng = np.random.default_rng(77)
+    N, D, k = 6000, 64, 25
+    emb = rng.standard_normal((N, D)).astype(np.float32)
+    tenants = (np.arange(N) % 3).astype(np.int32)
+    temporal = np.where(rng.uniform(size=N) < 0.4, 0.15 * 0.5 ** (rng.uniform(0, 90, N) / 30.0), 0.0)
+    post = _sparse_postings(rng, N, 12, 900)
+    # the best keyword match of query 0 belongs to ANOTHER tenant: the two normalisations differ
+    e2 = eng.__class__(dim=D, device=0)
+    try:
+        e2.index_load(emb)
+        e2.set_tenants(tenants)
+        e2.set_temporal(temporal)
+        post.load(e2)
+        terms_of = [[0, 1], [2, 3, 4], [5], [11, 0, 7]]
+        ptr = np.cumsum([0] + [len(t) for t in terms_of]).astype(np.int32)
+        terms = np.asarray([x for t in terms_of for x in t], dtype=np.int32)
+        q = (emb[[5, 100, 2000, 4001]] + 0.5 * rng.standard_normal((4, D))).astype(np.float32)
+        a, b, g = 0.5, 0.4, 0.1
+        differs = 0
+        for tenant in (1, 2):
+            out = e2.hybrid_linear_dev(torch.from_numpy(q).cuda(), torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda(), k, a, b, g,
+                                       tenant=tenant)
+            torch.cuda.synchronize()
+            got = {key: v.cpu().numpy() for key, v in out.items()}
+            mine = np.nonzero(tenants == tenant)[0]
+            for qi, t in enumerate(terms_of):
+                raw = O.bm25_scores_csr(post.indptr, post.doc, post.tf, post.doc_len, post.idf, post.avgdl, t)
+                m = raw[mine].max() if raw[mine].max() > 0 else 1.0
+                differs += m != (raw.max() if raw.max() > 0 else 1.0)
+                kw = raw[mine] / m
+                sem = O.cosine_matrix(q[qi:qi + 1], emb[mine])[0]
+                hyb = (a * sem + b * kw) + g * temporal[mine]
+                order = O.stable_topk_desc(hyb, k)
+                assert got["rows"][qi].tolist() == mine[order].tolist()
+                assert got["keyword"][qi].tolist() == kw[order].tolist()
+                np.testing.assert_allclose(got["hybrid"][qi], hyb[order], atol=1e-12)
+        assert differs > 0                                  # the tenant's max was not the corpus max at least once
+    finally:
+        e2.close()
+
+
+def test_fused_second_pass_overflow_after_a_larger_dense_batch(eng):
+    """the fused re-emission of rag_hybrid_linear_dev reads the bias row of every one of its 256 query-map
+    slots. Slots past the overflowed-query count used to keep whatever an EARLIER search left there - after a 1024-query dense
+    search whose overflow list held indices >= 256, that indexed far outside the 256-row bias buffer. Now dead slots map to
+    query 0. A 1024-query dense search is forced to overflow everywhere, then a 40-query linear fusion is forced to overflow:
+    every query must be recovered by the second pass (no float64 scan) with the oracle's result."""
+    import torch
+    rng = np.random.default_rng(91)
+    N, D, k = 300_000, 64, 100
+    emb = rng.standard_normal((N, D)).astype(np.float32)
+    post = _sparse_postings(rng, N, 16, 4000)
+    temporal = np.where(rng.uniform(size=N) < 0.3, 0.15 * 0.5 ** (rng.uniform(0, 90, N) / 30.0), 0.0)
+    e2 = eng.__class__(dim=D, device=0)
+    try:
+        e2.index_load(emb)
+        e2.set_temporal(temporal)
+        post.load(e2)
+        e2.set_option("stage_growth", 100000)               # one threshold stage over ~298k rows: ~15k keys per query emitted
+        qbig = (emb[rng.integers(0, N, 1024)] + 0.5 * rng.standard_normal((1024, D))).astype(np.float32)
+        e2.dense_topk(qbig, k)
+        st = e2.dense_stats()
+        assert st["overflowed"] >= 1024, st                 # the overflow list now holds 256 query indices drawn from 0..1023
+        Q = 40
+        rows_q = rng.integers(0, N, Q)
+        q = (emb[rows_q] + 0.5 * rng.standard_normal((Q, D))).astype(np.float32)
+        terms_of = [[int(x) for x in rng.integers(0, 16, int(rng.integers(1, 5)))] for _ in range(Q)]
+        ptr = np.cumsum([0] + [len(t) for t in terms_of]).astype(np.int32)
+        terms = np.asarray([x for t in terms_of for x in t], dtype=np.int32)
+        a, b, g = 0.55, 0.35, 0.10
+        out = e2.hybrid_linear_dev(torch.from_numpy(q).cuda(), torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda(), k, a, b, g)
+        torch.cuda.synchronize()
+        st = e2.dense_stats()
+        assert st["overflowed"] >= Q and st["second_pass"] == Q and st["exact_scan"] == 0, st
+        got = {key: v.cpu().numpy() for key, v in out.items()}
+        for qi in (0, 7, 39):
+            raw = O.bm25_scores_csr(post.indptr, post.doc, post.tf, post.doc_len, post.idf, post.avgdl, terms_of[qi])
+            kw = raw / (raw.max() if raw.max() > 0 else 1.0)
+            sem = O.cosine_matrix(q[qi:qi + 1], emb)[0]
+            hyb = (a * sem + b * kw) + g * temporal
+            order = O.stable_topk_desc(hyb, k)
+            assert got["rows"][qi].tolist() == order.tolist()
+            np.testing.assert_allclose(got["hybrid"][qi], hyb[order], atol=1e-12)
+    finally:
+        e2.close()

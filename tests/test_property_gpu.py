@@ -559,7 +559,7 @@ def test_cross_encoder_other_hidden_sizes_take_the_unfused_path(seed, hidden, ff
 
 
 def test_cross_encoder_unfused_layernorm_path_at_hidden_384(monkeypatch):
-    """RAG_CE_NO_FUSED_LN=1 sends the MiniLM shape through the residual GEMM + stand-alone LayerNorm kernels: same logits as
+    """Option ce_no_fused_ln sends the MiniLM shape through the residual GEMM + stand-alone LayerNorm kernels: same logits as
     the fused path to rounding, both within 4e-3 of the float64 forward."""
     from oracle import bert_oracle as B
     from optimized_rag_amd.cross_encoder import flatten_state_dict
@@ -575,9 +575,11 @@ def test_cross_encoder_unfused_layernorm_path_at_hidden_384(monkeypatch):
     ids[np.arange(L)[None, :] >= lens[:, None]] = 0
     tt = ((np.arange(L)[None, :] >= 9) & (np.arange(L)[None, :] < lens[:, None])).astype(np.int32)
     fused = eng.ce_score(ids, tt, lens)
-    monkeypatch.setenv("RAG_CE_NO_FUSED_LN", "1")
-    plain = eng.ce_score(ids, tt, lens)
-    monkeypatch.delenv("RAG_CE_NO_FUSED_LN")
+    eng.set_option("ce_no_fused_ln", 1)
+    try:
+        plain = eng.ce_score(ids, tt, lens)
+    finally:
+        eng.set_option("ce_no_fused_ln", 0)
     assert np.abs(fused - plain).max() < 1e-3
     sel = [0, 1, 150, 299]
     exp = B.forward_logits(w, cfg, ids[sel].astype(np.int64), tt[sel].astype(np.int64), lens[sel], fast_erf=True)

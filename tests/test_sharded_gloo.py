@@ -80,6 +80,18 @@ class OracleEngine:
                 scores_out[q, j] = sc[j] if j < len(keys) else 0.0
                 ranks_out[q, j] = torch.tensor(rk[j] if j < len(keys) else [0] * lists.shape[1], dtype=torch.int32)
 
+    def hybrid_fuse_gathered_dev(self, gathered, k, lists_out, scores_out, keys_out, rrf_out, ranks_out, rrf_k=60, stream=None):
+        """Double of rag_hybrid_fuse_gathered_dev: two merges, BM25 / global max, RRF on the merged lists."""
+        world, _, Q, pool = gathered.shape
+        gf = gathered.view(torch.float64)
+        stride = 4 * Q * pool
+        self.merge_topk_dev(gathered, gf[:, 1], lists_out[0], scores_out[0], n_lists=world, list_stride=stride)
+        self.merge_topk_dev(gathered[:, 2], gf[:, 3], lists_out[1], scores_out[1], n_lists=world, list_stride=stride)
+        for q in range(Q):
+            top = float(scores_out[1, q, 0])
+            scores_out[1, q] /= top if top > 0 else 1.0
+        self.rrf_fuse_dev(lists_out.permute(1, 0, 2), keys_out, rrf_out, ranks_out, rrf_k=rrf_k)
+
     def ce_score_dev(self, input_ids, token_type_ids, lens, logits_out, stream=None):
         logits_out.copy_(fake_logits(input_ids, token_type_ids, lens))
 

@@ -1,7 +1,8 @@
 """Diagnostic (not product): per-GEMM-site ablation of the split-fp16 correction terms of the cross-encoder.
 For each RAG_CE_TERMS setting (one digit per site: qkv, out-proj, ffn-up, ffn-down; bit 0 = W_lo*x_hi, bit 1 = W_hi*x_lo)
 score the same pairs, compare with the float64 BERT oracle (test infrastructure) and time a 4096-pair forward.
-Writes a markdown table to stdout. Usage (GPU box): python tools/ce_ablation.py > gpurun_out/ce_ablation.md"""
+Writes a markdown table to stdout. The product library ships only the full-term kernels: this tool needs the ablation build,
+  bash tools/ce_probe_build.sh ablation && RAG_HIP_LIB=tools/bin/librag_ablation.so python tools/ce_ablation.py > gpurun_out/ce_ablation.md"""
 import os
 import sys
 import time
@@ -14,6 +15,8 @@ from optimized_rag_amd import RagEngine  # noqa: E402
 from optimized_rag_amd.cross_encoder import flatten_state_dict  # noqa: E402
 from oracle import bert_oracle as B  # noqa: E402
 
+if "ablation" not in os.environ.get("RAG_HIP_LIB", ""):
+    sys.exit("set RAG_HIP_LIB to tools/bin/librag_ablation.so (bash tools/ce_probe_build.sh ablation): RAG_CE_TERMS is not read by the product library")
 cfg = B.minilm_config()
 eng = RagEngine(dim=1536, device=0)
 rng = np.random.default_rng(7)

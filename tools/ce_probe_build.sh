@@ -6,6 +6,11 @@ cd "$(dirname "$0")/../optimized-rag_amd/csrc"
 mkdir -p ../../tools/bin
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value -Wno-unused-result"
 OTHERS=$(ls *.o | grep -v cross_encoder.o)
+# the split-term ablation build (RAG_CE_TERMS, tools/ce_ablation.py): the product library ships only the full-term kernels
+/opt/rocm/bin/hipcc $FLAGS -DRAG_CE_ABLATION -c cross_encoder.hip -o /tmp/ce_ablation.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/bin/librag_ablation.so /tmp/ce_ablation.o $OTHERS
+echo built ablation
+[ "$1" = "ablation" ] && exit 0
 for v in NO_MFMA NO_DMA NO_EPI "NO_MFMA -DCE_PROBE_NO_EPI" "NO_DMA -DCE_PROBE_NO_EPI"; do
   name=$(echo "$v" | tr -d ' ' | sed 's/-DCE_PROBE_/_/g')
   /opt/rocm/bin/hipcc $FLAGS -DCE_PROBE_$v -c cross_encoder.hip -o /tmp/ce_$name.o
