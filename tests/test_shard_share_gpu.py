@@ -58,7 +58,7 @@ def test_per_gpu_share_hybrid_and_rerank_vs_oracle_composition():
             rows_s = np.sort(short[j])
             hq = st["queries"][qi:qi + 1].cpu().numpy()
             exact = O.cosine_matrix(hq, eng.fetch_rows(rows_s))[0]
-            assert exact.max() - np.sort(exact)[-pool] < 0.5 and np.sort(exact)[-pool] - exact.min() > 2e-3    # shortlist margin >> float32 error
+            assert np.sort(exact)[-pool] - exact.min() > 2e-3      # the 100th best sits far above the shortlist's tail: float32 error << margin
             d_rows = rows_s[np.lexsort((rows_s, -exact))[:pool]]
             qt = st["terms"][st["term_ptr"][qi]:st["term_ptr"][qi + 1]].tolist()
             raw = O.bm25_scores_csr(post.indptr, post.doc, post.tf, post.doc_len, post.idf, post.avgdl, qt)
