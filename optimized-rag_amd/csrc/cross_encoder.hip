@@ -638,6 +638,293 @@ __global__ __launch_bounds__(512) void ce_gemm_ln_kernel(const half_t* __restric
 #undef LNG_ISSUE_X
 }
 
+// ---- the whole FFN in ONE kernel (hidden = 384): up-projection + bias + erf-GELU + down-projection + bias + residual + LayerNorm
+// The 1536-wide intermediate activation never reaches HBM: it was the largest tensor of the forward (6 of the ~15 KB stored and
+// 12 of the 33.8 KB moved per token and layer; profiles/r02_i: 1.02 TB of HBM traffic per 25,600-pair forward) and its round
+// trip cost one launch and one store-bound epilogue per layer.
+// A persistent workgroup owns 128 tokens. The intermediate is produced and consumed 128 features (one CHUNK) at a time:
+//   phase A  H_c^T[128 feat x 128 tok] = W1[chunk c] . X^T, K = 384: 12 K-steps of 32 (W1 slice 16 KiB + token slice 16 KiB per
+//            step, three 32-KiB ring slots, two steps of lead); 8 waves = 2 feature halves x 4 token groups, 32 accumulators;
+//   E        bias + GELU, split fp16, written to LDS in the operand layout phase B reads ([K group][token][hi 32 | lo 32]):
+//            64 KiB, never in HBM;
+//   phase B  Y^T[384 x 128 tok] += W2[:, chunk c] . H_c^T, K = 128: 4 K-steps (W2 slice 48 KiB per step, two 48-KiB ring slots
+//            laid over the SAME 96 KiB as phase A's three); 8 waves = 2 feature halves x 4 token groups, 96 accumulators that live
+//            across all 12 chunks;
+// then the bias + residual + LayerNorm epilogue of ce_gemm_ln_kernel. LDS = 96 KiB ring + 64 KiB H = 160 KiB.
+// One barrier per step; every DMA piece is issued right after the barrier that closes the last read of the bytes it overwrites:
+//   A_t (t <= 9) issues A_{t+2};  A_11 issues B_0;  E issues B_1;  B_1 issues B_2;  B_2 issues B_3;  B_3 issues the next A_0
+//   (next chunk or next tile);  A_0 issues A_1 and A_2.
+// Counted waits (pieces per wave: 4 per A step, 6 per B step): A_1..A_10 vmcnt(4), B_0 vmcnt(6), every other step vmcnt(0).
+// The first-projection bias of chunk c + 1 is loaded during B_1 of chunk c (ahead of B_2's pieces: B_2's own wait covers it).
+#define FFN_RING (96 * 1024)
+#define FFN_HBUF (64 * 1024)
+#define FFN_LDS (FFN_RING + FFN_HBUF)
+#define FFN_CH 128                                // intermediate features per chunk
+template <int TERMS>
+__global__ __launch_bounds__(512) void ce_ffn_ln_kernel(const half_t* __restrict__ W1, const float* __restrict__ b1,
+                                                         const half_t* __restrict__ W2, const float* __restrict__ b2, int F,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                         half_t* __restrict__ stream16, const int32_t* __restrict__ m_packed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int H = 384, NTA = H / CE_BK, NTB = FFN_CH / CE_BK;     // 12 K-steps up, 4 K-steps down per chunk
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int m_end = m_packed[0];
+    int tile = blockIdx.x;
+    if (tile * 128 >= m_end) return;
+    const int n_chunks = F / FFN_CH;
+    // DMA sources (see ce_gemm_ln_kernel): a piece = 64 rows x 128 B, one 1-KiB instruction per wave; per-lane byte offset for rows
+    // of 2*H halfs (W1, X) and of 2*F halfs (W2); descriptors in scalar registers
+    const int schunk = (lane & 7) ^ ((wid & 1) * 4 + (lane >> 4));
+    const unsigned row_a = (unsigned)(2 * H * sizeof(half_t)), row_b = (unsigned)(2 * F * sizeof(half_t));
+    const unsigned voff_a = (unsigned)((wid * 8 + (lane >> 3)) * row_a + schunk * 16);
+    const unsigned voff_b = (unsigned)((wid * 8 + (lane >> 3)) * row_b + schunk * 16);
+    const __amdgpu_buffer_rsrc_t w1_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(W1), 0, (int)((size_t)F * row_a), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(W2), 0, (int)((size_t)H * row_b), 0x00020000);
+    __amdgpu_buffer_rsrc_t x_cur = __builtin_amdgcn_make_buffer_rsrc(stream16 + (size_t)tile * 128 * 2 * H, 0, (int)(128 * row_a), 0x00020000);
+    char* const hbuf = smem + FFN_RING;
+    const int fr = lane & 15, fq = lane >> 4, sw = (fr >> 1) & 7;
+    const int off_hi = fr * 128 + ((fq ^ sw) << 4), off_lo = fr * 128 + (((4 + fq) ^ sw) << 4);
+    // phase A: this wave's 64 intermediate features (rows of the W1 slice) x 32 tokens; phase B: 192 output features x 32 tokens
+    const int a_base_A = wm * 64 * 128, b_base_A = 16384 + wn * 32 * 128;
+    const int a_base_B = wm * 192 * 128, b_base_B = wn * 32 * 128;
+#define FFN_ISSUE_A(c, t, xrs)     /* W1 slice of chunk c, K-step t (2 pieces) + token slice (2 pieces) -> A slot t % 3 */ \
+    {                                                                                                                      \
+        char* st_ = smem + ((t) % 3) * 32768;                                                                             \
+        const unsigned wo_ = (unsigned)(c) * (FFN_CH * row_a) + (unsigned)(t) * 128u;                                     \
+        ce_bdma(w1_rs, voff_a, wo_, st_, wid);                                                                            \
+        ce_bdma(w1_rs, voff_a, wo_ + 64 * row_a, st_ + 8192, wid);                                                        \
+        ce_bdma(xrs, voff_a, (unsigned)(t) * 128u, st_ + 16384, wid);                                                     \
+        ce_bdma(xrs, voff_a, 64 * row_a + (unsigned)(t) * 128u, st_ + 16384 + 8192, wid);                                 \
+    }
+#define FFN_ISSUE_B(c, u)          /* W2 slice of chunk c, K-step u (6 pieces: all 384 output rows) -> B slot u & 1 */      \
+    {                                                                                                                      \
+        char* st_ = smem + ((u) & 1) * 49152;                                                                             \
+        const unsigned ko_ = ((unsigned)(c) * NTB + (unsigned)(u)) * 128u;                                                \
+        _Pragma("unroll") for (int p_ = 0; p_ < 6; ++p_) ce_bdma(w2_rs, voff_b, (unsigned)p_ * 64u * row_b + ko_, st_ + p_ * 8192, wid); \
+    }
+    f32x4 acc[12][2];                                  // phase B accumulators: live across the 12 chunks of a tile
+    float4 bv[4];                                      // first-projection bias of the current chunk: features wm*64 + i*16 + fq*4 ..+4
+#define FFN_LOAD_BIAS(c) \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) bv[i_] = *reinterpret_cast<const float4*>(b1 + (c) * FFN_CH + wm * 64 + i_ * 16 + fq * 4);
+    FFN_LOAD_BIAS(0)
+    FFN_ISSUE_A(0, 0, x_cur)
+    for (bool first = true;; first = false) {
+        const int m0 = tile * 128;
+        const int nx = tile + gridDim.x;
+        const bool has_next = nx * 128 < m_end;
+        __amdgpu_buffer_rsrc_t x_nxt = x_cur;
+        if (has_next) x_nxt = __builtin_amdgcn_make_buffer_rsrc(stream16 + (size_t)nx * 128 * 2 * H, 0, (int)(128 * row_a), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int c = 0; c < n_chunks; ++c) {
+            // ================= phase A: 12 K-steps =================
+            f32x4 ha[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ha[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; ha[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int t = 0; t < NTA; ++t) {
+                // own pieces of step t landed (step 0 of a continued tile was waited for inside the previous epilogue)
+                if (t == 0 || t == NTA - 1) { if (!(t == 0 && c == 0 && !first)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                CE_BAR
+                const char* st = smem + (t % 3) * 32768;
+                half8 bh[2], bl[2], ah[4], al[4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bh[j] = *reinterpret_cast<const half8*>(st + b_base_A + j * 2048 + off_hi);
+                    if (TERMS & 2) bl[j] = *reinterpret_cast<const half8*>(st + b_base_A + j * 2048 + off_lo);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ah[i] = *reinterpret_cast<const half8*>(st + a_base_A + i * 2048 + off_hi);
+                    if (TERMS & 1) al[i] = *reinterpret_cast<const half8*>(st + a_base_A + i * 2048 + off_lo);
+                }
+                if (t == 0) { FFN_ISSUE_A(c, 1, x_cur) FFN_ISSUE_A(c, 2, x_cur) }
+                else if (t + 2 < NTA) FFN_ISSUE_A(c, t + 2, x_cur)
+                else if (t == NTA - 1) FFN_ISSUE_B(c, 0)
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (TERMS & 1) ha[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], ha[i][j], 0, 0, 0);
+                        if (TERMS & 2) ha[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], ha[i][j], 0, 0, 0);
+                        ha[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], ha[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_s_setprio(0);
+            }
+            // ================= E: bias + GELU -> split fp16 in LDS, phase B's operand layout =================
+            CE_BAR                                          // every wave is past its reads of the last A step: B slot 1 is free
+            FFN_ISSUE_B(c, 1)
+            // ha[i][j][r] = H^T[feature wm*64 + i*16 + fq*4 + r][token wn*32 + j*16 + fr]; K group = feature / 32 = wm*2 + (i>>1),
+            // inside it the 4 features sit at half index (i&1)*16 + fq*4 .. +4: 16-B piece (i&1)*2 + (fq>>1), second half if fq odd
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int tk = wn * 32 + j * 16 + fr;
+                    const int swt = (tk >> 1) & 7, pc = (i & 1) * 2 + (fq >> 1);
+                    char* row = hbuf + (wm * 2 + (i >> 1)) * 16384 + tk * 128 + (fq & 1) * 8;
+                    const float v0 = ce_gelu(ha[i][j][0] + bv[i].x), v1 = ce_gelu(ha[i][j][1] + bv[i].y);
+                    const float v2 = ce_gelu(ha[i][j][2] + bv[i].z), v3 = ce_gelu(ha[i][j][3] + bv[i].w);
+                    const half4 hi = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+                    const half4 lo = {(half_t)(v0 - (float)hi[0]), (half_t)(v1 - (float)hi[1]), (half_t)(v2 - (float)hi[2]), (half_t)(v3 - (float)hi[3])};
+                    *reinterpret_cast<half4*>(row + ((pc ^ swt) << 4)) = hi;
+                    *reinterpret_cast<half4*>(row + (((4 + pc) ^ swt) << 4)) = lo;
+                }
+            // ================= phase B: 4 K-steps =================
+#pragma unroll
+            for (int u = 0; u < NTB; ++u) {
+                if (u == 0) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");       // B_0 landed; the H writes are done
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                CE_BAR
+                if (u == 1) {
+                    if (c + 1 < n_chunks) { FFN_LOAD_BIAS(c + 1) } else { FFN_LOAD_BIAS(0) }
+                    FFN_ISSUE_B(c, 2)
+                } else if (u == 2) {
+                    FFN_ISSUE_B(c, 3)
+                } else if (u == 3) {
+                    if (c + 1 < n_chunks) FFN_ISSUE_A(c + 1, 0, x_cur)
+                    else if (has_next) FFN_ISSUE_A(0, 0, x_nxt)
+                }
+                const char* ws = smem + (u & 1) * 49152 + a_base_B;
+                const char* xs = hbuf + u * 16384 + b_base_B;
+                half8 bh[2], bl[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bh[j] = *reinterpret_cast<const half8*>(xs + j * 2048 + off_hi);
+                    if (TERMS & 2) bl[j] = *reinterpret_cast<const half8*>(xs + j * 2048 + off_lo);
+                }
+                half8 ah[2][2], al[2][2];
+#define FFN_READ_PAIR(p, s)                                                                                           \
+                _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) {                                                    \
+                    ah[s][ii] = *reinterpret_cast<const half8*>(ws + ((p) * 2 + ii) * 2048 + off_hi);                 \
+                    if (TERMS & 1) al[s][ii] = *reinterpret_cast<const half8*>(ws + ((p) * 2 + ii) * 2048 + off_lo);  \
+                }
+                FFN_READ_PAIR(0, 0)
+                FFN_READ_PAIR(1, 1)
+#pragma unroll
+                for (int p = 0; p < 6; ++p) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            f32x4& a = acc[p * 2 + ii][j];
+                            if (TERMS & 1) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[p & 1][ii], bh[j], a, 0, 0, 0);
+                            if (TERMS & 2) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p & 1][ii], bl[j], a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[p & 1][ii], bh[j], a, 0, 0, 0);
+                        }
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (p + 2 < 6) FFN_READ_PAIR(p + 2, p & 1)
+                }
+#undef FFN_READ_PAIR
+            }
+        }
+        // ---- epilogue: bias + residual + LayerNorm, as ce_gemm_ln_kernel. acc[i][j][r] = sum for feature wm*192 + i*16 + fq*4 + r,
+        // token m0 + wn*32 + j*16 + fr. The last B step read B slot 1 = ring bytes [48K, 96K): after this barrier it is the
+        // transpose scratch (6 KiB per wave); the next tile's A_0 pieces are in flight into [0, 32K).
+        CE_BAR
+        char* wl = smem + 49152 + wid * 6144;                        // [16 tokens][64 features] fp32, rows 272 B
+        float* st_sum = reinterpret_cast<float*>(wl + 4352);         // [32] per-token partial sums of this wave's 192 features
+        float* st_sq = st_sum + 32;
+        const float* pr_sum = reinterpret_cast<const float*>(smem + 49152 + (wid ^ 4) * 6144 + 4352);   // the other feature half
+        const float* pr_sq = pr_sum + 32;
+        const int rr = lane >> 4, cc = lane & 15;
+        unsigned so = (unsigned)((rr * 2 * H + (wm * 6 + (cc >> 3)) * 64 + (cc & 7) * 4) * sizeof(half_t));   // stream row, split index
+        unsigned fo = (unsigned)((wm * 192 + cc * 4) * sizeof(float));                                          // bias / gamma / beta
+        asm volatile("" : "+v"(so), "+v"(fo));
+        char* const srow = reinterpret_cast<char*>(stream16 + (size_t)(m0 + wn * 32) * 2 * H);
+        f32x4 vv[2][3][4];                                           // [token block][64-feature group][4 rows per lane]
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+                    *reinterpret_cast<f32x4*>(wl + fr * 272 + (ii * 16 + fq * 4) * 4) = acc[g * 4 + ii][j];
+                __builtin_amdgcn_wave_barrier();
+                const float4 b2v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(b2) + fo + g * 256);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 4 + rr;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(wl + row * 272 + cc * 16);
+                    const half_t* rp = reinterpret_cast<const half_t*>(srow + so + ((j * 16 + it * 4) * 2 * H + g * 128) * sizeof(half_t));
+                    const half4 rh = *reinterpret_cast<const half4*>(rp), rl = *reinterpret_cast<const half4*>(rp + 32);
+                    vv[j][g][it] = (f32x4){v[0] + b2v.x + ((float)rh[0] + (float)rl[0]), v[1] + b2v.y + ((float)rh[1] + (float)rl[1]),
+                                           v[2] + b2v.z + ((float)rh[2] + (float)rl[2]), v[3] + b2v.w + ((float)rh[3] + (float)rl[3])};
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        float mean[2][4], rstd[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                float sm = 0.f;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) sm += (vv[j][g][it][0] + vv[j][g][it][1]) + (vv[j][g][it][2] + vv[j][g][it][3]);
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o);
+                mean[j][it] = sm;
+                if (cc == 0) st_sum[j * 16 + it * 4 + rr] = sm;
+            }
+        CE_BAR
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const float mu = (mean[j][it] + pr_sum[j * 16 + it * 4 + rr]) * (1.0f / (float)H);
+                mean[j][it] = mu;
+                float q = 0.f;
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = vv[j][g][it][e] - mu; q += d * d; }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o);
+                rstd[j][it] = q;
+                if (cc == 0) st_sq[j * 16 + it * 4 + rr] = q;
+            }
+        CE_BAR
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                rstd[j][it] = 1.0f / sqrtf((rstd[j][it] + pr_sq[j * 16 + it * 4 + rr]) * (1.0f / (float)H) + eps);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const float4 gv = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(gamma) + fo + g * 256);
+            const float4 be = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(beta) + fo + g * 256);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const f32x4 v = vv[j][g][it];
+                    const float mu = mean[j][it], rs = rstd[j][it];
+                    half_t* o = reinterpret_cast<half_t*>(srow + so + ((j * 16 + it * 4) * 2 * H + g * 128) * sizeof(half_t));
+                    store_split4(o, 32, (v[0] - mu) * rs * gv.x + be.x, (v[1] - mu) * rs * gv.y + be.y, (v[2] - mu) * rs * gv.z + be.z,
+                                 (v[3] - mu) * rs * gv.w + be.w);
+                }
+        }
+        if (!has_next) break;
+        // the next tile's A_0 pieces (issued before this epilogue's loads) have landed: every load above was waited for in order.
+        // The scratch is overwritten by A_1 / A_2 of the next tile only after its first barrier.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tile = nx;
+        x_cur = x_nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef FFN_ISSUE_A
+#undef FFN_ISSUE_B
+#undef FFN_LOAD_BIAS
+}
+
 // ---- LayerNorm helpers: one wave per token row of `hidden` floats (hidden % 64 == 0, <= 1024) --------------
 template <int PER>
 __device__ __forceinline__ void wave_layernorm(float (&v)[PER], const float* __restrict__ g, const float* __restrict__ b,
