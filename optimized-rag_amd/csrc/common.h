@@ -127,7 +127,7 @@ struct rag_ctx {
     void* pipe_ws = nullptr;
     size_t pipe_ws_bytes = 0;
     // hipFuncSetAttribute (dynamic LDS above 64 KiB) is per device: remembered per handle, not per process
-    bool attr_dense = false, attr_bm25 = false, attr_ce_gemm = false, attr_ce_gemm_ln = false;
+    bool attr_dense = false, attr_bm25 = false, attr_ce_gemm = false, attr_ce_gemm_ln = false, attr_ce_ffn = false;
     int attr_ce_attn_lds[3] = {0, 0, 0};
     rag_ce_model* ce = nullptr;
 };

@@ -1398,6 +1398,17 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
 #else
 #define CE_GEMM_LN(T, ...) hipLaunchKernelGGL((ce_gemm_ln_kernel<3>), dim3(n_cu), blk, LNG_LDS, st, __VA_ARGS__);
 #endif
+    // the whole FFN in one kernel (ce_ffn_ln_kernel) when the geometry allows; option ce_no_fused_ffn keeps the two-launch form
+    const bool fused_ffn = fused_ln && F % FFN_CH == 0 && !h->opt.ce_no_fused_ffn;
+    // the FFN intermediate [tokens][ffn] (the largest activation: 12 GB per 2M-token chunk) exists only for the two-launch form
+    if (!fused_ffn && !m->h16) {
+        HIP_TRY(h, hipMalloc(&m->h16, 2 * pp.h * 2));
+        HIP_TRY(h, hipMemsetAsync(m->h16, 0, 2 * pp.h * 2, st));            // padded token rows are read by the GEMM tiles: keep them finite
+    }
+    if (fused_ffn && !h->attr_ce_ffn) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_ffn_ln_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS));
+        h->attr_ce_ffn = true;
+    }
 #define CE_PER_DISPATCH(CALL)                                                                 \
     switch (per) {                                                                            \
         case 2: CALL(2); break; case 4: CALL(4); break; case 6: CALL(6); break;               \
@@ -1431,6 +1442,11 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
                     ly.bo, (const half_t*)m->x16, m->y32, (half_t*)nullptr, (half_t*)nullptr, (half_t*)nullptr, (size_t)0, H, m->cfg.heads, m->m_packed, (int)Mp)
             CE_PER_DISPATCH(LN1)
         }
+        if (fused_ffn) {
+            hipLaunchKernelGGL((ce_ffn_ln_kernel<3>), dim3(n_cu), blk, FFN_LDS, st, (const half_t*)ly.w1, (const float*)ly.b1, (const half_t*)ly.w2,
+                               (const float*)ly.b2, F, (const float*)ly.ln2_g, (const float*)ly.ln2_b, eps, m->x16, (const int32_t*)m->m_packed);
+            continue;
+        }
         CE_GEMM(EPI_GELU, terms[2], ly.w1, m->x16, F, H,
                 ly.b1, (const half_t*)nullptr, (float*)nullptr, m->h16, (half_t*)nullptr, (half_t*)nullptr, (size_t)0,
                 H, m->cfg.heads, m->m_packed, (int)Mp)
@@ -1463,7 +1479,6 @@ static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t s
     HIP_TRY(h, hipMalloc(&m->kf16, 2 * pp.kv * 2));
     HIP_TRY(h, hipMalloc(&m->vf16, 2 * pp.kv * 2));
     HIP_TRY(h, hipMalloc(&m->ctx16, 2 * pp.ctx * 2));
-    HIP_TRY(h, hipMalloc(&m->h16, 2 * pp.h * 2));
     HIP_TRY(h, hipMalloc(&m->ids, (size_t)Mp * 4));
     HIP_TRY(h, hipMalloc(&m->tt, (size_t)Mp * 4));
     HIP_TRY(h, hipMalloc(&m->lens, (size_t)P * 4));
@@ -1476,7 +1491,6 @@ static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t s
     // padded token rows are read by the GEMM tiles: keep them finite
     HIP_TRY(h, hipMemsetAsync(m->x16, 0, 2 * pp.x * 2, st));
     HIP_TRY(h, hipMemsetAsync(m->ctx16, 0, 2 * pp.ctx * 2, st));
-    HIP_TRY(h, hipMemsetAsync(m->h16, 0, 2 * pp.h * 2, st));
     HIP_TRY(h, hipMemsetAsync(m->q16, 0, 2 * pp.q * 2, st));
     HIP_TRY(h, hipMemsetAsync(m->kf16, 0, 2 * pp.kv * 2, st));
     HIP_TRY(h, hipMemsetAsync(m->vf16, 0, 2 * pp.kv * 2, st));

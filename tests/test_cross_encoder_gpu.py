@@ -182,3 +182,38 @@ def test_sixteen_row_packing_edges_and_position_independence(eng):
     np.testing.assert_array_equal(rev[::-1], got)
     for p in (0, 3, 6, 11, P - 1):
         np.testing.assert_array_equal(eng.ce_score(ids[p:p + 1], tt[p:p + 1], lens[p:p + 1]), got[p:p + 1])
+
+
+def test_fused_ffn_kernel_equals_the_two_launch_form(eng):
+    """ce_ffn_ln_kernel (up-projection + GELU + down-projection + bias + residual + LayerNorm per 128-token tile, the 1536-wide
+    intermediate living in LDS) against the two-launch form it replaces (option ce_no_fused_ffn: FFN-up GEMM writing the
+    intermediate to HBM, then the fused-LN down-projection). Both sum every output's K range in the same order with the same
+    split-fp16 roundings, so the logits must agree BIT FOR BIT; a sample is also held against the float64 oracle. 3000 pairs of
+    mixed length at L = 256 = ~600k packed rows: every persistent workgroup walks ~18 tiles (the cross-tile / cross-chunk DMA
+    hand-over of the ring), lengths hit every 16-row packing edge."""
+    import torch
+    cfg = B.minilm_config()
+    w = B.seeded_weights(cfg, 99)
+    load_model(eng, cfg, w)
+    P, L = 3000, 256
+    rng = np.random.default_rng(1536)
+    lens = (18 + rng.integers(96, 225, P)).clip(max=L).astype(np.int32)
+    lens[:40] = np.arange(1, 41)
+    lens[40:60] = L
+    ids, tt = _random_pairs(rng, cfg, P, L, lens)
+    d_ids, d_tt, d_lens = torch.from_numpy(ids).cuda(), torch.from_numpy(tt).cuda(), torch.from_numpy(lens).cuda()
+    fused = torch.empty((P,), dtype=torch.float32, device="cuda")
+    plain = torch.empty((P,), dtype=torch.float32, device="cuda")
+    eng.ce_score_dev(d_ids, d_tt, d_lens, fused)
+    eng.set_option("ce_no_fused_ffn", 1)
+    try:
+        eng.ce_score_dev(d_ids, d_tt, d_lens, plain)
+    finally:
+        eng.set_option("ce_no_fused_ffn", 0)
+    torch.cuda.synchronize()
+    f, p = fused.cpu().numpy(), plain.cpu().numpy()
+    assert np.isfinite(f).all()
+    np.testing.assert_array_equal(f, p)
+    sample = [0, 1, 15, 16, 39, 40, 59, 60, 1500, P - 1]
+    exp = B.forward_logits(w, cfg, ids[sample].astype(np.int64), tt[sample].astype(np.int64), lens[sample], fast_erf=True)
+    assert np.abs(f[sample] - exp).max() < LOGIT_TOL, (f[sample], exp)
