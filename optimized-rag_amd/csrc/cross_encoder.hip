@@ -689,21 +689,23 @@ __global__ __launch_bounds__(512) void ce_ffn_ln_kernel(const half_t* __restrict
     // phase A: this wave's 64 intermediate features (rows of the W1 slice) x 32 tokens; phase B: 192 output features x 32 tokens
     const int a_base_A = wm * 64 * 128, b_base_A = 16384 + wn * 32 * 128;
     const int a_base_B = wm * 192 * 128, b_base_B = wn * 32 * 128;
-#define FFN_ISSUE_A(c, t, xrs)     /* W1 slice of chunk c, K-step t (2 pieces) + token slice (2 pieces) -> A slot t % 3 */ \
+#ifdef CE_PROBE_FFN_SHARED_X      // timing experiment only (tools/ce_probe_build.sh): every workgroup streams tile 0's tokens (L2-hot) - results are wrong
+    const __amdgpu_buffer_rsrc_t x0_rs = __builtin_amdgcn_make_buffer_rsrc(stream16, 0, (int)(128 * row_a), 0x00020000);
+#define FFN_XSRC(x) x0_rs
+#else
+#define FFN_XSRC(x) x
+#endif
+    // one 8-KiB piece (64 rows x 128 B) at a time, so that the issue cost of a transfer (60-180 cycles per piece per wave) is
+    // spread behind the MFMA groups of a step instead of standing in front of them
+#define FFN_PIECE_A(c, t, xrs, k)  /* piece k of step t of chunk c: 0, 1 = W1 slice halves, 2, 3 = token slice halves -> A slot t % 3 */ \
     {                                                                                                                      \
-        char* st_ = smem + ((t) % 3) * 32768;                                                                             \
-        const unsigned wo_ = (unsigned)(c) * (FFN_CH * row_a) + (unsigned)(t) * 128u;                                     \
-        ce_bdma(w1_rs, voff_a, wo_, st_, wid);                                                                            \
-        ce_bdma(w1_rs, voff_a, wo_ + 64 * row_a, st_ + 8192, wid);                                                        \
-        ce_bdma(xrs, voff_a, (unsigned)(t) * 128u, st_ + 16384, wid);                                                     \
-        ce_bdma(xrs, voff_a, 64 * row_a + (unsigned)(t) * 128u, st_ + 16384 + 8192, wid);                                 \
+        char* st_ = smem + ((t) % 3) * 32768 + (k) * 8192;                                                                \
+        if ((k) < 2) ce_bdma(w1_rs, voff_a, (unsigned)(c) * (FFN_CH * row_a) + (unsigned)(t) * 128u + (unsigned)(k) * (64 * row_a), st_, wid); \
+        else ce_bdma(FFN_XSRC(xrs), voff_a, (unsigned)((k) - 2) * (64 * row_a) + (unsigned)(t) * 128u, st_, wid);          \
     }
-#define FFN_ISSUE_B(c, u)          /* W2 slice of chunk c, K-step u (6 pieces: all 384 output rows) -> B slot u & 1 */      \
-    {                                                                                                                      \
-        char* st_ = smem + ((u) & 1) * 49152;                                                                             \
-        const unsigned ko_ = ((unsigned)(c) * NTB + (unsigned)(u)) * 128u;                                                \
-        _Pragma("unroll") for (int p_ = 0; p_ < 6; ++p_) ce_bdma(w2_rs, voff_b, (unsigned)p_ * 64u * row_b + ko_, st_ + p_ * 8192, wid); \
-    }
+#define FFN_ISSUE_A(c, t, xrs) { FFN_PIECE_A(c, t, xrs, 0) FFN_PIECE_A(c, t, xrs, 1) FFN_PIECE_A(c, t, xrs, 2) FFN_PIECE_A(c, t, xrs, 3) }
+#define FFN_PIECE_B(c, u, k)       /* piece k (0..5: 64 output rows each) of the W2 slice of chunk c, K-step u -> B slot u & 1 */ \
+    ce_bdma(w2_rs, voff_b, (unsigned)(k) * 64u * row_b + ((unsigned)(c) * NTB + (unsigned)(u)) * 128u, smem + ((u) & 1) * 49152 + (k) * 8192, wid);
     f32x4 acc[12][2];                                  // phase B accumulators: live across the 12 chunks of a tile
     float4 bv[4];                                      // first-projection bias of the current chunk: features wm*64 + i*16 + fq*4 ..+4
 #define FFN_LOAD_BIAS(c) \
@@ -741,23 +743,26 @@ __global__ __launch_bounds__(512) void ce_ffn_ln_kernel(const half_t* __restrict
                     ah[i] = *reinterpret_cast<const half8*>(st + a_base_A + i * 2048 + off_hi);
                     if (TERMS & 1) al[i] = *reinterpret_cast<const half8*>(st + a_base_A + i * 2048 + off_lo);
                 }
-                if (t == 0) { FFN_ISSUE_A(c, 1, x_cur) FFN_ISSUE_A(c, 2, x_cur) }
-                else if (t + 2 < NTA) FFN_ISSUE_A(c, t + 2, x_cur)
-                else if (t == NTA - 1) FFN_ISSUE_B(c, 0)
-                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         if (TERMS & 1) ha[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], ha[i][j], 0, 0, 0);
                         if (TERMS & 2) ha[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], ha[i][j], 0, 0, 0);
                         ha[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], ha[i][j], 0, 0, 0);
                     }
-                __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the pieces this step owes, one or two behind each MFMA group (W1 halves first: the X halves are L2-hot)
+                    if (t == 0) { FFN_PIECE_A(c, 1 + (i >> 1), x_cur, (i & 1) * 2) FFN_PIECE_A(c, 1 + (i >> 1), x_cur, (i & 1) * 2 + 1) }
+                    else if (t + 2 < NTA) FFN_PIECE_A(c, t + 2, x_cur, i)
+                    else if (t == NTA - 1) { FFN_PIECE_B(c, 0, i) if (i >= 2) FFN_PIECE_B(c, 0, i + 2) }
+                }
             }
             // ================= E: bias + GELU -> split fp16 in LDS, phase B's operand layout =================
             CE_BAR                                          // every wave is past its reads of the last A step: B slot 1 is free
-            FFN_ISSUE_B(c, 1)
             // ha[i][j][r] = H^T[feature wm*64 + i*16 + fq*4 + r][token wn*32 + j*16 + fr]; K group = feature / 32 = wm*2 + (i>>1),
             // inside it the 4 features sit at half index (i&1)*16 + fq*4 .. +4: 16-B piece (i&1)*2 + (fq>>1), second half if fq odd
 #pragma unroll
@@ -773,6 +778,7 @@ __global__ __launch_bounds__(512) void ce_ffn_ln_kernel(const half_t* __restrict
                     const half4 lo = {(half_t)(v0 - (float)hi[0]), (half_t)(v1 - (float)hi[1]), (half_t)(v2 - (float)hi[2]), (half_t)(v3 - (float)hi[3])};
                     *reinterpret_cast<half4*>(row + ((pc ^ swt) << 4)) = hi;
                     *reinterpret_cast<half4*>(row + (((4 + pc) ^ swt) << 4)) = lo;
+                    if (i * 2 + j < 6) FFN_PIECE_B(c, 1, i * 2 + j)          // B_1's six pieces, one behind each block's GELU
                 }
             // ================= phase B: 4 K-steps =================
 #pragma unroll
@@ -780,15 +786,7 @@ __global__ __launch_bounds__(512) void ce_ffn_ln_kernel(const half_t* __restrict
                 if (u == 0) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");       // B_0 landed; the H writes are done
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 CE_BAR
-                if (u == 1) {
-                    if (c + 1 < n_chunks) { FFN_LOAD_BIAS(c + 1) } else { FFN_LOAD_BIAS(0) }
-                    FFN_ISSUE_B(c, 2)
-                } else if (u == 2) {
-                    FFN_ISSUE_B(c, 3)
-                } else if (u == 3) {
-                    if (c + 1 < n_chunks) FFN_ISSUE_A(c + 1, 0, x_cur)
-                    else if (has_next) FFN_ISSUE_A(0, 0, x_nxt)
-                }
+                if (u == 1) { if (c + 1 < n_chunks) { FFN_LOAD_BIAS(c + 1) } else { FFN_LOAD_BIAS(0) } }
                 const char* ws = smem + (u & 1) * 49152 + a_base_B;
                 const char* xs = hbuf + u * 16384 + b_base_B;
                 half8 bh[2], bl[2];
@@ -821,6 +819,13 @@ __global__ __launch_bounds__(512) void ce_ffn_ln_kernel(const half_t* __restrict
                     __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (p + 2 < 6) FFN_READ_PAIR(p + 2, p & 1)
+                    // what this step owes, one piece behind each MFMA group: B_1 -> B_2, B_2 -> B_3, B_3 -> the next A_0
+                    if (u == 1) FFN_PIECE_B(c, 2, p)
+                    else if (u == 2) FFN_PIECE_B(c, 3, p)
+                    else if (u == 3 && p < 4) {
+                        if (c + 1 < n_chunks) FFN_PIECE_A(c + 1, 0, x_cur, p)
+                        else if (has_next) FFN_PIECE_A(0, 0, x_nxt, p)
+                    }
                 }
 #undef FFN_READ_PAIR
             }
@@ -921,7 +926,9 @@ __global__ __launch_bounds__(512) void ce_ffn_ln_kernel(const half_t* __restrict
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef FFN_ISSUE_A
-#undef FFN_ISSUE_B
+#undef FFN_PIECE_A
+#undef FFN_PIECE_B
+#undef FFN_XSRC
 #undef FFN_LOAD_BIAS
 }
 

@@ -11,6 +11,11 @@ OTHERS=$(ls *.o | grep -v cross_encoder.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/bin/librag_ablation.so /tmp/ce_ablation.o $OTHERS
 echo built ablation
 [ "$1" = "ablation" ] && exit 0
+# fused-FFN probe: phase A's token slices always from tile 0 (L2-hot): is the kernel bound by re-fetching its token tile?
+/opt/rocm/bin/hipcc $FLAGS -DCE_PROBE_FFN_SHARED_X -c cross_encoder.hip -o /tmp/ce_ffn_shared_x.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/bin/librag_ffn_shared_x.so /tmp/ce_ffn_shared_x.o $OTHERS
+echo built ffn_shared_x
+[ "$1" = "ffn" ] && exit 0
 for v in NO_MFMA NO_DMA NO_EPI "NO_MFMA -DCE_PROBE_NO_EPI" "NO_DMA -DCE_PROBE_NO_EPI"; do
   name=$(echo "$v" | tr -d ' ' | sed 's/-DCE_PROBE_/_/g')
   /opt/rocm/bin/hipcc $FLAGS -DCE_PROBE_$v -c cross_encoder.hip -o /tmp/ce_$name.o

@@ -1,0 +1,83 @@
+"""Copies the summaries of tools/r3_measure.sh (gpurun_out/r3m_*) into the tracked profiles/r03_* files that bench_modes.py
+reads `roofline.traffic` from. FETCH_SIZE / WRITE_SIZE are KiB per launch; FETCH_SIZE is doubled for the wide (16 B per lane)
+streaming reads per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); Infinity-Cache hits are counted in it."""
+import csv
+import json
+import os
+import shutil
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
+
+
+def pmc(name):
+    return json.load(open(os.path.join(O, name)))
+
+
+def stats(name):
+    return {r["Name"]: r for r in csv.DictReader(open(os.path.join(O, name)))}
+
+
+def pick(d, sub):
+    return next(v for k, v in d.items() if sub in k)
+
+
+# ---- BM25: `python3 bench.py --mode hybrid --only-hybrid-calls --steps 6 --warmup 1`: 7 rag_hybrid_rrf_dev calls of 1024 queries
+shutil.copy(os.path.join(O, "r3m_hybrid_kernel_stats.csv"), os.path.join(P, "r03_hybrid_kernel_stats.csv"))
+line = json.loads([ln for ln in open(os.path.join(O, "r3m_hybrid_stats.log")) if ln.startswith("{")][-1])
+calls = line["steps"] + line["warmup"]
+ks = stats("r3m_hybrid_kernel_stats.csv")
+fetch, write, tcc = pmc("r3m_hybrid_pmc_FETCH_SIZE.json"), pmc("r3m_hybrid_pmc_WRITE_SIZE.json"), pmc("r3m_hybrid_pmc_TCC_HIT_sum_TCC_MISS_sum.json")
+kern = {}
+for short in ("bm25_range_kernel", "bm25_merge_stage_kernel", "bm25_plan_kernel"):
+    s = pick(ks, short + "(")
+    f, w, t = pick(fetch, short)["FETCH_SIZE"], pick(write, short)["WRITE_SIZE"], pick(tcc, short)
+    per_call = f["launches"] / calls
+    kern[short] = {"launches_per_call": per_call, "avg_us_per_launch": float(s["AverageUs"]), "us_per_call": float(s["TotalDurationUs"]) / calls,
+                   "fetch_bytes_per_call_x2": f["mean"] * 1024 * 2 * per_call, "write_bytes_per_call": w["mean"] * 1024 * per_call,
+                   "l2_hit_rate": t["TCC_HIT_sum"]["mean"] / (t["TCC_HIT_sum"]["mean"] + t["TCC_MISS_sum"]["mean"])}
+us = sum(k["us_per_call"] for k in kern.values())
+traffic = sum(k["fetch_bytes_per_call_x2"] + k["write_bytes_per_call"] for k in kern.values())
+alg = line["bm25"]["postings_touched_per_batch"] * 12.0
+json.dump({
+    "source": "tools/r3_measure.sh bm25pmc on one MI355X (round 3): rocprofv3 --kernel-trace --stats and three separate --pmc passes (FETCH_SIZE | "
+              "WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum) of `python3 bench.py --mode hybrid --only-hybrid-calls --steps 6 --warmup 1`: every BM25 launch "
+              "belongs to one of %d rag_hybrid_rrf_dev calls of 1024 queries (1M docs, nnz 9.5e7, 2048-document ranges x 256 threads, staged "
+              "threshold: 4 range + 4 merge launches and 1 plan launch per call). FETCH_SIZE x2 per MI355X_MICROARCH.md." % calls,
+    "bench_line_of_the_profiled_run": {k: line[k] for k in ("value", "ms_per_step")},
+    "kernels": kern,
+    "per_call": {"bm25_device_us_under_rocprof": us, "algorithmic_bytes": alg, "hbm_traffic_bytes": traffic,
+                 "traffic_over_algorithmic": traffic / alg, "algorithmic_GBs": alg / us * 1e-3, "traffic_GBs": traffic / us * 1e-3},
+    "reading": "The L2 serves %.0f %% of the range kernel's requests (r1's 89 %% was a different kernel: 16384-document ranges); what leaves L2 is "
+               "%.1f GB per 1024-query batch against %.1f GB algorithmic, i.e. the posting stream runs at %.1f TB/s of fabric traffic = %.2f of the "
+               "8 TB/s HBM peak (0.8 of the ~6.3 TB/s a streaming kernel reaches): the BM25 leg is HBM-bound, not L2-bound."
+               % (100 * kern["bm25_range_kernel"]["l2_hit_rate"], traffic / 1e9, alg / 1e9, traffic / us * 1e-6, traffic / us * 1e-6 / 8.0),
+}, open(os.path.join(P, "r03_bm25_pmc.json"), "w"), indent=1)
+
+# ---- cross-encoder: `python3 bench.py --mode rerank`: 3 forwards of 25,600 pairs = 4 activation chunks each, 6 layers
+shutil.copy(os.path.join(O, "r3m_ce_kernel_stats.csv"), os.path.join(P, "r03_ce_kernel_stats.csv"))
+cf, cw = pmc("r3m_ce_pmc_FETCH_SIZE.json"), pmc("r3m_ce_pmc_WRITE_SIZE.json")
+forwards = 3
+ce = {}
+for k, v in cf.items():
+    ce.setdefault(k, {}).update(v)
+for k, v in cw.items():
+    ce.setdefault(k, {}).update(v)
+rd = sum(v["FETCH_SIZE"]["mean"] * v["FETCH_SIZE"]["launches"] for v in ce.values() if "FETCH_SIZE" in v) * 1024 * 2 / forwards
+wr = sum(v["WRITE_SIZE"]["mean"] * v["WRITE_SIZE"]["launches"] for v in ce.values() if "WRITE_SIZE" in v) * 1024 / forwards
+ffn = pick(ce, "ce_ffn_ln")
+json.dump({
+    "source": "tools/r3_measure.sh cepmc on one MI355X (round 3): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) of "
+              "`python3 bench.py --mode rerank` (3 forwards of 25,600 pairs = 4 activation chunks each, 6 layers: 72 launches per layer kernel), "
+              "fused FFN kernel (ce_ffn_ln_kernel) on. KiB per launch; FETCH_SIZE x2 per MI355X_MICROARCH.md; Infinity-Cache hits are counted in FETCH_SIZE.",
+    "per_forward_bytes": {"read_corrected_x2": rd, "write": wr, "total": rd + wr},
+    "note": "Against r2 (profiles/r02_i: 577 GB read + 445 GB written): the writes fall by 40 %% (the 1536-wide FFN intermediate is never stored), "
+            "the counted reads RISE: the fused kernel re-streams its 128-token tile once per 128-feature chunk (12 x per layer), 32 tiles x 192 KiB "
+            "per XCD do not stay in its 4 MiB L2, and FETCH_SIZE counts the re-reads although the Infinity Cache serves them "
+            "(ce_ffn_ln_kernel: %.1f GB fetched per launch = %.1f x its 128-token tiles). DRAM traffic itself is lower than r2's (the h16 round trip is "
+            "gone); the counter cannot tell the two apart. A probe build that streams an L2-hot tile instead (tools/ce_probe_build.sh ffn) is 3 %% "
+            "faster: the re-reads are not what bounds the kernel." % (ffn["FETCH_SIZE"]["mean"] * 2048 / 1e9,
+                                                                       ffn["FETCH_SIZE"]["mean"] * 2048 / (ffn["WRITE_SIZE"]["mean"] * 1024)),
+    "kernels": ce}, open(os.path.join(P, "r03_ce_traffic.json"), "w"), indent=1)
+print("bm25 per call: %.0f us, alg %.2f GB, traffic %.2f GB, L2 hit %.2f" % (us, alg / 1e9, traffic / 1e9, kern["bm25_range_kernel"]["l2_hit_rate"]))
+print("ce per forward: read %.1f GB, write %.1f GB, total %.1f GB" % (rd / 1e9, wr / 1e9, (rd + wr) / 1e9))
