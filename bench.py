@@ -388,6 +388,9 @@ def main():
                                   f"float32 BLAS exact scan + top-{k} (oracle/cpu_baseline.py), {cdt:.2f}s",
                         "recall_at_k_vs_cpu_fp32": round(float(same), 5),
                         "max_abs_score_diff": float(np.abs(vals - got_sc[:qs]).max())}
+        # SURVEY 8d baseline (2): the reference's real SQL, only if a postgres with the `vector` extension exists on this box
+        from oracle.cpu_baseline import pgvector_probe_and_time
+        cpu_baseline["pgvector_sql"] = pgvector_probe_and_time(host_corpus.numpy(), hq.numpy(), k)
 
     out = {
         "metric": "queries/sec (dense cosine top-k=20, 1536-d)", "value": round(Q * args.steps / dt, 1),

@@ -261,6 +261,22 @@ int rag_ce_score_host(rag_handle_t h, const int32_t* input_ids_host, const int32
 int rag_ce_score_dev(rag_handle_t h, const int32_t* input_ids_dev, const int32_t* token_type_ids_dev,
                      const int32_t* lens_dev, int n_pairs, int seq_len, float* logits_out_dev, void* stream);
 
+/* ---- local sentence-embedding model on the device: stands where the reference calls the OpenAI
+ *      embeddings endpoint over HTTP for every query and every document - EmbeddingService._generate_embedding_uncached /
+ *      _generate_batch_uncached (memory/embeddings.py:100-115, 226-246; dimension lookup :312-332). NOT a parity
+ *      replacement: a local encoder produces DIFFERENT vectors than text-embedding-3-small, so an index must be built and
+ *      queried with the same model (outside the 1e-3 contract of the north star; what is pinned is this forward against
+ *      transformers.BertModel). The model is a BERT encoder (the cross-encoder's kernels) behind sentence-transformers'
+ *      Pooling(mean) + Normalize head: tensors as rag_ce_load_host WITHOUT the four pooler / classifier tensors
+ *      (5 + 16 * layers), normalize = 1 L2-normalises the pooled vector (x / max(|x|, 1e-12)).
+ *      rag_embed_*: input_ids / token_type_ids [n_texts][L] int32 (padded), lens[n_texts]; out[n_texts][hidden] float32. */
+int rag_embed_load_host(rag_handle_t h, const rag_ce_config* cfg, const float* const* tensors_host, int n_tensors, int normalize);
+int rag_embed_host(rag_handle_t h, const int32_t* input_ids_host, const int32_t* token_type_ids_host, const int32_t* lens_host,
+                   int n_texts, int seq_len, float* out_host);
+int rag_embed_dev(rag_handle_t h, const int32_t* input_ids_dev, const int32_t* token_type_ids_dev, const int32_t* lens_dev,
+                  int n_texts, int seq_len, float* out_dev, void* stream);
+int rag_embed_dim(rag_handle_t h, int* dim_out);
+
 /* ---- retrieve + rerank in one device-resident call (BASELINE.json configs[3]): the composition of
  *      HybridRetriever.retrieve (rag/retrieval.py:122-212) and CrossEncoderReranker.rerank (rag/reranker.py:320-384:
  *      pairs [query, passage], raw logits, sigmoid, sort desc, [:top_k]) with the passages' token ids resident in HBM.

@@ -96,6 +96,10 @@ _SIGS = {
     "rag_ce_build_pairs_dev": ([_P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
     "rag_rerank_topk_dev": ([_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
     "rag_ce_score_dev": ([_P, _P, _P, _P, C.c_int, C.c_int, _P, _P], C.c_int),
+    "rag_embed_load_host": ([_P, C.POINTER(CeConfig), C.POINTER(_P), C.c_int, C.c_int], C.c_int),
+    "rag_embed_host": ([_P, _P, _P, _P, C.c_int, C.c_int, _P], C.c_int),
+    "rag_embed_dev": ([_P, _P, _P, _P, C.c_int, C.c_int, _P, _P], C.c_int),
+    "rag_embed_dim": ([_P, C.POINTER(C.c_int)], C.c_int),
 }
 
 
@@ -545,6 +549,32 @@ class RagEngine:
         arrs = [_np(t, np.float32) for t in tensors]
         ptrs = (_P * len(arrs))(*[a.ctypes.data for a in arrs])
         self._check(self.lib.rag_ce_load_host(self.h, C.byref(c), ptrs, len(arrs)), "rag_ce_load_host")
+
+    # ---- local embedding model (BERT encoder + mean pooling) ---------------------------------------
+    def embed_load(self, cfg, tensors, normalize=True):
+        """tensors: rag_ce_load_host's order WITHOUT the pooler / classifier (cross_encoder.flatten_state_dict(..., head=False))."""
+        c = CeConfig(cfg["vocab_size"], cfg["hidden"], cfg["layers"], cfg["heads"], cfg["ffn"], cfg["max_pos"],
+                     cfg.get("type_vocab", 2), 0, float(cfg.get("eps", 1e-12)))
+        arrs = [_np(t, np.float32) for t in tensors]
+        ptrs = (_P * len(arrs))(*[a.ctypes.data for a in arrs])
+        self._check(self.lib.rag_embed_load_host(self.h, C.byref(c), ptrs, len(arrs), 1 if normalize else 0), "rag_embed_load_host")
+        self.embed_hidden = int(cfg["hidden"])
+
+    def embed(self, input_ids, token_type_ids, lens):
+        """int32 [n, L], [n, L], [n] (numpy) -> float32 [n, hidden] sentence embeddings."""
+        ids, tt, ln = _np(input_ids, np.int32), _np(token_type_ids, np.int32), _np(lens, np.int32)
+        n, L = ids.shape
+        out = np.empty((n, self.embed_hidden), dtype=np.float32)
+        self._check(self.lib.rag_embed_host(self.h, _ptr(ids), _ptr(tt), _ptr(ln), n, L, _ptr(out)), "rag_embed_host")
+        return out
+
+    def embed_dev(self, input_ids, token_type_ids, lens, out, stream=None):
+        """int32 CUDA tensors [n, L], [n, L], [n] -> float32 out [n, hidden]; asynchronous on `stream`."""
+        import torch
+        n, L = input_ids.shape
+        st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        self._check(self.lib.rag_embed_dev(self.h, C.c_void_p(input_ids.data_ptr()), C.c_void_p(token_type_ids.data_ptr()),
+                                           C.c_void_p(lens.data_ptr()), n, L, C.c_void_p(out.data_ptr()), st), "rag_embed_dev")
 
     def tokens_load(self, tokens, lens):
         """Passage token store: tokens [N, L] int32 WordPiece ids without [CLS]/[SEP], lens [N]; row-aligned with the index."""

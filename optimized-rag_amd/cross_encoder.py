@@ -19,14 +19,17 @@ LAYER_KEYS = ["attention.self.query.weight", "attention.self.query.bias", "atten
               "output.dense.weight", "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias"]
 
 
-def flatten_state_dict(sd, n_layers):
-    """HF BertForSequenceClassification state dict -> the tensor order rag_ce_load_host expects."""
-    names = ["bert.embeddings.word_embeddings.weight", "bert.embeddings.position_embeddings.weight",
-             "bert.embeddings.token_type_embeddings.weight", "bert.embeddings.LayerNorm.weight",
-             "bert.embeddings.LayerNorm.bias"]
+def flatten_state_dict(sd, n_layers, head=True, prefix="bert."):
+    """HF BertForSequenceClassification state dict -> the tensor order rag_ce_load_host expects. head=False: a plain BertModel
+    encoder for rag_embed_load_host (no pooler / classifier; sentence-transformers checkpoints store it without the `bert.`
+    prefix: prefix="")."""
+    names = [prefix + "embeddings.word_embeddings.weight", prefix + "embeddings.position_embeddings.weight",
+             prefix + "embeddings.token_type_embeddings.weight", prefix + "embeddings.LayerNorm.weight",
+             prefix + "embeddings.LayerNorm.bias"]
     for l in range(n_layers):
-        names += [f"bert.encoder.layer.{l}.{k}" for k in LAYER_KEYS]
-    names += ["bert.pooler.dense.weight", "bert.pooler.dense.bias", "classifier.weight", "classifier.bias"]
+        names += [f"{prefix}encoder.layer.{l}.{k}" for k in LAYER_KEYS]
+    if head:
+        names += [prefix + "pooler.dense.weight", prefix + "pooler.dense.bias", "classifier.weight", "classifier.bias"]
     missing = [n for n in names if n not in sd]
     if missing:
         raise KeyError(f"checkpoint lacks {missing[:3]}{'...' if len(missing) > 3 else ''}")

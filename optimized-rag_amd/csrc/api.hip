@@ -39,6 +39,9 @@ int ce_load_host(rag_ctx* h, const rag_ce_config* cfg, const float* const* tenso
 int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L, float* out,
              hipStream_t st, bool host_ptrs);
 void ce_free(rag_ctx* h);
+int embed_load_host(rag_ctx* h, const rag_ce_config* cfg, const float* const* tensors, int n, int normalize);
+int embed_run(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L, float* out, hipStream_t st, bool host_ptrs);
+int embed_dim(const rag_ctx* h);
 void pipeline_free(rag_ctx* h);
 int ce_build_pairs_dev(rag_ctx* h, const int32_t* q_tok_dev, const int32_t* q_len_dev, int Lq, const int64_t* cand_dev, int Q, int pool,
                        int64_t token_id_base, int L_pair, int cls_id, int sep_id, int32_t* ids_out, int32_t* tt_out, int32_t* lens_out,
@@ -616,6 +619,35 @@ int rag_ce_score_dev(rag_handle_t h, const int32_t* ids, const int32_t* tt, cons
     LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return ce_score(h, ids, tt, lens, P, L, out, (hipStream_t)stream, false);
+}
+
+int rag_embed_load_host(rag_handle_t h, const rag_ce_config* cfg, const float* const* tensors, int n, int normalize) {
+    if (!h) return RAG_ERR_ARG;
+    LOCK(h);
+    HIP_TRY(h, hipSetDevice(h->device));
+    return embed_load_host(h, cfg, tensors, n, normalize);
+}
+
+int rag_embed_host(rag_handle_t h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int n_texts, int L, float* out) {
+    if (!h) return RAG_ERR_ARG;
+    LOCK(h);
+    HIP_TRY(h, hipSetDevice(h->device));
+    return embed_run(h, ids, tt, lens, n_texts, L, out, h->stream, true);
+}
+
+int rag_embed_dev(rag_handle_t h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int n_texts, int L, float* out, void* stream) {
+    if (!h) return RAG_ERR_ARG;
+    LOCK(h);
+    HIP_TRY(h, hipSetDevice(h->device));
+    return embed_run(h, ids, tt, lens, n_texts, L, out, (hipStream_t)stream, false);
+}
+
+int rag_embed_dim(rag_handle_t h, int* dim_out) {
+    if (!h || !dim_out) return RAG_ERR_ARG;
+    LOCK(h);
+    ARG_CHECK(h, embed_dim(h) > 0, "no embedding model loaded");
+    *dim_out = embed_dim(h);
+    return RAG_OK;
 }
 
 int rag_mmr_select_host(rag_handle_t h, const float* query, const float* emb, int n, int dim, int top_k, double lambda,

@@ -130,6 +130,7 @@ struct rag_ctx {
     bool attr_dense = false, attr_bm25 = false, attr_ce_gemm = false, attr_ce_gemm_ln = false, attr_ce_ffn = false;
     int attr_ce_attn_lds[3] = {0, 0, 0};
     rag_ce_model* ce = nullptr;
+    rag_ce_model* emb = nullptr;             // sentence-embedding encoder (rag_embed_load_host): the K7 kernels behind a mean-pooling head
 };
 
 #define HIP_TRY(h, expr)                                                                      \

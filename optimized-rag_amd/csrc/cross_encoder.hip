@@ -36,6 +36,9 @@
 
 struct rag_ce_model {
     rag_ce_config cfg;
+    bool embed = false;          // true: sentence-embedding encoder (mean pooling over the tokens, no pooler / classifier head)
+    int normalize = 1;           // embed: L2-normalise the pooled vectors
+    int out_width = 1;           // floats per pair the forward produces: 1 logit, or `hidden` for an embedding model
     // embeddings fp32
     float *word = nullptr, *pos = nullptr, *type = nullptr, *emb_ln_g = nullptr, *emb_ln_b = nullptr;
     struct Layer {
@@ -50,6 +53,7 @@ struct rag_ce_model {
     int64_t ws_tokens = 0;
     int ws_pairs = 0, ws_L = 0;
     float* y32 = nullptr;                              // pre-LayerNorm sums: only the unfused fallback path allocates it
+    int64_t h16_rows = 0;                              // rows of h16 (the FFN intermediate of the two-launch form), grown on demand
     half_t *x16 = nullptr, *q16 = nullptr, *kf16 = nullptr, *vf16 = nullptr, *ctx16 = nullptr, *h16 = nullptr;
     int32_t *ids = nullptr, *tt = nullptr, *lens = nullptr;
     // packed (variable-length) row layout of the current chunk: pair p owns rows [pair_off[p], pair_off[p+1]) where
@@ -660,6 +664,7 @@ __global__ __launch_bounds__(512) void ce_gemm_ln_kernel(const half_t* __restric
 #define FFN_HBUF (64 * 1024)
 #define FFN_LDS (FFN_RING + FFN_HBUF)
 #define FFN_CH 128                                // intermediate features per chunk
+#define FFN_FUSED_MIN_ROWS 131072                 // P x L from which the fused kernel is used (below: the two-launch form)
 template <int TERMS>
 __global__ __launch_bounds__(512) void ce_ffn_ln_kernel(const half_t* __restrict__ W1, const float* __restrict__ b1,
                                                          const half_t* __restrict__ W2, const float* __restrict__ b2, int F,
@@ -1210,6 +1215,35 @@ __global__ __launch_bounds__(256) void ce_pool_classify_kernel(const half_t* __r
     if (tid == 0) logits[pair] = part[0] + part[1] + part[2] + part[3] + bc[0];
 }
 
+// Sentence embedding head (sentence-transformers' Pooling(mean) + Normalize): mean of the last hidden state over the pair's
+// real tokens, optionally L2-normalised. One workgroup per sequence; float32 sums over the split-fp16 stream (hi + lo).
+__global__ __launch_bounds__(256) void ce_meanpool_kernel(const half_t* __restrict__ x16, const int32_t* __restrict__ pair_off,
+                                                           const int32_t* __restrict__ lens, int L, int hidden, int normalize,
+                                                           float* __restrict__ out) {
+    __shared__ float part[4];
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int len = max(1, min(lens[pair], L));
+    const half_t* x = x16 + (size_t)pair_off[pair] * 2 * hidden;
+    float sq = 0.f;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};                               // hidden <= 1024: up to 4 features per thread
+    for (int e = 0, c = tid; c < hidden; c += 256, ++e) {
+        float s = 0.f;
+        for (int t = 0; t < len; ++t) {
+            const half_t* r = x + (size_t)t * 2 * hidden + SPLIT_IDX(c);
+            s += (float)r[0] + (float)r[32];
+        }
+        v[e] = s / (float)len;
+        sq += v[e] * v[e];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if (lane == 0) part[wv] = sq;
+    __syncthreads();
+    const float nrm = sqrtf(part[0] + part[1] + part[2] + part[3]);
+    const float sc = normalize ? 1.0f / fmaxf(nrm, 1e-12f) : 1.0f;  // torch.nn.functional.normalize: x / max(||x||, eps)
+    for (int e = 0, c = tid; c < hidden; c += 256, ++e) out[(size_t)pair * hidden + c] = v[e] * sc;
+}
+
 __global__ void ce_f32_split_kernel(const float* __restrict__ in, half_t* __restrict__ out, int64_t n, int cols) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -1227,18 +1261,24 @@ static void ce_free_ws(rag_ce_model* m) {
     hipFree(m->y32); hipFree(m->x16); hipFree(m->q16); hipFree(m->kf16); hipFree(m->vf16); hipFree(m->ctx16);
     hipFree(m->h16); hipFree(m->ids); hipFree(m->tt); hipFree(m->lens); hipFree(m->logits); hipFree(m->pair_off); hipFree(m->row_pair); hipFree(m->m_packed); hipFree(m->sid); hipFree(m->stt);
     m->y32 = nullptr; m->x16 = m->q16 = m->kf16 = m->vf16 = m->ctx16 = m->h16 = nullptr;
+    m->h16_rows = 0;
     m->ids = m->tt = m->lens = nullptr; m->logits = nullptr;
     m->pair_off = m->row_pair = m->m_packed = nullptr;
     m->sid = m->stt = nullptr;
     m->ws_tokens = 0; m->ws_pairs = 0; m->ws_L = 0;
 }
 
+static void ce_free_model(rag_ce_model** slot) {
+    if (!*slot) return;
+    for (void* p : (*slot)->allocs) hipFree(p);
+    ce_free_ws(*slot);
+    delete *slot;
+    *slot = nullptr;
+}
+
 void ce_free(rag_ctx* h) {
-    if (!h->ce) return;
-    for (void* p : h->ce->allocs) hipFree(p);
-    ce_free_ws(h->ce);
-    delete h->ce;
-    h->ce = nullptr;
+    ce_free_model(&h->ce);
+    ce_free_model(&h->emb);
 }
 
 static int up_f32(rag_ctx* h, rag_ce_model* m, const float* src, size_t n, float** dst) {
@@ -1267,15 +1307,19 @@ static int up_f16_concat(rag_ctx* h, rag_ce_model* m, std::vector<const float*> 
 //  0 word, 1 position, 2 token_type, 3 emb LN weight, 4 emb LN bias,
 //  per layer (16): q.w q.b k.w k.b v.w v.b attn.out.w attn.out.b attn.LN.w attn.LN.b inter.w inter.b out.w out.b out.LN.w out.LN.b
 //  then pooler.w pooler.b classifier.w classifier.b
-int ce_load_host(rag_ctx* h, const rag_ce_config* cfg, const float* const* T, int n) {
+//  (an embedding model - BertModel behind a mean-pooling head - ends after the layers: no pooler / classifier tensors)
+static int ce_load_model(rag_ctx* h, const rag_ce_config* cfg, const float* const* T, int n, bool embed, int normalize, rag_ce_model** slot) {
     ARG_CHECK(h, cfg && T, "ce_load: null");
     ARG_CHECK(h, cfg->hidden % 128 == 0 && cfg->hidden <= 1024 && cfg->ffn % 128 == 0, "ce_load: hidden/ffn must be multiples of 128");
     ARG_CHECK(h, cfg->heads > 0 && cfg->hidden / cfg->heads == 32, "ce_load: head dim must be 32");
-    ARG_CHECK(h, n == 5 + 16 * cfg->layers + 4, "ce_load: wrong tensor count");
-    ce_free(h);
+    ARG_CHECK(h, n == 5 + 16 * cfg->layers + (embed ? 0 : 4), "ce_load: wrong tensor count");
+    ce_free_model(slot);
     rag_ce_model* m = new rag_ce_model();
-    h->ce = m;
+    *slot = m;
     m->cfg = *cfg;
+    m->embed = embed;
+    m->normalize = normalize;
+    m->out_width = embed ? cfg->hidden : 1;
     const size_t H = cfg->hidden, F = cfg->ffn;
     int rc;
     if ((rc = up_f32(h, m, T[0], (size_t)cfg->vocab_size * H, &m->word))) return rc;
@@ -1303,13 +1347,23 @@ int ce_load_host(rag_ctx* h, const rag_ce_config* cfg, const float* const* T, in
         if ((rc = up_f32(h, m, t[14], H, &ly.ln2_g))) return rc;
         if ((rc = up_f32(h, m, t[15], H, &ly.ln2_b))) return rc;
     }
-    const float* const* t = T + 5 + 16 * cfg->layers;
-    if ((rc = up_f32(h, m, t[0], H * H, &m->wp))) return rc;
-    if ((rc = up_f32(h, m, t[1], H, &m->bp))) return rc;
-    if ((rc = up_f32(h, m, t[2], H, &m->wc))) return rc;
-    if ((rc = up_f32(h, m, t[3], 1, &m->bc))) return rc;
+    if (!embed) {
+        const float* const* t = T + 5 + 16 * cfg->layers;
+        if ((rc = up_f32(h, m, t[0], H * H, &m->wp))) return rc;
+        if ((rc = up_f32(h, m, t[1], H, &m->bp))) return rc;
+        if ((rc = up_f32(h, m, t[2], H, &m->wc))) return rc;
+        if ((rc = up_f32(h, m, t[3], 1, &m->bc))) return rc;
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return RAG_OK;
+}
+
+int ce_load_host(rag_ctx* h, const rag_ce_config* cfg, const float* const* T, int n) {
+    return ce_load_model(h, cfg, T, n, false, 0, &h->ce);
+}
+
+int embed_load_host(rag_ctx* h, const rag_ce_config* cfg, const float* const* T, int n, int normalize) {
+    return ce_load_model(h, cfg, T, n, true, normalize, &h->emb);
 }
 
 static const int kAttnL[] = {32, 64, 96, 128, 192, 256, 384, 512};
@@ -1406,11 +1460,21 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
 #define CE_GEMM_LN(T, ...) hipLaunchKernelGGL((ce_gemm_ln_kernel<3>), dim3(n_cu), blk, LNG_LDS, st, __VA_ARGS__);
 #endif
     // the whole FFN in one kernel (ce_ffn_ln_kernel) when the geometry allows; option ce_no_fused_ffn keeps the two-launch form
-    const bool fused_ffn = fused_ln && F % FFN_CH == 0 && !h->opt.ce_no_fused_ffn;
+    // ... from FFN_FUSED_MIN_ROWS padded rows on (tools/ffn_sweep.py): a small batch (one query's 100 pairs = ~140 tiles of 128
+    // tokens for 256 CUs) finishes sooner as two launches whose tiles are finer. ce_no_fused_ffn: 1 = never, -1 = always.
+    const bool fused_ffn = fused_ln && F % FFN_CH == 0 && h->opt.ce_no_fused_ffn <= 0 &&
+                           (h->opt.ce_no_fused_ffn < 0 || (int64_t)P * L >= FFN_FUSED_MIN_ROWS);
     // the FFN intermediate [tokens][ffn] (the largest activation: 12 GB per 2M-token chunk) exists only for the two-launch form
-    if (!fused_ffn && !m->h16) {
-        HIP_TRY(h, hipMalloc(&m->h16, 2 * pp.h * 2));
-        HIP_TRY(h, hipMemsetAsync(m->h16, 0, 2 * pp.h * 2, st));            // padded token rows are read by the GEMM tiles: keep them finite
+    // (sized by what this call needs, not by the workspace: after a large fused batch a single query must not allocate 12 GB)
+    const int64_t h_rows = round_up((int64_t)P * L, CE_BN);
+    if (!fused_ffn && h_rows > m->h16_rows) {
+        HIP_TRY(h, hipStreamSynchronize(st));
+        hipFree(m->h16);
+        m->h16 = nullptr;
+        m->h16_rows = 0;
+        HIP_TRY(h, hipMalloc(&m->h16, (size_t)h_rows * F * 4));
+        HIP_TRY(h, hipMemsetAsync(m->h16, 0, (size_t)h_rows * F * 4, st));   // padded token rows are read by the GEMM tiles: keep them finite
+        m->h16_rows = h_rows;
     }
     if (fused_ffn && !h->attr_ce_ffn) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_ffn_ln_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS));
@@ -1467,7 +1531,11 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
         }
     }
     (void)nullh;
-    hipLaunchKernelGGL(ce_pool_classify_kernel, dim3(P), dim3(256), 0, st, m->x16, m->wp, m->bp, m->wc, m->bc, m->pair_off, H, logits_dev);
+    if (m->embed)
+        hipLaunchKernelGGL(ce_meanpool_kernel, dim3(P), dim3(256), 0, st, (const half_t*)m->x16, (const int32_t*)m->pair_off, lens_dev, L, H,
+                           m->normalize, logits_dev);
+    else
+        hipLaunchKernelGGL(ce_pool_classify_kernel, dim3(P), dim3(256), 0, st, m->x16, m->wp, m->bp, m->wc, m->bc, m->pair_off, H, logits_dev);
     HIP_TRY(h, hipGetLastError());
     return RAG_OK;
 }
@@ -1494,7 +1562,7 @@ static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t s
     HIP_TRY(h, hipMalloc(&m->m_packed, 4));
     HIP_TRY(h, hipMalloc(&m->sid, (size_t)P * L * 4));            // L_in <= L
     HIP_TRY(h, hipMalloc(&m->stt, (size_t)P * L * 4));
-    HIP_TRY(h, hipMalloc(&m->logits, (size_t)P * 4));
+    HIP_TRY(h, hipMalloc(&m->logits, (size_t)P * m->out_width * 4));
     // padded token rows are read by the GEMM tiles: keep them finite
     HIP_TRY(h, hipMemsetAsync(m->x16, 0, 2 * pp.x * 2, st));
     HIP_TRY(h, hipMemsetAsync(m->ctx16, 0, 2 * pp.ctx * 2, st));
@@ -1517,11 +1585,11 @@ __global__ void ce_pad_tokens_kernel(const int32_t* __restrict__ in_ids, const i
     tt[i] = t < L_in ? in_tt[(size_t)p * L_in + t] : 0;
 }
 
-int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L_in, float* out,
-             hipStream_t st, bool host_ptrs) {
-    ARG_CHECK(h, h->ce != nullptr, "no cross-encoder loaded");
+// out: [P][m->out_width] floats (logits of a cross-encoder, pooled vectors of an embedding model)
+static int ce_run(rag_ctx* h, rag_ce_model* m, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L_in, float* out,
+                  hipStream_t st, bool host_ptrs) {
     ARG_CHECK(h, ids && tt && lens && out && P > 0 && L_in > 0, "ce_score: bad arguments");
-    rag_ce_model* m = h->ce;
+    const size_t ow = (size_t)m->out_width;
     ARG_CHECK(h, L_in <= m->cfg.max_pos && L_in <= 512, "ce_score: sequence longer than max_position_embeddings/512");
     int L = 0;
     for (int c : kAttnL) if (c >= L_in) { L = c; break; }
@@ -1539,7 +1607,7 @@ int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* l
         // host arrays are staged chunk by chunk; device arrays are read (ids, lens) and written (logits) where they are: four
         // small copies less per chunk, 45 us of a single-query call
         const int32_t *src_ids = ids + (size_t)p0 * L_in, *src_tt = tt + (size_t)p0 * L_in, *lens_dev = lens + p0;
-        float* logits_dev = out + p0;
+        float* logits_dev = out + (size_t)p0 * ow;
         if (host_ptrs) {
             HIP_TRY(h, hipMemcpyAsync(sid, src_ids, (size_t)pc * L_in * 4, kin, st));
             HIP_TRY(h, hipMemcpyAsync(stt, src_tt, (size_t)pc * L_in * 4, kin, st));
@@ -1550,7 +1618,7 @@ int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* l
         hipLaunchKernelGGL(ce_pad_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src_ids, src_tt, pc, L_in, L, m->ids, m->tt);
         rc = ce_forward_chunk(h, m, pc, L, st, lens_dev, logits_dev);
         if (rc) break;
-        if (host_ptrs) HIP_TRY(h, hipMemcpyAsync(out + p0, m->logits, (size_t)pc * 4, kout, st));
+        if (host_ptrs) HIP_TRY(h, hipMemcpyAsync(out + (size_t)p0 * ow, m->logits, (size_t)pc * ow * 4, kout, st));
     }
     if (!rc) rc = prof_end(h, 2, st);
     // device-pointer calls stay asynchronous on the caller's stream (all buffers belong to the model workspace);
@@ -1563,3 +1631,17 @@ int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* l
     }
     return RAG_OK;
 }
+
+int ce_score(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L_in, float* out,
+             hipStream_t st, bool host_ptrs) {
+    ARG_CHECK(h, h->ce != nullptr, "no cross-encoder loaded");
+    return ce_run(h, h->ce, ids, tt, lens, P, L_in, out, st, host_ptrs);
+}
+
+int embed_run(rag_ctx* h, const int32_t* ids, const int32_t* tt, const int32_t* lens, int P, int L_in, float* out, hipStream_t st,
+              bool host_ptrs) {
+    ARG_CHECK(h, h->emb != nullptr, "no embedding model loaded");
+    return ce_run(h, h->emb, ids, tt, lens, P, L_in, out, st, host_ptrs);
+}
+
+int embed_dim(const rag_ctx* h) { return h->emb ? h->emb->cfg.hidden : -1; }

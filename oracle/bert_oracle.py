@@ -72,6 +72,24 @@ def forward_logits(w, cfg, input_ids, token_type_ids, lens, dtype=np.float64, fa
     """[P,L] ids, [P] valid lengths -> [P] raw logits (what CrossEncoder.predict returns for this checkpoint).
     fast_erf: scipy.special.erf instead of the per-element math.erf (same function to ~1 ulp; tests/test_oracle_bert.py
     bounds the difference) so that hundreds of 256-token pairs finish in seconds."""
+    W, x = forward_hidden(w, cfg, input_ids, token_type_ids, lens, dtype, fast_erf)
+    pooled = np.tanh(x[:, 0] @ W["bert.pooler.dense.weight"].T + W["bert.pooler.dense.bias"])
+    return (pooled @ W["classifier.weight"].T + W["classifier.bias"])[:, 0]
+
+
+def sentence_embeddings(w, cfg, input_ids, token_type_ids, lens, normalize=True, dtype=np.float64, fast_erf=False):
+    """sentence-transformers' Pooling(mean) + Normalize over the BERT encoder: mean of the last hidden state over the real
+    tokens, then x / max(|x|, 1e-12) (torch.nn.functional.normalize). The pooler / classifier weights are not used."""
+    _, x = forward_hidden(w, cfg, input_ids, token_type_ids, lens, dtype, fast_erf)
+    ok = (np.arange(x.shape[1])[None, :] < np.asarray(lens)[:, None]).astype(dtype)[:, :, None]
+    pooled = (x * ok).sum(1) / np.maximum(ok.sum(1), 1e-9)
+    if normalize:
+        pooled = pooled / np.maximum(np.linalg.norm(pooled, axis=1, keepdims=True), 1e-12)
+    return pooled
+
+
+def forward_hidden(w, cfg, input_ids, token_type_ids, lens, dtype=np.float64, fast_erf=False):
+    """The encoder: (weights as `dtype`, last hidden state [P, L, H])."""
     erf = _erf
     if fast_erf:
         from scipy.special import erf
@@ -102,5 +120,4 @@ def forward_logits(w, cfg, input_ids, token_type_ids, lens, dtype=np.float64, fa
         h = 0.5 * h * (1.0 + erf(h / math.sqrt(2.0)))
         o = h @ W[p + "output.dense.weight"].T + W[p + "output.dense.bias"]
         x = _ln(o + x, W[p + "output.LayerNorm.weight"], W[p + "output.LayerNorm.bias"], cfg["eps"])
-    pooled = np.tanh(x[:, 0] @ W["bert.pooler.dense.weight"].T + W["bert.pooler.dense.bias"])
-    return (pooled @ W["classifier.weight"].T + W["classifier.bias"])[:, 0]
+    return W, x

@@ -167,3 +167,60 @@ def python_loop_mmr(q, embs, k, lam):
         selected.append(best)
         remaining.remove(best)
     return time.perf_counter() - t0, selected
+
+
+def pgvector_probe_and_time(corpus, queries, k, sample_rows=200_000, timeout_s=120):
+    """SURVEY 8d baseline (2): when - and only when - a `postgres` server binary WITH the `vector` extension is found on this
+    box at run time, time the reference's real statement, `ORDER BY embedding <=> $1 LIMIT k` as a sequential scan
+    (/root/reference/rag/document_store.py:448-460 without the HNSW index), in a throw-away cluster under /tmp. Absent in the
+    build container and on the GPU boxes of this pool: the function then says what it looked for. corpus [N, D] / queries
+    [Q, D] float32 numpy arrays; a bounded prefix of the corpus is loaded. Returns a dict for the bench line."""
+    import shutil
+    import subprocess
+    import tempfile
+    need = {b: shutil.which(b) for b in ("postgres", "initdb", "pg_ctl", "psql", "pg_config")}
+    missing = [b for b, p in need.items() if p is None]
+    if missing:
+        return {"found": False, "looked_for": sorted(need), "missing": missing}
+    try:
+        share = subprocess.run([need["pg_config"], "--sharedir"], capture_output=True, text=True, timeout=10).stdout.strip()
+    except (OSError, subprocess.SubprocessError) as e:
+        return {"found": False, "error": f"pg_config: {e}"}
+    if not os.path.exists(os.path.join(share, "extension", "vector.control")):
+        return {"found": False, "postgres": need["postgres"], "missing": ["extension/vector.control (pgvector)"]}
+    n = min(int(sample_rows), corpus.shape[0])
+    d = tempfile.mkdtemp(prefix="rag_pg_")
+    sock, data = d, os.path.join(d, "data")
+    run = lambda cmd, **kw: subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, **kw)
+    psql = [need["psql"], "-h", sock, "-d", "postgres", "-v", "ON_ERROR_STOP=1", "-qAt"]
+    try:
+        r = run([need["initdb"], "-D", data, "-A", "trust"])
+        if r.returncode:
+            return {"found": True, "error": "initdb: " + r.stderr[-300:]}
+        r = run([need["pg_ctl"], "-D", data, "-o", f"-k {sock} -c listen_addresses='' -c shared_buffers=1GB -c max_parallel_workers_per_gather={effective_cores()}",
+                 "-w", "start"])
+        if r.returncode:
+            return {"found": True, "error": "pg_ctl start: " + r.stderr[-300:]}
+        D = corpus.shape[1]
+        rows = "\n".join("%d\t[%s]" % (i, ",".join("%.7g" % x for x in corpus[i])) for i in range(n))
+        r = run(psql + ["-c", f"CREATE EXTENSION vector; CREATE TABLE c (id bigint, embedding vector({D}));"])
+        if r.returncode:
+            return {"found": True, "error": "create: " + r.stderr[-300:]}
+        r = subprocess.run(psql + ["-c", "COPY c FROM STDIN"], input=rows, capture_output=True, text=True, timeout=timeout_s)
+        if r.returncode:
+            return {"found": True, "error": "copy: " + r.stderr[-300:]}
+        nq = min(8, queries.shape[0])
+        t0 = time.perf_counter()
+        for qi in range(nq):
+            lit = "[" + ",".join("%.7g" % x for x in queries[qi]) + "]"
+            r = run(psql + ["-c", f"SELECT id FROM c ORDER BY embedding <=> '{lit}'::vector LIMIT {int(k)};"])
+            if r.returncode:
+                return {"found": True, "error": "query: " + r.stderr[-300:]}
+        dt = time.perf_counter() - t0
+        return {"found": True, "value": round(nq / dt, 3), "unit": "queries/sec", "kind": "reference",
+                "sample": f"{nq} queries, sequential `ORDER BY embedding <=> q LIMIT {k}` over the first {n} rows ({dt:.2f}s, psql round trips included)"}
+    except (OSError, subprocess.SubprocessError) as e:
+        return {"found": True, "error": f"{type(e).__name__}: {e}"}
+    finally:
+        subprocess.run([need["pg_ctl"], "-D", data, "-m", "immediate", "stop"], capture_output=True, timeout=60)
+        shutil.rmtree(d, ignore_errors=True)

@@ -217,3 +217,13 @@ def test_fused_ffn_kernel_equals_the_two_launch_form(eng):
     sample = [0, 1, 15, 16, 39, 40, 59, 60, 1500, P - 1]
     exp = B.forward_logits(w, cfg, ids[sample].astype(np.int64), tt[sample].astype(np.int64), lens[sample], fast_erf=True)
     assert np.abs(f[sample] - exp).max() < LOGIT_TOL, (f[sample], exp)
+    # small batches take the two-launch form by default (FFN_FUSED_MIN_ROWS); forced through the fused kernel (-1) a 70-pair
+    # batch - fewer tiles than CUs, the last tile partial - still gives the same bits
+    small = torch.empty((70,), dtype=torch.float32, device="cuda")
+    eng.set_option("ce_no_fused_ffn", -1)
+    try:
+        eng.ce_score_dev(d_ids[:70].contiguous(), d_tt[:70].contiguous(), d_lens[:70].contiguous(), small)
+        torch.cuda.synchronize()
+    finally:
+        eng.set_option("ce_no_fused_ffn", 0)
+    np.testing.assert_array_equal(small.cpu().numpy(), p[:70])
