@@ -664,7 +664,7 @@ __global__ __launch_bounds__(512) void ce_gemm_ln_kernel(const half_t* __restric
 #define FFN_HBUF (64 * 1024)
 #define FFN_LDS (FFN_RING + FFN_HBUF)
 #define FFN_CH 128                                // intermediate features per chunk
-#define FFN_FUSED_MIN_ROWS 131072                 // P x L from which the fused kernel is used (below: the two-launch form)
+#define FFN_FUSED_MIN_ROWS (5120 * 256)            // P x L from which the fused kernel is used (below: the two-launch form)
 template <int TERMS>
 __global__ __launch_bounds__(512) void ce_ffn_ln_kernel(const half_t* __restrict__ W1, const float* __restrict__ b1,
                                                          const half_t* __restrict__ W2, const float* __restrict__ b2, int F,
@@ -1460,7 +1460,8 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
 #define CE_GEMM_LN(T, ...) hipLaunchKernelGGL((ce_gemm_ln_kernel<3>), dim3(n_cu), blk, LNG_LDS, st, __VA_ARGS__);
 #endif
     // the whole FFN in one kernel (ce_ffn_ln_kernel) when the geometry allows; option ce_no_fused_ffn keeps the two-launch form
-    // ... from FFN_FUSED_MIN_ROWS padded rows on (tools/ffn_sweep.py): a small batch (one query's 100 pairs = ~140 tiles of 128
+    // ... from FFN_FUSED_MIN_ROWS padded rows on (tools/ffn_sweep.py, forward ms fused | two-launch: 100 pairs 2.03 | 1.92, 400
+    // 6.51 | 5.99, 1600 23.2 | 22.7, 3200 44.8 | 44.6, 6400 88.2 | 88.9): a small batch (one query's 100 pairs = ~140 tiles of 128
     // tokens for 256 CUs) finishes sooner as two launches whose tiles are finer. ce_no_fused_ffn: 1 = never, -1 = always.
     const bool fused_ffn = fused_ln && F % FFN_CH == 0 && h->opt.ce_no_fused_ffn <= 0 &&
                            (h->opt.ce_no_fused_ffn < 0 || (int64_t)P * L >= FFN_FUSED_MIN_ROWS);
