@@ -120,7 +120,7 @@ int rag_destroy(rag_handle_t h) {
     ce_free(h);
     pipeline_free(h);
     hipFree(h->q32); hipFree(h->q16); hipFree(h->cand); hipFree(h->cnt); hipFree(h->tau); hipFree(h->bound);
-    hipFree(h->n_sorted); hipFree(h->exact); hipFree(h->flag); hipFree(h->stats); hipFree(h->stage);
+    hipFree(h->n_sorted); hipFree(h->exact); hipFree(h->flag); hipFree(h->scan_list); hipFree(h->stats); hipFree(h->stage);
     hipFree(h->temporal); hipFree(h->lin_ws);
     hipFree(h->q16b); hipFree(h->candb); hipFree(h->cntb); hipFree(h->taub); hipFree(h->boundb); hipFree(h->n_sortedb); hipFree(h->ovf_list);
     for (auto& p : h->prof)

@@ -87,7 +87,8 @@ struct rag_ctx {
     float* bound = nullptr;          // [ws_qpad]   -inf, or +inf once the candidate buffer overflowed (sticky)
     int* n_sorted = nullptr;         // [ws_qpad]   survivors left in cand[] after the final select
     double* exact = nullptr;         // [ws_qpad][RAG_CAND_CAP] float64 rescored cosines
-    int* flag = nullptr;             // [ws_qpad]   0 done, 1 needs wide ranking, 2 needs exact scan, 3 scanned
+    int* flag = nullptr;             // [ws_qpad]   0 done, 2 needs exact scan, 3 scanned
+    int* scan_list = nullptr;        // [ws_qpad]   queries flagged 2 (appended by finalize_kernel; count = stats[7])
     int* stats = nullptr;            // [8] device counters
     // second pass for overflowed queries: one 256-query tile of its own (dense.hip)
     half_t* q16b = nullptr;

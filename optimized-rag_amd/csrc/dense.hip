@@ -452,7 +452,7 @@ __global__ __launch_bounds__(512) void dense_emit_persist_kernel(int n_vblocks, 
 // so the common small case runs with a quarter of the registers (3 of the 4 selects of a 1M-row search: 16 -> 5 us each).
 template <int NREG>
 __device__ __forceinline__ void select_wave(uint64_t* __restrict__ c, uint64_t* __restrict__ spill, int n_in, int k, float two_eps,
-                                            float tau_in, int lane, float& tau_new, int& n_top) {
+                                            float tau_in, int lane, float& tau_new, int& n_top, uint64_t* __restrict__ copy_to) {
     // keys: first NREG*64 in registers (element e*64 + lane), the rest (rare) in this wave's LDS slice
     uint64_t kreg[NREG];
 #pragma unroll
@@ -490,7 +490,10 @@ __device__ __forceinline__ void select_wave(uint64_t* __restrict__ c, uint64_t* 
         const uint64_t key = kreg[e];
         const bool top = key != 0ull && key >= cut;
         const uint64_t bt = __ballot(top);
-        if (top) c[n_top + __popcll(bt & lt_mask)] = key;
+        if (top) {
+            c[n_top + __popcll(bt & lt_mask)] = key;
+            if (copy_to != nullptr) copy_to[n_top + __popcll(bt & lt_mask)] = key;
+        }
         n_top += __popcll(bt);
     }
     for (int i0 = 0; i0 < n_spill; i0 += 64) {
@@ -498,39 +501,63 @@ __device__ __forceinline__ void select_wave(uint64_t* __restrict__ c, uint64_t* 
         const uint64_t key = i < n_spill ? spill[i] : 0ull;
         const bool top = key != 0ull && key >= cut;
         const uint64_t bt = __ballot(top);
-        if (top) c[n_top + __popcll(bt & lt_mask)] = key;
+        if (top) {
+            c[n_top + __popcll(bt & lt_mask)] = key;
+            if (copy_to != nullptr) copy_to[n_top + __popcll(bt & lt_mask)] = key;
+        }
         n_top += __popcll(bt);
     }
 }
 
+// Two jobs ride on it so that an uneventful search launches nothing extra (each idle launch costs ~3-5 us on a small shard):
+//   ovf_list / ovf_count (the FINAL first-pass select): queries whose buffer overflowed at any stage append themselves
+//     (count may exceed the RAG_TILE slots of the list: readers clamp);
+//   sc_list (the second-pass select): a re-emission that fitted replaces the query's candidate list - the compacted keys are
+//     written to the query's own buffer straight from registers - and clears its overflow mark.
+struct select_extra {
+    int* ovf_list; int* ovf_count;
+    const int* sc_list; uint64_t* sc_cand; int* sc_n_sorted; float* sc_bound;
+};
 __global__ __launch_bounds__(256) void select_kernel(uint64_t* __restrict__ cand, unsigned* __restrict__ cnt,
                                                       float* __restrict__ tau, float* __restrict__ bound,
                                                       int* __restrict__ n_sorted, int* __restrict__ stats, int n_queries,
                                                       int dense0_rows, int k, float two_eps, int final_stage,
-                                                      const int* __restrict__ active_count) {
+                                                      const int* __restrict__ active_count, select_extra ex) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wv;
     if (q >= n_queries) return;                              // whole wave exits; no block-level sync is used
-    if (active_count != nullptr && q >= *active_count) return;   // second pass: only the re-emitted queries
+    if (active_count != nullptr && q >= min(*active_count, RAG_TILE)) return;   // second pass: only the re-emitted queries
     uint64_t* spill = reinterpret_cast<uint64_t*>(smem) + (size_t)wv * (RAG_CAND_CAP - SEL_REG * 64);
     uint64_t* c = cand + (size_t)q * RAG_CAND_CAP;
     const unsigned emitted = cnt[q];
     const bool overflow = dense0_rows == 0 && emitted > RAG_CAND_CAP;
     const int n_in = dense0_rows > 0 ? dense0_rows : (int)min(emitted, (unsigned)RAG_CAND_CAP);
-    if (overflow && lane == 0 && stats != nullptr) atomicAdd(&stats[4], 1);
+    if (overflow && lane == 0 && stats != nullptr && ex.sc_list == nullptr) atomicAdd(&stats[4], 1);   // first-pass overflow events
     const float tau_in = tau[q];
     float tau_new;
     int n_top;
-    if (n_in <= SEL_REG_SMALL * 64) select_wave<SEL_REG_SMALL>(c, spill, n_in, k, two_eps, tau_in, lane, tau_new, n_top);
-    else select_wave<SEL_REG>(c, spill, n_in, k, two_eps, tau_in, lane, tau_new, n_top);
+    const int dst_q = ex.sc_list != nullptr ? ex.sc_list[q] : 0;
+    uint64_t* copy_to = (ex.sc_list != nullptr && !overflow) ? ex.sc_cand + (size_t)dst_q * RAG_CAND_CAP : nullptr;
+    if (n_in <= SEL_REG_SMALL * 64) select_wave<SEL_REG_SMALL>(c, spill, n_in, k, two_eps, tau_in, lane, tau_new, n_top, copy_to);
+    else select_wave<SEL_REG>(c, spill, n_in, k, two_eps, tau_in, lane, tau_new, n_top, copy_to);
     if (lane == 0) {
         // bound[] starts at -inf; an overflow at ANY stage lost candidates for good -> sticky +inf: the query goes to the
-        // exact scan.
+        // second pass, and from there to the exact scan if it overflows again.
+        const bool lost = overflow || bound[q] == INFINITY;
         if (overflow) bound[q] = INFINITY;
         if (final_stage) n_sorted[q] = n_top;
         cnt[q] = (unsigned)n_top;
         tau[q] = tau_new;
+        if (ex.ovf_list != nullptr && final_stage && lost) {
+            const int o = atomicAdd(ex.ovf_count, 1);
+            if (o < RAG_TILE) ex.ovf_list[o] = q;
+        }
+        if (copy_to != nullptr) {                            // second pass fitted: the query is proven again
+            ex.sc_n_sorted[dst_q] = n_top;
+            ex.sc_bound[dst_q] = -INFINITY;
+            atomicAdd(&stats[5], 1);
+        }
     }
 }
 
@@ -571,14 +598,19 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
     }
 }
 
-// order the survivors by (exact desc, row asc) and write the top-k. Up to RAG_MAX_K survivors are ranked here; more
-// (tight clusters / many duplicates) go to wide_kernel, an overflowed buffer to the exact scan.
+// order the survivors by (exact desc, row asc) and write the top-k. Up to RAG_MAX_K survivors are ranked in one step; more
+// (tight clusters / many duplicates: up to the buffer's 4096) are ranked by the same workgroup in blocks of 256 through the
+// same LDS (each thread keeps up to 16 of the entries and counts, block by block, how many others come before each); a query
+// whose buffer overflowed in the second pass too appends itself to the exact-scan list. (Round 2 used three more launches for
+// this - wide_kernel and a flag-list kernel - that an uneventful search paid for without using them.)
+#define FIN_PER_THREAD (RAG_CAND_CAP / 256)
 __global__ __launch_bounds__(256) void finalize_kernel(const uint64_t* __restrict__ cand, const int* __restrict__ n_sorted,
                                                         const double* __restrict__ exact, const float* __restrict__ bound,
                                                         const int64_t* __restrict__ ids, int64_t id_base, int k,
                                                         int force_level, int64_t* __restrict__ ids_out,
                                                         int32_t* __restrict__ rows_out, double* __restrict__ scores_out,
-                                                        int* __restrict__ flag, int* __restrict__ stats) {
+                                                        int* __restrict__ flag, int* __restrict__ stats,
+                                                        int* __restrict__ scan_list, int* __restrict__ scan_count) {
     __shared__ double sc[RAG_MAX_K];
     __shared__ uint32_t rw[RAG_MAX_K];
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -589,13 +621,59 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint64_t* __restric
         scores_out[(size_t)q * k + i] = 0.0;
     }
     const bool overflowed = bound[q] == INFINITY;
-    if (overflowed || m > RAG_MAX_K || force_level > 0) {
-        if (tid == 0) flag[q] = (overflowed || force_level > 1) ? 2 : 1;
+    if (overflowed || force_level > 1) {
+        if (tid == 0) {
+            flag[q] = 2;
+            scan_list[atomicAdd(scan_count, 1)] = q;
+        }
+        return;
+    }
+    const uint64_t* c = cand + (size_t)q * RAG_CAND_CAP;
+    const double* ex = exact + (size_t)q * RAG_CAND_CAP;
+    if (m > RAG_MAX_K || force_level > 0) {
+        double e[FIN_PER_THREAD];
+        uint32_t r[FIN_PER_THREAD];
+        int rank[FIN_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < FIN_PER_THREAD; ++j) {
+            const int i = j * 256 + tid;
+            e[j] = i < m ? ex[i] : 0.0;
+            r[j] = i < m ? key_row(c[i]) : 0u;
+            rank[j] = 0;
+        }
+        for (int u0 = 0; u0 < m; u0 += RAG_MAX_K) {
+            const int nu = min(RAG_MAX_K, m - u0);
+            __syncthreads();                               // the previous block's readers are done
+            if (tid < nu) {
+                sc[tid] = ex[u0 + tid];
+                rw[tid] = key_row(c[u0 + tid]);
+            }
+            __syncthreads();
+            for (int u = 0; u < nu; ++u) {
+                const double su = sc[u];
+                const uint32_t ru = rw[u];
+#pragma unroll
+                for (int j = 0; j < FIN_PER_THREAD; ++j) rank[j] += (su > e[j]) || (su == e[j] && ru < r[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FIN_PER_THREAD; ++j) {
+            const int i = j * 256 + tid;
+            if (i < m && rank[j] < k) {
+                ids_out[(size_t)q * k + rank[j]] = ids ? ids[r[j]] : id_base + (int64_t)r[j];
+                if (rows_out) rows_out[(size_t)q * k + rank[j]] = (int32_t)r[j];
+                scores_out[(size_t)q * k + rank[j]] = e[j];
+            }
+        }
+        if (tid == 0) {
+            flag[q] = 0;
+            atomicAdd(&stats[1], 1);
+        }
         return;
     }
     if (tid < m) {
-        sc[tid] = exact[(size_t)q * RAG_CAND_CAP + tid];
-        rw[tid] = key_row(cand[(size_t)q * RAG_CAND_CAP + tid]);
+        sc[tid] = ex[tid];
+        rw[tid] = key_row(c[tid]);
     }
     __syncthreads();
     if (tid < m) {
@@ -612,43 +690,6 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint64_t* __restric
     if (tid == 0) {
         flag[q] = 0;
         atomicAdd(&stats[0], 1);
-    }
-}
-
-// Wide path: more than RAG_MAX_K survivors (already rescored): rank all of them (up to the buffer capacity).
-__global__ __launch_bounds__(512) void wide_kernel(const uint64_t* __restrict__ cand, const int* __restrict__ n_sorted,
-                                                    const double* __restrict__ exact, const int64_t* __restrict__ ids,
-                                                    int64_t id_base, int k, int64_t* __restrict__ ids_out,
-                                                    int32_t* __restrict__ rows_out, double* __restrict__ scores_out,
-                                                    int* __restrict__ flag, int* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* sc = reinterpret_cast<double*>(smem);                       // [cap]
-    uint32_t* rw = reinterpret_cast<uint32_t*>(smem + RAG_CAND_CAP * 8);   // [cap]
-    const int q = blockIdx.x, tid = threadIdx.x;
-    if (flag[q] != 1) return;
-    const int n = n_sorted[q];
-    const uint64_t* c = cand + (size_t)q * RAG_CAND_CAP;
-    const double* ex = exact + (size_t)q * RAG_CAND_CAP;
-    for (int i = tid; i < n; i += 512) {
-        sc[i] = ex[i];
-        rw[i] = key_row(c[i]);
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += 512) {
-        const double e = sc[i];
-        const uint32_t r = rw[i];
-        int rank = 0;
-        for (int u = 0; u < n && rank < k; ++u) rank += (sc[u] > e) || (sc[u] == e && rw[u] < r);
-        if (rank < k) {
-            ids_out[(size_t)q * k + rank] = ids ? ids[r] : id_base + (int64_t)r;
-            if (rows_out) rows_out[(size_t)q * k + rank] = (int32_t)r;
-            scores_out[(size_t)q * k + rank] = e;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        flag[q] = 0;
-        atomicAdd(&stats[1], 1);
     }
 }
 
@@ -679,26 +720,6 @@ __device__ __forceinline__ void bitonic_sort_pairs(uint64_t* k1, uint32_t* k2, i
             __syncthreads();
         }
     }
-}
-
-// queries with flag == want -> list (in query order is not required), count. One workgroup. Slots [count, cap) are set to
-// query 0: the list is read as a query MAP by the fused re-emission (bias row of slot f), and a dead slot (threshold +inf, never
-// emits) must still index inside the bias buffer - a stale entry of an earlier, larger batch would not.
-__global__ __launch_bounds__(256) void flag_list_kernel(const int* __restrict__ flag, const float* __restrict__ bound, int Q,
-                                                         int want, int cap, int* __restrict__ list, int* __restrict__ count) {
-    __shared__ int n;
-    if (threadIdx.x == 0) n = 0;
-    __syncthreads();
-    for (int q = threadIdx.x; q < Q; q += 256) {
-        const bool hit = flag != nullptr ? flag[q] == want : bound[q] == INFINITY;
-        if (hit) {
-            const int o = atomicAdd(&n, 1);
-            if (o < cap) list[o] = q;
-        }
-    }
-    __syncthreads();
-    for (int o = min(n, cap) + threadIdx.x; o < cap; o += 256) list[o] = 0;
-    if (threadIdx.x == 0) *count = min(n, cap);
 }
 
 __global__ __launch_bounds__(256) void scan_chunk_kernel(const float* __restrict__ q32, const float* __restrict__ emb32,
@@ -795,13 +816,16 @@ __global__ __launch_bounds__(256) void scan_merge_kernel(const uint64_t* __restr
 // above it is almost always small again, so those queries (up to 256 per search) are re-emitted over the whole corpus with
 // that tau into a fresh buffer by the same MFMA kernel; only if THAT overflows too does the query go to the float64 scan.
 // gather: workgroup f copies the fp16 query row and tau of the f-th overflowed query; unused slots get tau = +inf.
-__global__ __launch_bounds__(256) void overflow_gather_kernel(const int* __restrict__ list, const int* __restrict__ count,
+// (the list was appended to by the final select; its dead slots are pointed at query 0 here: the fused re-emission reads the
+// bias row of every slot through it, and a stale entry of an earlier, larger batch would index outside the bias buffer)
+__global__ __launch_bounds__(256) void overflow_gather_kernel(int* __restrict__ list, const int* __restrict__ count,
                                                                const half_t* __restrict__ q16, const float* __restrict__ tau, int Dp,
                                                                half_t* __restrict__ q16b, float* __restrict__ taub,
                                                                float* __restrict__ boundb, unsigned* __restrict__ cntb) {
     const int f = blockIdx.x;
-    const bool live = f < *count;
+    const bool live = f < min(*count, RAG_TILE);
     if (threadIdx.x == 0) {
+        if (!live) list[f] = 0;
         taub[f] = live ? tau[list[f]] : INFINITY;
         boundb[f] = -INFINITY;
         cntb[f] = 0u;
@@ -810,23 +834,6 @@ __global__ __launch_bounds__(256) void overflow_gather_kernel(const int* __restr
     const half8* src = reinterpret_cast<const half8*>(q16 + (size_t)list[f] * Dp);
     half8* dst = reinterpret_cast<half8*>(q16b + (size_t)f * Dp);
     for (int i = threadIdx.x; i < Dp / 8; i += 256) dst[i] = src[i];
-}
-
-// scatter: a second pass that did not overflow replaces the query's candidate list and clears its overflow mark
-__global__ __launch_bounds__(256) void overflow_scatter_kernel(const int* __restrict__ list, const int* __restrict__ count,
-                                                                const uint64_t* __restrict__ candb, const int* __restrict__ n_sortedb,
-                                                                const float* __restrict__ boundb, uint64_t* __restrict__ cand,
-                                                                int* __restrict__ n_sorted, float* __restrict__ bound,
-                                                                int* __restrict__ stats) {
-    const int f = blockIdx.x;
-    if (f >= *count || boundb[f] == INFINITY) return;
-    const int q = list[f], m = n_sortedb[f];
-    for (int i = threadIdx.x; i < m; i += 256) cand[(size_t)q * RAG_CAND_CAP + i] = candb[(size_t)f * RAG_CAND_CAP + i];
-    if (threadIdx.x == 0) {
-        n_sorted[q] = m;
-        bound[q] = -INFINITY;
-        atomicAdd(&stats[5], 1);
-    }
 }
 
 // ---- linear fusion over the resident index (rag_hybrid_linear_dev) -------------------------------------------------------
@@ -907,7 +914,7 @@ __global__ __launch_bounds__(256) void linear_components_kernel(const float* __r
 
 // per-search state in one launch: thresholds / proof bounds to -inf, candidate counters and statistics to 0
 __global__ void search_init_kernel(float* __restrict__ tau, float* __restrict__ bound, unsigned* __restrict__ cnt,
-                                   int* __restrict__ stats, int n) {
+                                   int* __restrict__ stats, int* __restrict__ ovf_count, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         tau[i] = -INFINITY;
@@ -915,6 +922,7 @@ __global__ void search_init_kernel(float* __restrict__ tau, float* __restrict__ 
         cnt[i] = 0u;
     }
     if (i < 8) stats[i] = 0;
+    if (i == 0) *ovf_count = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -923,7 +931,7 @@ __global__ void search_init_kernel(float* __restrict__ tau, float* __restrict__ 
 static int ensure_workspace(rag_ctx* h, int Q, hipStream_t st) {
     if (Q <= h->ws_q) return RAG_OK;
     hipFree(h->q32); hipFree(h->q16); hipFree(h->cand); hipFree(h->cnt); hipFree(h->tau); hipFree(h->bound);
-    hipFree(h->n_sorted); hipFree(h->exact); hipFree(h->flag);
+    hipFree(h->n_sorted); hipFree(h->exact); hipFree(h->flag); hipFree(h->scan_list);
     h->ws_q = 0;
     const int64_t qpad = round_up(Q, RAG_TILE);
     HIP_TRY(h, hipMalloc(&h->q32, (size_t)Q * h->dim * sizeof(float)));
@@ -935,6 +943,7 @@ static int ensure_workspace(rag_ctx* h, int Q, hipStream_t st) {
     HIP_TRY(h, hipMalloc(&h->n_sorted, (size_t)qpad * sizeof(int)));
     HIP_TRY(h, hipMalloc(&h->exact, (size_t)qpad * RAG_CAND_CAP * sizeof(double)));
     HIP_TRY(h, hipMalloc(&h->flag, (size_t)qpad * sizeof(int)));
+    HIP_TRY(h, hipMalloc(&h->scan_list, (size_t)qpad * sizeof(int)));
     if (!h->stats) HIP_TRY(h, hipMalloc(&h->stats, 8 * sizeof(int)));
     // zero fills go on the search's own stream: a null-stream hipMemset is not ordered against a non-blocking stream
     HIP_TRY(h, hipMemsetAsync(h->q16, 0, (size_t)qpad * h->dim_pad * sizeof(half_t), st));
@@ -1078,7 +1087,11 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
     h->q16_dirty = Q;
     hipLaunchKernelGGL(normalize_rows_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, q_dev, h->q16, (int64_t)Q, h->dim,
                        h->dim_pad, (int*)nullptr);
-    hipLaunchKernelGGL(search_init_kernel, dim3((qpad + 255) / 256), dim3(256), 0, st, tau, h->bound, h->cnt, h->stats, qpad);
+    int* const ovf_count = h->ovf_list + RAG_TILE;
+    hipLaunchKernelGGL(search_init_kernel, dim3((qpad + 255) / 256), dim3(256), 0, st, tau, h->bound, h->cnt, h->stats, ovf_count, qpad);
+    const select_extra no_extra = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const bool second_pass = !h->opt.no_second_pass;
+    const select_extra list_extra = {second_pass ? h->ovf_list : (int*)nullptr, ovf_count, nullptr, nullptr, nullptr, nullptr};
 
     bool& attr_set = h->attr_dense;
     if (!attr_set) {
@@ -1098,8 +1111,6 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SELECT_LDS_BYTES));
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(wide_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, RAG_CAND_CAP * 12));
         attr_set = true;
     }
 
@@ -1167,20 +1178,18 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
         const bool last = end == total_tiles;
         hipLaunchKernelGGL(select_kernel, dim3((Q + 3) / 4), dim3(256), SELECT_LDS_BYTES, st, h->cand, h->cnt, tau, h->bound,
                            h->n_sorted, h->stats, Q, stage == 0 ? n_rt * RAG_TILE : 0, k, two_eps, last ? 1 : 0,
-                           (const int*)nullptr);
+                           (const int*)nullptr, last ? list_extra : no_extra);
         HIP_TRY(h, hipGetLastError());
         begin = end;
         ++stage;
     }
     if (total_tiles == 0) {   // empty index / unknown tenant: nothing found
         hipLaunchKernelGGL(select_kernel, dim3((Q + 3) / 4), dim3(256), SELECT_LDS_BYTES, st, h->cand, h->cnt, tau, h->bound,
-                           h->n_sorted, h->stats, Q, 0, k, two_eps, 1, (const int*)nullptr);
+                           h->n_sorted, h->stats, Q, 0, k, two_eps, 1, (const int*)nullptr, no_extra);
     }
 
     // ---- second pass for overflowed queries (device-side early exit when there are none) ---------------------------
-    if (total_tiles > 0 && !h->opt.no_second_pass) {
-        int* ovf_count = h->ovf_list + RAG_TILE;
-        hipLaunchKernelGGL(flag_list_kernel, dim3(1), dim3(256), 0, st, (const int*)nullptr, h->bound, Q, 0, RAG_TILE, h->ovf_list, ovf_count);
+    if (total_tiles > 0 && second_pass) {
         hipLaunchKernelGGL(overflow_gather_kernel, dim3(RAG_TILE), dim3(256), 0, st, h->ovf_list, ovf_count, h->q16, tau, h->dim_pad,
                            h->q16b, h->taub, h->boundb, h->cntb);
         {
@@ -1193,10 +1202,9 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
                 hipLaunchKernelGGL((dense_emit_persist_kernel<false>), dim3(std::min(n_cu, total_tiles)), dim3(512), DENSE_LDS_BYTES, st, total_tiles,
                                    EMIT_ARGS(h->q16b, 1, RAG_TILE, h->taub, h->cntb, h->candb, ovf_count, nullptr));
         }
+        const select_extra scatter_extra = {nullptr, nullptr, h->ovf_list, h->cand, h->n_sorted, h->bound};
         hipLaunchKernelGGL(select_kernel, dim3(RAG_TILE / 4), dim3(256), SELECT_LDS_BYTES, st, h->candb, h->cntb, h->taub, h->boundb,
-                           h->n_sortedb, (int*)nullptr, RAG_TILE, 0, k, two_eps, 1, (const int*)ovf_count);
-        hipLaunchKernelGGL(overflow_scatter_kernel, dim3(RAG_TILE), dim3(256), 0, st, h->ovf_list, ovf_count, h->candb, h->n_sortedb,
-                           h->boundb, h->cand, h->n_sorted, h->bound, h->stats);
+                           h->n_sortedb, h->stats, RAG_TILE, 0, k, two_eps, 1, (const int*)ovf_count, scatter_extra);
         HIP_TRY(h, hipGetLastError());
     }
 
@@ -1204,10 +1212,10 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
     if (fz)
         hipLaunchKernelGGL(linear_fuse_kernel, dim3(4, Q), dim3(256), 0, st, h->cand, h->n_sorted, h->exact, fz->raw, fz->n, fz->mx,
                            fz->temporal, fz->alpha, fz->beta, fz->gamma);
+    int* const scan_list = h->scan_list;              // [ws_qpad]: queries that need the float64 scan, appended by finalize
+    int* const scan_count = h->stats + 7;
     hipLaunchKernelGGL(finalize_kernel, dim3(Q), dim3(256), 0, st, h->cand, h->n_sorted, h->exact, h->bound, h->ids, h->id_base, k,
-                       force_level, ids_dev, rows_dev, scores_dev, h->flag, h->stats);
-    hipLaunchKernelGGL(wide_kernel, dim3(Q), dim3(512), RAG_CAND_CAP * 12, st, h->cand, h->n_sorted, h->exact, h->ids, h->id_base, k,
-                       ids_dev, rows_dev, scores_dev, h->flag, h->stats);
+                       force_level, ids_dev, rows_dev, scores_dev, h->flag, h->stats, scan_list, scan_count);
     HIP_TRY(h, hipGetLastError());
     // exact scan for whatever is still unproven: rounds of SCAN_ROUND flagged queries, device-side early exit when none
     if (h->n_rows > 0) {
@@ -1227,9 +1235,6 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
         }
         uint64_t* pk = reinterpret_cast<uint64_t*>(h->scan_scores);
         uint32_t* pr = reinterpret_cast<uint32_t*>(pk + h->scan_rows);
-        int* scan_list = h->n_sorted;                 // free after the wide kernel; [Q] ints
-        int* scan_count = h->stats + 7;
-        hipLaunchKernelGGL(flag_list_kernel, dim3(1), dim3(256), 0, st, (const int*)h->flag, (const float*)nullptr, Q, 2, Q, scan_list, scan_count);
         for (int f0 = 0; f0 < Q; f0 += round_q) {
             hipLaunchKernelGGL(scan_chunk_kernel, dim3(n_blocks), dim3(256), 0, st, q_dev, h->emb32, tenants, tenant, h->n_rows,
                                rows_per_block, h->dim, k, scan_list, scan_count, f0, round_q, pk, pr, fz ? fz->raw : (const double*)nullptr,

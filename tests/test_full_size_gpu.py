@@ -112,10 +112,11 @@ def _postings(world):
 
 
 def test_bm25_full_size_staged_equals_exhaustive_select(world, monkeypatch):
-    """BASELINE.json configs[2] at FULL size (1M docs, ~9.5e7 postings, 1024 queries, top-100): the staged-threshold BM25
-    path must return bit-identical ids and scores to the path that runs the exact per-range select on every range, its
-    scores are max-normalised and sorted, and the sharded pipeline property holds: scoring two doc partitions with the
-    global statistics and merging == scoring the whole corpus."""
+    """BASELINE.json configs[2] at FULL size (1M docs, ~9.5e7 postings, 489 doc ranges, 1024 queries, top-100): the staged-
+    threshold BM25 path must return bit-identical ids and scores to the path that runs the exact per-range select on every range,
+    six sampled queries must equal the CSR oracle (BM25Okapi.get_scores / max, stable top-100) bit for bit, the scores are
+    max-normalised and sorted, and the sharded pipeline property holds: scoring two doc partitions with the global statistics
+    and merging == scoring the whole corpus."""
     import torch
     eng = world["whole"]
     post, ptr, terms = _postings(world)
@@ -140,6 +141,13 @@ def test_bm25_full_size_staged_equals_exhaustive_select(world, monkeypatch):
     np.testing.assert_array_equal(sc_s, sc_e)
     np.testing.assert_array_equal(mx_s, mx_e)
     assert (sc_s[:, 0] == 1.0).all() and (np.diff(sc_s, axis=1) <= 0).all() and (ids_s >= 0).all()
+    from oracle import rag_oracle as O
+    for qi in (0, 1, 255, 256, 700, 1023):
+        raw = O.bm25_scores_csr(post.indptr, post.doc, post.tf, post.doc_len, post.idf, post.avgdl, terms[ptr[qi]:ptr[qi + 1]].tolist())
+        top = O.stable_topk_desc(raw, pool)
+        np.testing.assert_array_equal(ids_s[qi], top)
+        np.testing.assert_array_equal(sc_s[qi], raw[top] / (raw.max() if raw.max() > 0 else 1.0))
+        assert mx_s[qi] == (raw.max() if raw.max() > 0 else 1.0)
     # two doc partitions with global statistics, raw scores, merged on the device == the whole corpus
     cut = 437_000
     parts = []
