@@ -152,7 +152,7 @@ int rag_rrf_fuse_host(rag_handle_t h, const int64_t* lists_host, int n_queries, 
  * BASELINE.json configs[2] in one call: dense top-`pool` + BM25 top-`pool` -> RRF(rrf_k) -> top-k, nothing leaves HBM.
  * rag_rrf_fuse_dev: lists_dev is [Q][n_lists][list_len]. rag_hybrid_rrf_dev: lists_ws_dev is caller scratch
  * [2][Q][pool] int64, scores_ws_dev [Q][pool] float64; keys are doc ids (BM25 rows use the dense index's id mapping,
- * the two indexes must be row-aligned). For up to 16 queries the BM25 leg of rag_hybrid_rrf_dev / rag_retrieve_rerank_dev
+ * the two indexes must be row-aligned). For batches of up to 4096 queries the BM25 leg of rag_hybrid_rrf_dev / rag_retrieve_rerank_dev
  * runs on an internal side stream that is forked from and joined back into `stream` by events: everything the call
  * reads and writes is still ordered on `stream` as if it had run there alone. */
 int rag_rrf_fuse_dev(rag_handle_t h, const int64_t* lists_dev, int n_queries, int n_lists, int list_len, int rrf_k,

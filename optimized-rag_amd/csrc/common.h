@@ -39,6 +39,7 @@ struct rag_options {
     int bm25_first_ranges = 0;    // exact first-stage BM25 ranges (0 = BM_FIRST_RANGES)
     int bm25_no_staging = 0;      // exact per-range select for every BM25 range
     int no_fork = 0;              // keep the BM25 leg of a small hybrid batch in line on the caller's stream
+    int fork_max_q = 0;           // largest batch whose BM25 leg runs on the side stream beside the dense leg (0 = RAG_FORK_MAX_Q)
     int ce_no_fused_ln = 0;       // unfused residual + LayerNorm path of the cross-encoder
     int ce_no_fused_ffn = 0;      // FFN as two GEMM launches (up-projection, then the fused-LN down-projection)
     int ce_chunk_tokens = 0;      // activation chunk size in tokens (0 = sized from the model)

@@ -20,15 +20,18 @@ int rrf_fuse_dev(rag_ctx* h, const int64_t* lists_dev, int Q, int L, int len, in
                  int top_k, int64_t* keys_dev, double* scores_dev, int32_t* ranks_dev, hipStream_t st);
 
 // The two candidate legs of the hybrid search: dense top-pool into lists[0], BM25 top-pool into lists[1] ([2][Q][pool]).
-// They are independent, and for a handful of queries both are latency-bound (one query: 0.6 ms of HBM-bound scan and 0.4 ms
-// of BM25 launches that occupy a quarter of the CUs), so up to RAG_FORK_MAX_Q queries the BM25 leg runs on a side stream,
-// forked from and joined back into the caller's stream by events; larger batches saturate the device in either leg and stay
-// in line. RAG_NO_FORK=1 (diagnostic) keeps them in line always.
-#define RAG_FORK_MAX_Q 16
+// They are independent: the BM25 leg runs on a side stream, forked from and joined back into the caller's stream by events.
+// For a handful of queries both legs are latency-bound (one query: 0.6 ms of HBM-bound scan beside 0.2 ms of BM25 launches that
+// occupy a quarter of the CUs: 0.99 -> 0.80 ms). Large batches (r2 kept them in line) gain less - the dense GEMM's 128-KiB
+// workgroups leave room for ONE 20-KiB BM25 workgroup per CU - but the BM25 stages fill the thin opening stages, selects and
+// the rescoring of the dense leg: 1024-query hybrid batches 6.85 -> 6.58 ms on one box (A/B by option fork_max_q).
+// Option no_fork keeps the legs in line always; fork_max_q lowers the largest batch that forks.
+#define RAG_FORK_MAX_Q 4096
 int hybrid_legs(rag_ctx* h, const float* q_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int pool, int tenant,
                 int64_t* lists_dev, double* scores_ws_dev, hipStream_t st) {
     int64_t* const bm_ids = lists_dev + (size_t)Q * pool;
-    if (Q > RAG_FORK_MAX_Q || h->opt.no_fork) {
+    const int fork_max = h->opt.fork_max_q > 0 ? h->opt.fork_max_q : RAG_FORK_MAX_Q;
+    if (Q > fork_max || h->opt.no_fork) {
         int rc = dense_search(h, q_dev, Q, pool, tenant, lists_dev, nullptr, scores_ws_dev, st);
         if (rc) return rc;
         return bm25_topk_dev(h, term_ptr_dev, terms_dev, Q, pool, tenant, bm_ids, nullptr, scores_ws_dev, nullptr, st);
@@ -43,8 +46,9 @@ int hybrid_legs(rag_ctx* h, const float* q_dev, const int32_t* term_ptr_dev, con
         hipFree(h->side_scores);
         h->side_scores = nullptr;
         h->side_scores_n = 0;
-        HIP_TRY(h, hipMalloc(&h->side_scores, (size_t)RAG_FORK_MAX_Q * RAG_MAX_K * sizeof(double)));
-        h->side_scores_n = (size_t)RAG_FORK_MAX_Q * RAG_MAX_K;
+        const size_t want = std::max(need, (size_t)RAG_FORK_MAX_Q * RAG_MAX_K);
+        HIP_TRY(h, hipMalloc(&h->side_scores, want * sizeof(double)));
+        h->side_scores_n = want;
     }
     HIP_TRY(h, hipEventRecord(h->ev_fork, st));                    // inputs are ready wherever the caller's stream is now
     HIP_TRY(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
