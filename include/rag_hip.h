@@ -48,8 +48,8 @@ const char* rag_last_error(rag_handle_t h);
 int rag_synchronize(rag_handle_t h);
 /* Diagnostic / tuning switch of one handle (no reference counterpart). Every switch <name> takes its default from the
  * environment variable RAG_<NAME> ONCE, when rag_create runs; afterwards only this call changes it. Names: force_level,
- * stage_growth, no_smallq, no_second_pass, dense_linear_order, bm25_first_ranges, bm25_no_staging, no_fork,
- * ce_no_fused_ln, ce_no_fused_ffn, ce_chunk_tokens. Unknown name: RAG_ERR_ARG. */
+ * stage_growth, no_smallq, no_second_pass, dense_linear_order, bm25_first_ranges, bm25_no_staging, bm25_packed, no_fork,
+ * fork_max_q, ce_no_fused_ln, ce_no_fused_ffn, ce_chunk_tokens. Unknown name: RAG_ERR_ARG. */
 int rag_set_option(rag_handle_t h, const char* name, int value);
 
 /* ---- dense index: replaces the pgvector tables behind
@@ -193,7 +193,9 @@ int rag_bm25_load_host(rag_handle_t h, const int64_t* indptr_host /*V+1*/, const
                        const double* idf_host /*V*/, int64_t n_docs, int64_t n_terms, double avgdl,
                        double k1, double b);
 /* HBM bytes rag_bm25_load_host will take for a CSR with these offsets, computed on the host from indptr alone (no GPU call):
- * postings (doc id + float64 impact, 12 B each), per-term metadata (32 B each) and the per-term bracket tables that replace
+ * postings (doc id + float64 impact, 12 B each; 8 B with option bm25_packed: the impact is then idf * g[code of the posting's
+ * (term frequency, document length) pair] - bit-identical, less HBM, a slower scoring loop), per-term metadata (32 B each) and
+ * the per-term bracket tables that replace
  * a binary search of the posting list per (query token, 2048-document range). A term's table is sized by its document
  * frequency, so table bytes <= postings/12 for ANY vocabulary - the reference tokeniser (`doc.lower().split()`,
  * rag/retrieval.py:334-335) produces millions of distinct terms on a large shard. Lets a loader budget a shard before

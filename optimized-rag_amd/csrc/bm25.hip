@@ -63,6 +63,15 @@ struct rag_bm25_index {
     int32_t* doc = nullptr;
     double* w = nullptr;
     double* idf = nullptr;
+    // OPTIONAL compact form (option bm25_packed at load time): 4-byte postings (doc & (BM_RANGE - 1)) | code << BM_RANGE_LOG2, code =
+    // tf rank * n_dl + length rank, and the table g[code] = tf (k1+1) / (tf + k1 (1 - b + b dl / avgdl)) shared by all terms
+    // (impact = idf * g, the same float64 product): 8 B per posting resident instead of 12 (`doc` stays for the plan kernel's
+    // searches, `w` is not built) and a third of the streamed bytes - but the scoring loop gets SLOWER (1M documents, 1024 queries:
+    // 4.22 against 3.36 ms): four 8-byte table gathers per chunk cost the texture path more than the two coalesced impact loads
+    // they replace. The default therefore streams (doc i32, impact f64).
+    uint32_t* packed = nullptr;
+    double* gtab = nullptr;
+    int64_t n_codes = 0;
     bm_term_meta* meta = nullptr;      // [n_terms]
     int32_t* range_tab = nullptr;      // concatenated per-term tables: entry c = first posting (rel. to meta.post) with doc >= c << shift
     int64_t tab_entries = 0;
@@ -107,6 +116,29 @@ __global__ void bm25_weights_kernel(const int64_t* __restrict__ indptr, const in
     // the impact is stored already multiplied by the term's idf: `idf * (...)` is the product rank-bm25 adds to the score, so
     // the scoring loop is a pure load + add (one float64 multiply and one LDS lookup fewer per posting)
     w[p] = idf[lo] * (num / den);
+}
+
+// packed postings (see rag_bm25_index): one thread per posting
+__global__ void bm25_pack_kernel(const int32_t* __restrict__ doc, const int32_t* __restrict__ tf, const uint32_t* __restrict__ tf_rank,
+                                 const uint32_t* __restrict__ dl_rank_of_doc, int64_t nnz, uint32_t n_dl, uint32_t* __restrict__ packed) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    const int32_t d = doc[p];
+    packed[p] = ((uint32_t)d & (BM_RANGE - 1)) | ((tf_rank[tf[p]] * n_dl + dl_rank_of_doc[d]) << BM_RANGE_LOG2);
+}
+
+// g[ti * n_dl + di] for the ti-th distinct term frequency and the di-th distinct document length - the second factor of
+// rank-bm25's `idf * (q_freq * (k1 + 1) / (q_freq + k1 * (1 - b + b * doc_len / avgdl)))`, same association as bm25_weights_kernel
+__global__ void bm25_gtab_kernel(const double* __restrict__ tf_values, const double* __restrict__ dl_values, int64_t n_codes, uint32_t n_dl,
+                                 double avgdl, double k1, double b, double* __restrict__ gtab) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_codes) return;
+    const double f = tf_values[c / n_dl], dl = dl_values[c % n_dl];
+    const double num = f * (k1 + 1.0);
+    const double t1 = (b * dl) / avgdl;
+    const double t2 = (1.0 - b) + t1;
+    const double den = f + k1 * t2;
+    gtab[c] = num / den;
 }
 
 __device__ __forceinline__ int64_t lower_bound_doc(const int32_t* __restrict__ doc, int64_t lo, int64_t hi, int target) {
@@ -212,8 +244,14 @@ __global__ __launch_bounds__(256) void bm25_plan_kernel(const bm_term_meta* __re
 
 // One workgroup per (query, doc range).
 // mode 0: per-range top-k partials; mode 1: dense scores out[q][doc]
-__global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const bm_term_meta* __restrict__ meta, const int32_t* __restrict__ doc,
-                                                                 const double* __restrict__ w,
+// PACKED (option bm25_packed, off by default - see rag_bm25_index): the scoring loop streams 4-byte postings (document number
+// inside its 2048-document range | code of its (tf, doc length) pair) and looks the impact factor g(tf, dl) up in a table shared
+// by all terms. Default: (doc i32, impact f64) = 12 bytes per posting.
+// (SGPRs capped at 96: 256-thread workgroups are admitted 7 per CU up to 96 scalar registers, 6 from 97 on - MI355X_MICROARCH.md)
+template <bool PACKED>
+__global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_num_sgpr(96))) void bm25_range_kernel(const bm_term_meta* __restrict__ meta, const int32_t* __restrict__ doc,
+                                                                 const double* __restrict__ w, const uint32_t* __restrict__ packed,
+                                                                 const double* __restrict__ gtab,
                                                                  const int32_t* __restrict__ range_tab, int n_ranges,
                                                                  const int32_t* __restrict__ term_ptr, const int32_t* __restrict__ terms,
                                                                  int64_t n_docs, int64_t n_terms, int k, int mode,
@@ -293,6 +331,85 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const bm_term_me
 #define TOK_A(TI) (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(my_a_hi, TI) << 32) | (uint32_t)__builtin_amdgcn_readlane(my_a_lo, TI))
         int ti = 0, c = 0;
         while (ti < nb && TOK_N(ti) == 0) ++ti;
+#define BM_NEXT(TI, C, NTI, NC)                                                                    \
+            NTI = TI; NC = C + 1;                                                                  \
+            if (NC * 4 * BM_THREADS >= TOK_N(TI)) {                                                \
+                NC = 0;                                                                            \
+                ++NTI;                                                                             \
+                while (NTI < nb && TOK_N(NTI) == 0) ++NTI;                                         \
+            }
+#define BM_TOKEN_BARRIER asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+        if constexpr (PACKED) {
+            // 4-byte postings: u = (doc - base) | code << 11; the impact is idf(token) * gtab[code], one float64 multiply - the same
+            // product the 12-byte form stored (`idf * (num / den)`, rank-bm25's association), so the sums are bit-identical.
+            // Three chunks are in flight per thread: the postings of chunk i + 2, the table values of chunk i + 1 (they need that
+            // chunk's postings), the adds of chunk i.
+            const double my_f = m_idf[lane];
+            const int my_f_lo = (int)(uint32_t)__builtin_bit_cast(uint64_t, my_f), my_f_hi = (int)(__builtin_bit_cast(uint64_t, my_f) >> 32);
+#define TOK_IDF(TI) __builtin_bit_cast(double, ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(my_f_hi, TI) << 32) | (uint32_t)__builtin_amdgcn_readlane(my_f_lo, TI))
+#define BMP_LOAD(TI, C, U)                                                                         \
+            {                                                                                      \
+                const int64_t o_ = TOK_A(TI) + min((C) * 4 * BM_THREADS + tid * 4, max(TOK_N(TI) - 1, 0)); \
+                U = *reinterpret_cast<const int4u*>(packed + o_);                                  \
+            }
+#define BMP_GATHER(U, G)                                                                           \
+            {                                                                                      \
+                G[0] = gtab[(uint32_t)U[0] >> BM_RANGE_LOG2]; G[1] = gtab[(uint32_t)U[1] >> BM_RANGE_LOG2]; \
+                G[2] = gtab[(uint32_t)U[2] >> BM_RANGE_LOG2]; G[3] = gtab[(uint32_t)U[3] >> BM_RANGE_LOG2]; \
+            }
+#define BMP_ADD(TI, C, U, G)                                                                       \
+            {                                                                                      \
+                const int p_ = (C) * 4 * BM_THREADS + tid * 4, n_ = TOK_N(TI);                     \
+                if (p_ < n_) {                                                                     \
+                    const double f_ = TOK_IDF(TI);                                                 \
+                    double* a0_ = &sc[SC_IDX(U[0] & (BM_RANGE - 1))];                              \
+                    double* a1_ = p_ + 1 < n_ ? &sc[SC_IDX(U[1] & (BM_RANGE - 1))] : &sc[BM_SC_DOUBLES - 1]; \
+                    double* a2_ = p_ + 2 < n_ ? &sc[SC_IDX(U[2] & (BM_RANGE - 1))] : &sc[BM_SC_DOUBLES - 2]; \
+                    double* a3_ = p_ + 3 < n_ ? &sc[SC_IDX(U[3] & (BM_RANGE - 1))] : &sc[BM_SC_DOUBLES - 3]; \
+                    const double v0_ = *a0_, v1_ = *a1_, v2_ = *a2_, v3_ = *a3_;                   \
+                    *a0_ = v0_ + f_ * G[0];                                                        \
+                    if (p_ + 1 < n_) *a1_ = v1_ + f_ * G[1];                                       \
+                    if (p_ + 2 < n_) *a2_ = v2_ + f_ * G[2];                                       \
+                    if (p_ + 3 < n_) *a3_ = v3_ + f_ * G[3];                                       \
+                }                                                                                  \
+            }
+            // one turn of the pipeline: chunk X is added, chunk Y (postings in flight) gets its table values requested, the
+            // postings of the chunk after Y are requested into Z. (tx, cx) / (ty, cy) walk the (token, chunk) sequence.
+#define BMP_TURN(UX, GX, UY, GY, UZ)                                                               \
+            {                                                                                      \
+                int tz_ = ty, cz_ = cy;                                                            \
+                bool more_z_ = false;                                                              \
+                if (more_y) { BM_NEXT(ty, cy, tz_, cz_) more_z_ = tz_ < nb; }                      \
+                { const int lt_ = more_z_ ? tz_ : ty, lc_ = more_z_ ? cz_ : cy; BMP_LOAD(lt_, lc_, UZ) } \
+                BMP_GATHER(UY, GY)                                                                 \
+                BMP_ADD(tx, cx, UX, GX)                                                            \
+                if (!more_y) break;                                                                \
+                if (ty != tx) BM_TOKEN_BARRIER;                                                    \
+                tx = ty; cx = cy; more_y = more_z_;                                                \
+                if (more_z_) { ty = tz_; cy = cz_; }        /* else (ty, cy) stays a valid (token, chunk) for the spare loads */ \
+            }
+            if (ti < nb) {
+                int4u ua, ub, uc;
+                double ga[4], gb[4], gc[4];
+                int tx = ti, cx = c, ty = ti, cy = c;
+                BMP_LOAD(tx, cx, ua)
+                BM_NEXT(tx, cx, ty, cy)
+                bool more_y = ty < nb;
+                { const int lt_ = more_y ? ty : tx, lc_ = more_y ? cy : cx; BMP_LOAD(lt_, lc_, ub) }
+                if (!more_y) { ty = tx; cy = cx; }
+                BMP_GATHER(ua, ga)
+                for (;;) {
+                    BMP_TURN(ua, ga, ub, gb, uc)
+                    BMP_TURN(ub, gb, uc, gc, ua)
+                    BMP_TURN(uc, gc, ua, ga, ub)
+                }
+            }
+#undef BMP_LOAD
+#undef BMP_GATHER
+#undef BMP_ADD
+#undef BMP_TURN
+#undef TOK_IDF
+        } else
         if (ti < nb) {
             int4u da, db;
             double2u wa0, wa1, wb0, wb1;
@@ -318,14 +435,6 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_range_kernel(const bm_term_me
                     if (p_ + 3 < n_) *a3_ = v3_ + W1[1];                                           \
                 }                                                                                  \
             }
-#define BM_NEXT(TI, C, NTI, NC)                                                                    \
-            NTI = TI; NC = C + 1;                                                                  \
-            if (NC * 4 * BM_THREADS >= TOK_N(TI)) {                                                \
-                NC = 0;                                                                            \
-                ++NTI;                                                                             \
-                while (NTI < nb && TOK_N(NTI) == 0) ++NTI;                                         \
-            }
-#define BM_TOKEN_BARRIER asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
             BM_LOAD(ti, c, da, wa0, wa1)
             for (;;) {
                 int nti, nc;
@@ -647,6 +756,16 @@ struct bm25_topk_out {
 // of the query gives tau (k-th best so far), and the next stage - up to BM_STAGE_GROWTH x the ranges seen so far - only
 // compacts keys >= tau. Expected survivors per stage ~ k * growth per query however large the shard is (a single
 // threshold from 32768 docs left ~k/2 per range: 38 k entries per query to merge on a 12.5M-doc shard).
+// the scoring launch: packed 4-byte postings when the index has them, the 12-byte form otherwise
+#define BM_RANGE_LAUNCH(IX, GRID, ST, NR, TP, TM, K, MODE, ...)                                                                    \
+    {                                                                                                                              \
+        if ((IX)->packed != nullptr)                                                                                               \
+            hipLaunchKernelGGL(bm25_range_kernel<true>, GRID, dim3(BM_THREADS), BM_LDS_BYTES, ST, (IX)->meta, (IX)->doc, (IX)->w,  \
+                               (IX)->packed, (IX)->gtab, (IX)->range_tab, NR, TP, TM, (IX)->n_docs, (IX)->n_terms, K, MODE, __VA_ARGS__); \
+        else                                                                                                                       \
+            hipLaunchKernelGGL(bm25_range_kernel<false>, GRID, dim3(BM_THREADS), BM_LDS_BYTES, ST, (IX)->meta, (IX)->doc, (IX)->w, \
+                               (IX)->packed, (IX)->gtab, (IX)->range_tab, NR, TP, TM, (IX)->n_docs, (IX)->n_terms, K, MODE, __VA_ARGS__); \
+    }
 static size_t bm25_plan_off_entries(const rag_bm25_index* ix, int Q) { return (size_t)Q * BM_PLAN_T * (ix->n_ranges + 1); }
 static void bm25_launch_plan(const rag_bm25_index* ix, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, const bm25_plan_ws& p,
                              hipStream_t st) {
@@ -664,10 +783,9 @@ static void bm25_launch_topk(const rag_ctx* h, const rag_bm25_index* ix, const i
     while (begin < nr) {
         int end = !staged ? nr : (stage == 0 ? first_cfg : (int)std::min<int64_t>(nr, (int64_t)begin * BM_STAGE_GROWTH));
         if (staged && nr - end < end / 4) end = nr;                   // no tiny trailing stage
-        hipLaunchKernelGGL(bm25_range_kernel, dim3(end - begin, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->meta, ix->doc, ix->w,
-                           ix->range_tab, nr, term_ptr_dev, terms_dev, ix->n_docs, ix->n_terms, k, 0, (double*)nullptr,
-                           w.part_key, w.part_row, begin, stage == 0 ? (const uint64_t*)nullptr : (const uint64_t*)w.tau, w.part_cnt,
-                           tenants, tenant, (const int32_t*)w.plan.off, (const bm_plan_meta*)w.plan.meta);
+        BM_RANGE_LAUNCH(ix, dim3(end - begin, Q), st, nr, term_ptr_dev, terms_dev, k, 0, (double*)nullptr,
+                        w.part_key, w.part_row, begin, stage == 0 ? (const uint64_t*)nullptr : (const uint64_t*)w.tau, w.part_cnt,
+                        tenants, tenant, (const int32_t*)w.plan.off, (const bm_plan_meta*)w.plan.meta)
         const int last = end == nr;
         hipLaunchKernelGGL(bm25_merge_stage_kernel, dim3(Q), dim3(256), 0, st, w.part_key, w.part_row, w.part_cnt, nr, begin, end, k,
                            w.run_key, w.run_row, stage == 0 ? 1 : 0, w.tau, last, o.idmap, o.id_base, o.ids, o.rows, o.scores,
@@ -681,6 +799,7 @@ static void bm25_launch_topk(const rag_ctx* h, const rag_bm25_index* ix, const i
 static void bm25_index_free(rag_bm25_index* ix) {
     if (!ix) return;
     hipFree(ix->indptr); hipFree(ix->doc); hipFree(ix->w); hipFree(ix->idf); hipFree(ix->meta); hipFree(ix->range_tab);
+    hipFree(ix->packed); hipFree(ix->gtab);
     hipFree(ix->ws_key); hipFree(ix->ws_row); hipFree(ix->ws_tau); hipFree(ix->ws_cnt); hipFree(ix->ws_run_key); hipFree(ix->ws_run_row);
     hipFree(ix->ws_plan_off); hipFree(ix->ws_plan_meta);
     delete ix;
@@ -721,13 +840,57 @@ static int bm25_build(rag_ctx* h, const int64_t* indptr, const int32_t* doc, con
         n_tab += e_t;
     }
     ix->tab_entries = n_tab;
+    // code space of the packed postings: distinct term frequencies x distinct document lengths (host scans of tf[] and doc_len[])
+    const int64_t code_cap = (int64_t)1 << (32 - BM_RANGE_LOG2);
+    std::vector<uint32_t> tf_rank_h, dl_rank_of_doc_h;
+    std::vector<double> tf_values_h, dl_values_h;
+    bool packed_ok = nnz > 0 && h->opt.bm25_packed;      // opt-in: a third less HBM for the postings, a slower scoring loop
+    if (packed_ok) {
+        int32_t tf_max = 0, dl_max = 0;
+        bool bad = false;
+        for (int64_t p = 0; p < nnz; ++p) { const int32_t v = tf[p]; bad |= v <= 0; tf_max = v > tf_max ? v : tf_max; }
+        for (int64_t d = 0; d < n_docs; ++d) { const int32_t v = doc_len[d]; bad |= v < 0; dl_max = v > dl_max ? v : dl_max; }
+        packed_ok = !bad && tf_max < (1 << 24) && dl_max < (1 << 26);
+        if (packed_ok) {
+            std::vector<char> seen_tf((size_t)tf_max + 1, 0), seen_dl((size_t)dl_max + 1, 0);
+            for (int64_t p = 0; p < nnz; ++p) seen_tf[(size_t)tf[p]] = 1;
+            for (int64_t d = 0; d < n_docs; ++d) seen_dl[(size_t)doc_len[d]] = 1;
+            tf_rank_h.assign((size_t)tf_max + 1, 0);
+            std::vector<uint32_t> dl_rank((size_t)dl_max + 1, 0);
+            for (int32_t v = 0; v <= tf_max; ++v) if (seen_tf[(size_t)v]) { tf_rank_h[(size_t)v] = (uint32_t)tf_values_h.size(); tf_values_h.push_back((double)v); }
+            for (int32_t v = 0; v <= dl_max; ++v) if (seen_dl[(size_t)v]) { dl_rank[(size_t)v] = (uint32_t)dl_values_h.size(); dl_values_h.push_back((double)v); }
+            ix->n_codes = (int64_t)tf_values_h.size() * (int64_t)dl_values_h.size();
+            packed_ok = ix->n_codes <= code_cap;
+            if (packed_ok) {
+                dl_rank_of_doc_h.resize((size_t)n_docs);
+                for (int64_t d = 0; d < n_docs; ++d) dl_rank_of_doc_h[(size_t)d] = dl_rank[(size_t)doc_len[d]];
+            }
+        }
+    }
+    if (!packed_ok) ix->n_codes = 0;
     // + 8 postings of padding: the scoring kernel reads 4 consecutive postings per thread, the bracket search 8 doc ids, without
     // a bounds branch
+    uint32_t *tfr_d = nullptr, *dlr_d = nullptr;
+    double *tfv_d = nullptr, *dlv_d = nullptr;
     hipError_t e = hipMalloc(&ix->indptr, (size_t)(n_terms + 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc(&ix->doc, (size_t)(nnz + 8) * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&ix->w, (size_t)(nnz + 8) * sizeof(double));
     if (e == hipSuccess) e = hipMemsetAsync(ix->doc + nnz, 0, 8 * sizeof(int32_t), st);
-    if (e == hipSuccess) e = hipMemsetAsync(ix->w + nnz, 0, 8 * sizeof(double), st);
+    if (packed_ok) {
+        if (e == hipSuccess) e = hipMalloc(&ix->packed, (size_t)(nnz + 8) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(ix->packed + nnz, 0, 8 * sizeof(uint32_t), st);
+        if (e == hipSuccess) e = hipMalloc(&ix->gtab, (size_t)ix->n_codes * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc(&tfr_d, tf_rank_h.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&dlr_d, dl_rank_of_doc_h.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&tfv_d, tf_values_h.size() * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc(&dlv_d, dl_values_h.size() * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpyAsync(tfr_d, tf_rank_h.data(), tf_rank_h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(dlr_d, dl_rank_of_doc_h.data(), dl_rank_of_doc_h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(tfv_d, tf_values_h.data(), tf_values_h.size() * sizeof(double), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(dlv_d, dl_values_h.data(), dl_values_h.size() * sizeof(double), hipMemcpyHostToDevice, st);
+    } else {
+        if (e == hipSuccess) e = hipMalloc(&ix->w, (size_t)(nnz + 8) * sizeof(double));
+        if (e == hipSuccess) e = hipMemsetAsync(ix->w + nnz, 0, 8 * sizeof(double), st);
+    }
     if (e == hipSuccess) e = hipMalloc(&ix->idf, std::max<size_t>(1, n_terms) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&ix->meta, meta_h.size() * sizeof(bm_term_meta));
     if (e == hipSuccess) e = hipMalloc(&tfd, std::max<size_t>(1, nnz) * sizeof(int32_t));
@@ -739,9 +902,16 @@ static int bm25_build(rag_ctx* h, const int64_t* indptr, const int32_t* doc, con
     if (e == hipSuccess && n_terms) e = hipMemcpyAsync(ix->idf, idf, (size_t)n_terms * sizeof(double), hipMemcpyHostToDevice, st);
     if (e == hipSuccess && n_terms) e = hipMemcpyAsync(ix->meta, meta_h.data(), (size_t)n_terms * sizeof(bm_term_meta), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(dld, doc_len, (size_t)n_docs * sizeof(int32_t), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && nnz) {
+    if (e == hipSuccess && nnz && !packed_ok) {
         hipLaunchKernelGGL(bm25_weights_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, ix->indptr, ix->doc, tfd,
                            dld, nnz, avgdl, k1, b, ix->idf, n_terms, ix->w);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && packed_ok) {
+        hipLaunchKernelGGL(bm25_pack_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, ix->doc, tfd, tfr_d, dlr_d, nnz,
+                           (uint32_t)dl_values_h.size(), ix->packed);
+        hipLaunchKernelGGL(bm25_gtab_kernel, dim3((unsigned)((ix->n_codes + 255) / 256)), dim3(256), 0, st, tfv_d, dlv_d, ix->n_codes,
+                           (uint32_t)dl_values_h.size(), avgdl, k1, b, ix->gtab);
         e = hipGetLastError();
     }
     if (e == hipSuccess && n_tab) {
@@ -750,7 +920,7 @@ static int bm25_build(rag_ctx* h, const int64_t* indptr, const int32_t* doc, con
         e = hipGetLastError();
     }
     const hipError_t e2 = hipStreamSynchronize(st);               // (also keeps meta_h alive until its copy has been read)
-    hipFree(tfd); hipFree(dld);
+    hipFree(tfd); hipFree(dld); hipFree(tfr_d); hipFree(dlr_d); hipFree(tfv_d); hipFree(dlv_d);
     hipFree(ix->indptr); hipFree(ix->idf);                         // only the builders above read them: the metadata carries both
     ix->indptr = nullptr; ix->idf = nullptr;
     if (e != hipSuccess || e2 != hipSuccess) {
@@ -774,7 +944,9 @@ int bm25_load_host(rag_ctx* h, const int64_t* indptr, const int32_t* doc, const 
 
 static int bm25_set_attr(rag_ctx* h) {
     if (!h->attr_bm25) {
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bm25_range_kernel),
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bm25_range_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, BM_LDS_BYTES));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bm25_range_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, BM_LDS_BYTES));
         h->attr_bm25 = true;
     }
@@ -843,10 +1015,9 @@ static int bm25_run(rag_ctx* h, rag_bm25_index* ix, const int32_t* term_ptr, con
         if (raw_max_out) HIP_TRY(h, hipMemcpyAsync(raw_max_out, mxd, (size_t)Q * sizeof(double), hipMemcpyDeviceToHost, st));
     } else {
         bm25_launch_plan(ix, tp, tm, Q, w.plan, st);
-        hipLaunchKernelGGL(bm25_range_kernel, dim3(nr, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->meta, ix->doc, ix->w,
-                           ix->range_tab, nr, tp, tm, ix->n_docs, ix->n_terms, k, 1, dd, (uint64_t*)nullptr, (uint32_t*)nullptr, 0,
-                           (const uint64_t*)nullptr, (int*)nullptr, (const int32_t*)nullptr, -1, (const int32_t*)w.plan.off,
-                           (const bm_plan_meta*)w.plan.meta);
+        BM_RANGE_LAUNCH(ix, dim3(nr, Q), st, nr, tp, tm, k, 1, dd, (uint64_t*)nullptr, (uint32_t*)nullptr, 0,
+                        (const uint64_t*)nullptr, (int*)nullptr, (const int32_t*)nullptr, -1, (const int32_t*)w.plan.off,
+                        (const bm_plan_meta*)w.plan.meta)
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipMemcpyAsync(dense_out, dd, n_dense * sizeof(double), hipMemcpyDeviceToHost, st));
     }
@@ -938,10 +1109,9 @@ int bm25_scores_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* term
     if ((rc = bm25_ensure_plan(h, ix, Q))) return rc;
     const bm25_plan_ws pw = {ix->ws_plan_off, ix->ws_plan_meta};
     bm25_launch_plan(ix, term_ptr_dev, terms_dev, Q, pw, st);
-    hipLaunchKernelGGL(bm25_range_kernel, dim3(ix->n_ranges, Q), dim3(BM_THREADS), BM_LDS_BYTES, st, ix->meta, ix->doc, ix->w,
-                       ix->range_tab, ix->n_ranges, term_ptr_dev, terms_dev, ix->n_docs, ix->n_terms, 1, 1, out_dev, (uint64_t*)nullptr,
-                       (uint32_t*)nullptr, 0, (const uint64_t*)nullptr, (int*)nullptr, (const int32_t*)nullptr, -1,
-                       (const int32_t*)pw.off, (const bm_plan_meta*)pw.meta);
+    BM_RANGE_LAUNCH(ix, dim3(ix->n_ranges, Q), st, ix->n_ranges, term_ptr_dev, terms_dev, 1, 1, out_dev, (uint64_t*)nullptr,
+                    (uint32_t*)nullptr, 0, (const uint64_t*)nullptr, (int*)nullptr, (const int32_t*)nullptr, -1,
+                    (const int32_t*)pw.off, (const bm_plan_meta*)pw.meta)
     HIP_TRY(h, hipGetLastError());
     return RAG_OK;
 }
@@ -967,7 +1137,7 @@ int bm25_index_bytes(const int64_t* indptr, int64_t n_docs, int64_t n_terms, int
         bm_plan_term(df, n_pad, &e_t);
         n_tab += e_t;
     }
-    if (postings_out) *postings_out = ((n_terms ? indptr[n_terms] - indptr[0] : 0) + 8) * 12;
+    if (postings_out) *postings_out = ((n_terms ? indptr[n_terms] - indptr[0] : 0) + 8) * 12;     // default form: doc i32 + impact f64
     if (meta_out) *meta_out = n_terms * (int64_t)sizeof(bm_term_meta);
     if (table_out) *table_out = n_tab * 4;
     return RAG_OK;

@@ -140,3 +140,37 @@ def test_two_million_term_zipf_vocabulary(eng):
         top = O.stable_topk_desc(raw, k)
         np.testing.assert_array_equal(rows[qi], top.astype(np.int32))
         np.testing.assert_array_equal(sc[qi], raw[top] / (raw.max() if raw.max() > 0 else 1.0))
+
+
+def test_packed_postings_equal_the_twelve_byte_form(eng):
+    """Option bm25_packed: the scoring loop streams 4-byte postings (document number inside its range | code of its (tf, doc length) pair) and
+    multiplies idf by a table value g[code] instead of streaming (doc i32, impact f64). Both are the same float64 product
+    (`idf * (num / den)`, rank-bm25's association), so top-k rows, scores and all-document scores must be bit-identical between
+    an index loaded with the option and a default one - and equal to the CSR oracle. Term frequencies up to 300
+    and document lengths spread over thousands of values exercise a large code table."""
+    from optimized_rag_amd import RagEngine
+    rng = np.random.default_rng(77)
+    n_docs = 40_000
+    lists = [rng.choice(n_docs, n, replace=False) for n in (40_000, 21_000, 5000, 700, 64, 9, 3)]
+    post = _postings(n_docs, lists, rng)
+    post.tf[:] = rng.integers(1, 301, post.tf.shape[0]).astype(np.int32)
+    post.doc_len[:] = rng.integers(1, 6000, n_docs).astype(np.int32)
+    post.avgdl = float(post.doc_len.sum()) / n_docs
+    terms_of = [[0, 1, 2], [3, 4, 5, 6], [0], [2, 2, 6, -1], [1, 3, 5]]
+    ptr = np.cumsum([0] + [len(t) for t in terms_of]).astype(np.int32)
+    terms = np.asarray([x for t in terms_of for x in t], dtype=np.int32)
+    out = {}
+    for name, flag in (("packed", 1), ("wide", 0)):
+        e = RagEngine(dim=64, device=0)
+        try:
+            e.set_option("bm25_packed", flag)
+            post.load(e)
+            out[name] = (e.bm25_topk(ptr, terms, 50), e.bm25_scores(ptr, terms))
+        finally:
+            e.close()
+    for a, b in zip(out["packed"][0], out["wide"][0]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(out["packed"][1], out["wide"][1])
+    for qi, t in enumerate(terms_of):
+        raw = O.bm25_scores_csr(post.indptr, post.doc, post.tf, post.doc_len, post.idf, post.avgdl, t)
+        np.testing.assert_array_equal(out["packed"][1][qi], raw)

@@ -13,6 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 for part in "$@"; do
 case $part in
 bm25pmc)
+  export RAG_NO_FORK=1          # the two hybrid legs in line: per-kernel durations are then those of the BM25 leg alone
   CMD="python3 $R/bench.py --mode hybrid --only-hybrid-calls --steps 6 --warmup 1"
   echo "== hybrid kernel stats"; timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $S/hy_stats -o s -- $CMD > $O/r3m_hybrid_stats.log 2>&1 || echo FAILED
   python3 $R/tools/rocpd_top.py $S/hy_stats/s_results.db > $O/r3m_hybrid_kernel_stats.csv
@@ -20,7 +21,8 @@ bm25pmc)
     tag=$(echo $pmc | tr ' ' '_')
     echo "== hybrid pmc $pmc"; timeout -k 10 400 rocprofv3 --pmc $pmc --kernel-trace -d $S/hy_$tag -o p -- $CMD > $O/r3m_hybrid_pmc_$tag.log 2>&1 || echo FAILED
     python3 $R/tools/rocpd_pmc.py $S/hy_$tag/p_results.db bm25 > $O/r3m_hybrid_pmc_$tag.json
-  done ;;
+  done
+  unset RAG_NO_FORK ;;
 cepmc)
   CMD="python3 $R/bench.py --mode rerank"
   echo "== rerank kernel stats"; timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $S/ce_stats -o s -- $CMD > $O/r3m_ce_stats.log 2>&1 || echo FAILED
