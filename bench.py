@@ -311,12 +311,30 @@ def main():
     got_sc = final_scores.cpu().numpy()
     planted_hit = float((got_ids[:, 0] == planted.numpy()).mean())
 
+    def finish(block):
+        headline_line(args, world, n_local, tenant, gemm_ms, gemm_launches, dt, p50, lat1, stats, planted_hit, comm, host_corpus,
+                      queries, got_ids, got_sc, eng, block)
+
     # ---- N > 1: BASELINE.json configs[4] at its real per-GPU size (12.5M rows each; weak scaling) through the sharded classes
     shard_block = None
     if world > 1 and args.shard_rows > 0 and args.corpus == "iid":
         import bench_shard as BS
         ranks_seen = torch.ones(1, device=device)
         dist.all_reduce(ranks_seen)                                # what the collective layer itself counted
+        # The block is a secondary result: if it stalls (one rank failing inside a collective leaves the others waiting), the
+        # headline line measured above must still come out. A timer thread prints it from rank 0 and ends every rank.
+        import threading
+        deadline = float(os.environ.get("RAG_BENCH_SHARD_DEADLINE", "600"))
+
+        def give_up():
+            if rank == 0:
+                finish({"error": f"no result within {deadline:.0f} s (RAG_BENCH_SHARD_DEADLINE); headline unaffected"})
+            sys.stdout.flush()
+            os._exit(0)
+
+        watchdog = threading.Timer(deadline, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             del index
             st_sh = BS.build_shard(eng, device, args.shard_rows, rank=rank, world=world, Q=256)
@@ -327,12 +345,21 @@ def main():
                                             "hybrid (BM25 over a 2M-term vocabulary) and retrieve + rerank, 256-query batches"})
         except Exception as e:                                     # never at the cost of the headline line
             shard_block = {"error": f"{type(e).__name__}: {e}"}
-
+        watchdog.cancel()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
+    finish(shard_block)
+    if world > 1:
+        dist.destroy_process_group()
 
+
+def headline_line(args, world, n_local, tenant, gemm_ms, gemm_launches, dt, p50, lat1, stats, planted_hit, comm, host_corpus, queries,
+                  got_ids, got_sc, eng, shard_block):
+    """Rank 0: the roofline / cpu_baseline objects and the ONE JSON line. For N > 1 nothing here touches the GPU or a collective
+    (it may run on the watchdog thread while the main thread waits inside one)."""
+    Q, k = args.queries, args.k
     # ---- roofline of the dominant kernel: dense_emit_kernel<false> (the thresholded GEMM stages) -----------
     # rows one search scores: the whole shard, or (tenant filter) the tenant's own tiles only
     t_lo, t_hi = (BENCH_TENANT * args.rows // N_TENANTS, (BENCH_TENANT + 1) * args.rows // N_TENANTS) if tenant >= 0 else (0, n_local)
@@ -426,9 +453,7 @@ def main():
                 out[name] = {"error": f"{type(e).__name__}: {e}"}
     if shard_block is not None:
         out["shard_12p5M"] = shard_block
-    print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
 
 
 def launcher_selftest(args):
