@@ -242,6 +242,26 @@ __global__ __launch_bounds__(256) void bm25_plan_kernel(const bm_term_meta* __re
     }
 }
 
+// Launch geometry of the scoring kernel: a 1-D grid over (range of this launch, query). The hardware hands consecutive workgroup
+// ids to the 8 XCDs in turn, each XCD has its own 4 MiB L2, and one range's postings are ~2 MB: with the queries of a column
+// running side by side on one XCD, the posting segments the queries share (frequent terms: most of the bytes) are served by
+// that L2. n_groups splits the queries of a range into several columns when a launch has few ranges (the opening stages), so
+// that every XCD owns >= 16 columns or so and the XCDs finish together. Few queries (qgroup_len = 0): range-major, the ranges
+// of one query spread over the chip. The id -> XCD rule is a performance assumption only; any placement gives the same result.
+struct bm_grid { unsigned blocks; int nr_l, n_queries, n_groups, qgroup_len; };
+static bm_grid bm_make_grid(int nr_l, int Q, int linear) {
+    bm_grid g{(unsigned)((int64_t)nr_l * Q), nr_l, Q, 1, 0};
+    if (linear || Q < 128) return g;
+    int G = 1;
+    while (nr_l * G < 128 && G < 8 && Q / (2 * G) >= 64) G <<= 1;
+    const int ql = (Q + G - 1) / G;
+    const int64_t per_xcd = ((int64_t)nr_l * G + 7) / 8;
+    g.blocks = (unsigned)(8 * per_xcd * ql);
+    g.n_groups = G;
+    g.qgroup_len = ql;
+    return g;
+}
+
 // One workgroup per (query, doc range).
 // mode 0: per-range top-k partials; mode 1: dense scores out[q][doc]
 // PACKED (option bm25_packed, off by default - see rag_bm25_index): the scoring loop streams 4-byte postings (document number
@@ -259,16 +279,31 @@ __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_num_sgpr(96))) vo
                                                                  uint32_t* __restrict__ part_row, int range_begin,
                                                                  const uint64_t* __restrict__ tau_key, int* __restrict__ part_cnt,
                                                                  const int32_t* __restrict__ tenants, int tenant,
-                                                                 const int32_t* __restrict__ plan_off, const bm_plan_meta* __restrict__ plan_meta) {
+                                                                 const int32_t* __restrict__ plan_off, const bm_plan_meta* __restrict__ plan_meta,
+                                                                 const bm_grid gm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int r = range_begin + blockIdx.x;
+    // workgroup -> (range, query), see bm_make_grid: XCD x (= workgroup id % 8) walks its columns (range, query group) one after the
+    // other, every query of the group on the SAME range side by side, so a range's postings are fetched into that XCD's L2 once
+    // per column instead of once per query that holds the term.
+    int r, q;
+    if (gm.qgroup_len == 0) {
+        r = range_begin + (int)(blockIdx.x % (unsigned)gm.nr_l);
+        q = (int)(blockIdx.x / (unsigned)gm.nr_l);
+    } else {
+        const unsigned x = blockIdx.x & 7u, s_ = blockIdx.x >> 3;
+        const unsigned col = x + 8u * (s_ / (unsigned)gm.qgroup_len), qi = s_ % (unsigned)gm.qgroup_len;
+        const int rl = (int)(col / (unsigned)gm.n_groups);
+        q = (int)(col % (unsigned)gm.n_groups) * gm.qgroup_len + (int)qi;
+        if (rl >= gm.nr_l || q >= gm.n_queries) return;
+        r = range_begin + rl;
+    }
     // the query's threshold (thresholded stages) is fetched up front: at the compaction step it would be an exposed global
     // round trip for every workgroup
-    const uint64_t tk = tau_key != nullptr ? tau_key[blockIdx.y] : 0ull;
+    const uint64_t tk = tau_key != nullptr ? tau_key[q] : 0ull;
     double* sc = reinterpret_cast<double*>(smem);                       // [BM_RANGE]
     int* hist = reinterpret_cast<int*>(smem + BM_SC_DOUBLES * 8);       // [256]
     int* wsum = hist + 256;                                             // [16] scratch
-    const int q = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int64_t base = (int64_t)r * BM_RANGE;
     const int lim = (int)min((int64_t)BM_RANGE, n_docs - base);
@@ -757,14 +792,15 @@ struct bm25_topk_out {
 // compacts keys >= tau. Expected survivors per stage ~ k * growth per query however large the shard is (a single
 // threshold from 32768 docs left ~k/2 per range: 38 k entries per query to merge on a 12.5M-doc shard).
 // the scoring launch: packed 4-byte postings when the index has them, the 12-byte form otherwise
-#define BM_RANGE_LAUNCH(IX, GRID, ST, NR, TP, TM, K, MODE, ...)                                                                    \
+#define BM_RANGE_LAUNCH(H, IX, NR_L, NQ, ST, NR, TP, TM, K, MODE, ...)                                                             \
     {                                                                                                                              \
+        const bm_grid gm_ = bm_make_grid(NR_L, NQ, (H)->opt.bm25_linear_grid);                                                     \
         if ((IX)->packed != nullptr)                                                                                               \
-            hipLaunchKernelGGL(bm25_range_kernel<true>, GRID, dim3(BM_THREADS), BM_LDS_BYTES, ST, (IX)->meta, (IX)->doc, (IX)->w,  \
-                               (IX)->packed, (IX)->gtab, (IX)->range_tab, NR, TP, TM, (IX)->n_docs, (IX)->n_terms, K, MODE, __VA_ARGS__); \
+            hipLaunchKernelGGL(bm25_range_kernel<true>, dim3(gm_.blocks), dim3(BM_THREADS), BM_LDS_BYTES, ST, (IX)->meta, (IX)->doc, (IX)->w, \
+                               (IX)->packed, (IX)->gtab, (IX)->range_tab, NR, TP, TM, (IX)->n_docs, (IX)->n_terms, K, MODE, __VA_ARGS__, gm_); \
         else                                                                                                                       \
-            hipLaunchKernelGGL(bm25_range_kernel<false>, GRID, dim3(BM_THREADS), BM_LDS_BYTES, ST, (IX)->meta, (IX)->doc, (IX)->w, \
-                               (IX)->packed, (IX)->gtab, (IX)->range_tab, NR, TP, TM, (IX)->n_docs, (IX)->n_terms, K, MODE, __VA_ARGS__); \
+            hipLaunchKernelGGL(bm25_range_kernel<false>, dim3(gm_.blocks), dim3(BM_THREADS), BM_LDS_BYTES, ST, (IX)->meta, (IX)->doc, (IX)->w, \
+                               (IX)->packed, (IX)->gtab, (IX)->range_tab, NR, TP, TM, (IX)->n_docs, (IX)->n_terms, K, MODE, __VA_ARGS__, gm_); \
     }
 static size_t bm25_plan_off_entries(const rag_bm25_index* ix, int Q) { return (size_t)Q * BM_PLAN_T * (ix->n_ranges + 1); }
 static void bm25_launch_plan(const rag_bm25_index* ix, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, const bm25_plan_ws& p,
@@ -783,7 +819,7 @@ static void bm25_launch_topk(const rag_ctx* h, const rag_bm25_index* ix, const i
     while (begin < nr) {
         int end = !staged ? nr : (stage == 0 ? first_cfg : (int)std::min<int64_t>(nr, (int64_t)begin * BM_STAGE_GROWTH));
         if (staged && nr - end < end / 4) end = nr;                   // no tiny trailing stage
-        BM_RANGE_LAUNCH(ix, dim3(end - begin, Q), st, nr, term_ptr_dev, terms_dev, k, 0, (double*)nullptr,
+        BM_RANGE_LAUNCH(h, ix, end - begin, Q, st, nr, term_ptr_dev, terms_dev, k, 0, (double*)nullptr,
                         w.part_key, w.part_row, begin, stage == 0 ? (const uint64_t*)nullptr : (const uint64_t*)w.tau, w.part_cnt,
                         tenants, tenant, (const int32_t*)w.plan.off, (const bm_plan_meta*)w.plan.meta)
         const int last = end == nr;
@@ -1015,7 +1051,7 @@ static int bm25_run(rag_ctx* h, rag_bm25_index* ix, const int32_t* term_ptr, con
         if (raw_max_out) HIP_TRY(h, hipMemcpyAsync(raw_max_out, mxd, (size_t)Q * sizeof(double), hipMemcpyDeviceToHost, st));
     } else {
         bm25_launch_plan(ix, tp, tm, Q, w.plan, st);
-        BM_RANGE_LAUNCH(ix, dim3(nr, Q), st, nr, tp, tm, k, 1, dd, (uint64_t*)nullptr, (uint32_t*)nullptr, 0,
+        BM_RANGE_LAUNCH(h, ix, nr, Q, st, nr, tp, tm, k, 1, dd, (uint64_t*)nullptr, (uint32_t*)nullptr, 0,
                         (const uint64_t*)nullptr, (int*)nullptr, (const int32_t*)nullptr, -1, (const int32_t*)w.plan.off,
                         (const bm_plan_meta*)w.plan.meta)
         HIP_TRY(h, hipGetLastError());
@@ -1109,7 +1145,7 @@ int bm25_scores_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* term
     if ((rc = bm25_ensure_plan(h, ix, Q))) return rc;
     const bm25_plan_ws pw = {ix->ws_plan_off, ix->ws_plan_meta};
     bm25_launch_plan(ix, term_ptr_dev, terms_dev, Q, pw, st);
-    BM_RANGE_LAUNCH(ix, dim3(ix->n_ranges, Q), st, ix->n_ranges, term_ptr_dev, terms_dev, 1, 1, out_dev, (uint64_t*)nullptr,
+    BM_RANGE_LAUNCH(h, ix, ix->n_ranges, Q, st, ix->n_ranges, term_ptr_dev, terms_dev, 1, 1, out_dev, (uint64_t*)nullptr,
                     (uint32_t*)nullptr, 0, (const uint64_t*)nullptr, (int*)nullptr, (const int32_t*)nullptr, -1,
                     (const int32_t*)pw.off, (const bm_plan_meta*)pw.meta)
     HIP_TRY(h, hipGetLastError());

@@ -38,6 +38,7 @@ struct rag_options {
     int dense_linear_order = 0;   // walk the tiles in table order (r1 behaviour, for A/B)
     int bm25_first_ranges = 0;    // exact first-stage BM25 ranges (0 = BM_FIRST_RANGES)
     int bm25_no_staging = 0;      // exact per-range select for every BM25 range
+    int bm25_linear_grid = 0;     // scoring workgroups range-major (the ranges of one query side by side) instead of the XCD-aware column order
     int bm25_packed = 0;          // (read when postings are LOADED) 4-byte packed postings + shared impact table instead of (doc, impact)
     int no_fork = 0;              // keep the BM25 leg of a small hybrid batch in line on the caller's stream
     int fork_max_q = 0;           // largest batch whose BM25 leg runs on the side stream beside the dense leg (0 = RAG_FORK_MAX_Q)
