@@ -40,6 +40,9 @@ typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
 // made the per-thread segment reads of the select conflict-free; with 8 docs per thread it still spreads the lanes (lane t
 // starts at bank pair 8(t%4) + t/4: at most 2-way instead of 8-way). The adds of the token loop fall on random banks either way.
 #define SC_IDX(i) ((i) + ((i) >> 5))
+// the same place as an LDS byte offset, from an UNSIGNED index: shift, add-and-shift (the pointer form &sc[SC_IDX(i)] costs the
+// token loop two more vector instructions per posting, and that loop is bound by vector-instruction issue - DESIGN 4.2)
+#define SC_OFF(u) ((((uint32_t)(u)) + (((uint32_t)(u)) >> 5)) << 3)
 #define BM_SC_DOUBLES (BM_RANGE + BM_RANGE / 32)
 #define BM_LDS_BYTES (BM_SC_DOUBLES * 8 + 4096)
 
@@ -458,11 +461,22 @@ __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_num_sgpr(96))) vo
 #define BM_ADD(TI, C, D, W0, W1)                                                                   \
             {                                                                                      \
                 const int p_ = (C) * 4 * BM_THREADS + tid * 4, n_ = TOK_N(TI);                     \
-                if (p_ < n_) {                                                                     \
-                    double* a0_ = &sc[SC_IDX(D[0] - (int)base)];                                   \
-                    double* a1_ = p_ + 1 < n_ ? &sc[SC_IDX(D[1] - (int)base)] : &sc[BM_SC_DOUBLES - 1]; \
-                    double* a2_ = p_ + 2 < n_ ? &sc[SC_IDX(D[2] - (int)base)] : &sc[BM_SC_DOUBLES - 2]; \
-                    double* a3_ = p_ + 3 < n_ ? &sc[SC_IDX(D[3] - (int)base)] : &sc[BM_SC_DOUBLES - 3]; \
+                char* const sb_ = reinterpret_cast<char*>(sc);                                     \
+                if (((C) + 1) * 4 * BM_THREADS <= n_) {      /* a full chunk (uniform): no tail tests */ \
+                    double* a0_ = reinterpret_cast<double*>(sb_ + SC_OFF(D[0] - (int)base));       \
+                    double* a1_ = reinterpret_cast<double*>(sb_ + SC_OFF(D[1] - (int)base));       \
+                    double* a2_ = reinterpret_cast<double*>(sb_ + SC_OFF(D[2] - (int)base));       \
+                    double* a3_ = reinterpret_cast<double*>(sb_ + SC_OFF(D[3] - (int)base));       \
+                    const double v0_ = *a0_, v1_ = *a1_, v2_ = *a2_, v3_ = *a3_;                   \
+                    *a0_ = v0_ + W0[0];                                                            \
+                    *a1_ = v1_ + W0[1];                                                            \
+                    *a2_ = v2_ + W1[0];                                                            \
+                    *a3_ = v3_ + W1[1];                                                            \
+                } else if (p_ < n_) {                                                              \
+                    double* a0_ = reinterpret_cast<double*>(sb_ + SC_OFF(D[0] - (int)base));       \
+                    double* a1_ = p_ + 1 < n_ ? reinterpret_cast<double*>(sb_ + SC_OFF(D[1] - (int)base)) : &sc[BM_SC_DOUBLES - 1]; \
+                    double* a2_ = p_ + 2 < n_ ? reinterpret_cast<double*>(sb_ + SC_OFF(D[2] - (int)base)) : &sc[BM_SC_DOUBLES - 2]; \
+                    double* a3_ = p_ + 3 < n_ ? reinterpret_cast<double*>(sb_ + SC_OFF(D[3] - (int)base)) : &sc[BM_SC_DOUBLES - 3]; \
                     const double v0_ = *a0_, v1_ = *a1_, v2_ = *a2_, v3_ = *a3_;                   \
                     *a0_ = v0_ + W0[0];                                                            \
                     if (p_ + 1 < n_) *a1_ = v1_ + W0[1];                                           \
@@ -516,23 +530,34 @@ __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_num_sgpr(96))) vo
         return;
     }
     const int seg0 = tid * BM_SEG;
-    uint64_t keys[BM_SEG];           // this thread's BM_SEG docs, read once
+    // this thread's BM_SEG docs, read once and UNCONDITIONALLY (the whole LDS array is initialised, a guarded read per doc was
+    // eight serial LDS round trips); bit j of `valid` = doc seg0 + j exists and belongs to the tenant
+    double sv[BM_SEG];
 #pragma unroll
-    for (int j = 0; j < BM_SEG; ++j) keys[j] = (seg0 + j) < lim ? f64_orderable(sc[SC_IDX(seg0 + j)]) : 0ull;
+    for (int j = 0; j < BM_SEG; ++j) sv[j] = sc[SC_IDX(seg0 + j)];
+    const int n_here = lim - seg0;
+    unsigned valid = n_here >= BM_SEG ? (1u << BM_SEG) - 1u : (n_here <= 0 ? 0u : (1u << n_here) - 1u);
     if (tenants != nullptr) {
 #pragma unroll
         for (int j = 0; j < BM_SEG; ++j)
-            if ((seg0 + j) < lim && tenants[base + seg0 + j] != tenant) keys[j] = 0ull;
+            if ((valid >> j & 1u) && tenants[base + seg0 + j] != tenant) valid &= ~(1u << j);
     }
     // Thresholded ranges (second stage, see bm25_launch_topk): tau_key[q] is the k-th best key over the first-stage
     // ranges, a lower bound of the global k-th. Only keys >= tau can reach the global top-k; a later range holds
     // about k * BM_RANGE / (docs of stage one) of them, so they are compacted in doc order (the merge sorts anyway) and the
     // 8-pass radix select — 26 us per block, three quarters of this kernel's time when run for every range — is
     // skipped. More than k survivors (possible, e.g. a tie plateau) falls through to the exact select below.
+    // The test runs on the scores themselves: key(s) >= tau_key <=> s >= the double tau_key stands for (the key map is a monotone
+    // bijection of the non-NaN doubles; an accumulator is never -0.0: it starts at +0.0 and x + y is -0.0 only for two -0.0),
+    // one compare per document instead of a key conversion and two 64-bit compares; only survivors are converted.
     if (tau_key != nullptr) {
-        int n_in = 0;
+        const uint64_t tb_ = (tk & 0x8000000000000000ull) ? (tk & 0x7fffffffffffffffull) : ~tk;
+        const double tau_d = tk == 0ull ? -__builtin_inf() : __builtin_bit_cast(double, tb_);
+        unsigned pass = 0;
 #pragma unroll
-        for (int j = 0; j < BM_SEG; ++j) n_in += keys[j] != 0ull && keys[j] >= tk;
+        for (int j = 0; j < BM_SEG; ++j) pass |= (sv[j] >= tau_d ? 1u : 0u) << j;
+        pass &= valid;
+        const int n_in = __builtin_popcount(pass);
         int sc_in = n_in;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -548,17 +573,22 @@ __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_num_sgpr(96))) vo
         }
         __syncthreads();                                   // hist is reused by the select below
         if (total_in <= k) {
+            if (pass) {
 #pragma unroll
-            for (int j = 0; j < BM_SEG; ++j)
-                if (keys[j] != 0ull && keys[j] >= tk) {
-                    part_key[po + off] = keys[j];
-                    part_row[po + off] = (uint32_t)(base + seg0 + j);
-                    ++off;
-                }
+                for (int j = 0; j < BM_SEG; ++j)
+                    if (pass >> j & 1u) {
+                        part_key[po + off] = f64_orderable(sv[j]);
+                        part_row[po + off] = (uint32_t)(base + seg0 + j);
+                        ++off;
+                    }
+            }
             if (tid == 0) part_cnt[(size_t)q * n_ranges + r] = total_in;
             return;
         }
     }
+    uint64_t keys[BM_SEG];
+#pragma unroll
+    for (int j = 0; j < BM_SEG; ++j) keys[j] = (valid >> j & 1u) ? f64_orderable(sv[j]) : 0ull;
     uint64_t prefix = 0ull;          // matched high bytes of the pivot
     int remaining = k;               // the pivot is the `remaining`-th largest among keys matching `prefix`
     for (int pass = 0; pass < 8; ++pass) {
