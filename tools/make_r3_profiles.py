@@ -30,28 +30,53 @@ ks = stats("r3m_hybrid_kernel_stats.csv")
 fetch, write, tcc = pmc("r3m_hybrid_pmc_FETCH_SIZE.json"), pmc("r3m_hybrid_pmc_WRITE_SIZE.json"), pmc("r3m_hybrid_pmc_TCC_HIT_sum_TCC_MISS_sum.json")
 kern = {}
 for short in ("bm25_range_kernel", "bm25_merge_stage_kernel", "bm25_plan_kernel"):
-    s = pick(ks, short + "(")
+    s = pick(ks, short)
     f, w, t = pick(fetch, short)["FETCH_SIZE"], pick(write, short)["WRITE_SIZE"], pick(tcc, short)
     per_call = f["launches"] / calls
     kern[short] = {"launches_per_call": per_call, "avg_us_per_launch": float(s["AverageUs"]), "us_per_call": float(s["TotalDurationUs"]) / calls,
                    "fetch_bytes_per_call_x2": f["mean"] * 1024 * 2 * per_call, "write_bytes_per_call": w["mean"] * 1024 * per_call,
                    "l2_hit_rate": t["TCC_HIT_sum"]["mean"] / (t["TCC_HIT_sum"]["mean"] + t["TCC_MISS_sum"]["mean"])}
+# SQ-side counters of the range kernel (tools/bm25_sq_pmc.sh: three more --pmc passes of the same command), per launch
+sq = {}
+for i in (1, 2, 3):
+    f_ = os.path.join(O, "bm25_sq_%d.json" % i)
+    if os.path.exists(f_):
+        for name, v in json.load(open(f_)).items():
+            if "bm25_range_kernel" in name:
+                sq.update({cn: c["mean"] for cn, c in v.items()})
+if "GRBM_GUI_ACTIVE" in sq:
+    cyc = sq["GRBM_GUI_ACTIVE"] / 8.0                          # the counter is summed over the 8 XCDs
+    sq["kernel_cycles"] = cyc
+    sq["valu_busy_per_simd"] = sq["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cyc
+    sq["salu_busy_per_simd"] = sq["SQ_ACTIVE_INST_SCA"] * 4 / 1024 / cyc
+    sq["lds_busy_per_simd"] = sq["SQ_ACTIVE_INST_LDS"] * 4 / 1024 / cyc
+    sq["wait_any_share"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
+    sq["valu_instructions_per_wave"] = sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"]
+    sq["salu_instructions_per_wave"] = sq["SQ_INSTS_SALU"] / sq["SQ_WAVES"]
 us = sum(k["us_per_call"] for k in kern.values())
 traffic = sum(k["fetch_bytes_per_call_x2"] + k["write_bytes_per_call"] for k in kern.values())
 alg = line["bm25"]["postings_touched_per_batch"] * 12.0
 json.dump({
     "source": "tools/r3_measure.sh bm25pmc on one MI355X (round 3): rocprofv3 --kernel-trace --stats and three separate --pmc passes (FETCH_SIZE | "
               "WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum) of `python3 bench.py --mode hybrid --only-hybrid-calls --steps 6 --warmup 1`: every BM25 launch "
-              "belongs to one of %d rag_hybrid_rrf_dev calls of 1024 queries (1M docs, nnz 9.5e7, 2048-document ranges x 256 threads, staged "
-              "threshold: 4 range + 4 merge launches and 1 plan launch per call). FETCH_SIZE x2 per MI355X_MICROARCH.md." % calls,
+              "belongs to one of %d rag_hybrid_rrf_dev calls of 1024 queries (1M docs, nnz 9.5e7, 2048-document ranges x 256 threads, XCD-aware "
+              "workgroup order, staged threshold: 4 range + 4 merge launches and 1 plan launch per call). FETCH_SIZE x2 per MI355X_MICROARCH.md." % calls,
     "bench_line_of_the_profiled_run": {k: line[k] for k in ("value", "ms_per_step")},
     "kernels": kern,
     "per_call": {"bm25_device_us_under_rocprof": us, "algorithmic_bytes": alg, "hbm_traffic_bytes": traffic,
                  "traffic_over_algorithmic": traffic / alg, "algorithmic_GBs": alg / us * 1e-3, "traffic_GBs": traffic / us * 1e-3},
-    "reading": "The L2 serves %.0f %% of the range kernel's requests (r1's 89 %% was a different kernel: 16384-document ranges); what leaves L2 is "
-               "%.1f GB per 1024-query batch against %.1f GB algorithmic, i.e. the posting stream runs at %.1f TB/s of fabric traffic = %.2f of the "
-               "8 TB/s HBM peak (0.8 of the ~6.3 TB/s a streaming kernel reaches): the BM25 leg is HBM-bound, not L2-bound."
-               % (100 * kern["bm25_range_kernel"]["l2_hit_rate"], traffic / 1e9, alg / 1e9, traffic / us * 1e-6, traffic / us * 1e-6 / 8.0),
+    "sq_counters_range_kernel": sq,
+    "reading": "With the XCD-aware workgroup order (every query of a column on the same 2048-document range, side by side on one XCD) the L2 "
+               "serves %.0f %% of the range kernel's requests (range-major order, profiles/r03_bm25_pmc_range_major_order.json: 42 %%, 17.2 GB "
+               "leaving L2 per batch); what leaves L2 now is %.2f GB per 1024-query batch against %.1f GB algorithmic (sum over the queries of "
+               "df x 12 B: the batch shares its frequent terms, the L2 now sees that). The posting stream is served by the L2 at %.1f TB/s; "
+               "algorithmic bytes / time exceeds the 8 TB/s HBM peak, so the HBM roof no longer describes this kernel. What bounds it is "
+               "instruction issue: per SIMD the vector ALU is busy %.0f %% and the scalar ALU %.0f %% of the kernel's cycles (SQ_ACTIVE_INST_VALU / "
+               "_SCA, in 4-cycle units, / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8)), waves are parked at a barrier or waitcnt %.0f %% of their "
+               "lifetime (SQ_WAIT_ANY / SQ_WAVE_CYCLES): ~10 (token, chunk) iterations per workgroup, each with a barrier, about half of them "
+               "for a term with a handful of postings in the range."
+               % (100 * kern["bm25_range_kernel"]["l2_hit_rate"], traffic / 1e9, alg / 1e9, alg / us * 1e-6,
+                  100 * sq.get("valu_busy_per_simd", 0), 100 * sq.get("salu_busy_per_simd", 0), 100 * sq.get("wait_any_share", 0)),
 }, open(os.path.join(P, "r03_bm25_pmc.json"), "w"), indent=1)
 
 # ---- cross-encoder: `python3 bench.py --mode rerank`: 3 forwards of 25,600 pairs = 4 activation chunks each, 6 layers
