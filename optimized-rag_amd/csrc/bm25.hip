@@ -702,7 +702,9 @@ __device__ __forceinline__ void bm_sort_pairs(uint64_t* k1, uint32_t* k2, int P,
 
 #define BM_FIRST_RANGES 4      // exact per-range top-k for these (8192 docs), thresholded compaction for the rest (2048-doc ranges: 2 -> 134.2 k hybrid q/s, 4 -> 151.2 k;
                                // 4096-doc ranges: 2 -> 144.8 k, 4 -> 143.3 k; 16384-doc ranges, BM25 leg alone: 1 -> 7.5 ms, 2 -> 4.87, 4 -> 5.08)
+#ifndef BM_STAGE_GROWTH        // -DBM_STAGE_GROWTH: variant builds (tools/lib_ab.sh; r3: 4 -> 3.04 ms, 8 -> 2.88, 16 -> 3.05, 32 -> 3.44 per 1024-query batch)
 #define BM_STAGE_GROWTH 8      // every thresholded stage covers up to 8x the ranges seen before it
+#endif
 
 // Folds the partial lists of the doc ranges [r_begin, r_end) into the query's RUNNING top-k (run_key / run_row [Q][k], key 0 =
 // empty) and publishes tau_key[q] = its k-th key: a lower bound of the global k-th best, 0 ("everything passes") while fewer

@@ -174,3 +174,40 @@ def test_packed_postings_equal_the_twelve_byte_form(eng):
     for qi, t in enumerate(terms_of):
         raw = O.bm25_scores_csr(post.indptr, post.doc, post.tf, post.doc_len, post.idf, post.avgdl, t)
         np.testing.assert_array_equal(out["packed"][1][qi], raw)
+
+
+def test_column_workgroup_order_equals_range_major(eng):
+    """From 128 queries on, the scoring workgroups are ordered in XCD-aware columns (csrc/bm25.hip bm_make_grid: every query of a
+    column on the same 2048-document range, the queries of a range split into up to 8 columns when a launch has few ranges, empty
+    workgroups where columns x queries do not fill the grid). Placement must not change a bit: top-k rows / scores / maxima and
+    all-document scores equal the range-major order (option bm25_linear_grid) and the CSR oracle, for query counts that hit
+    every split (129: groups of 65 with padding; 200; 260: ragged last group) on 3 and on 45 ranges."""
+    rng = np.random.default_rng(4242)
+    for n_docs in (5_000, 91_000):
+        lists = [rng.choice(n_docs, int(np.exp(rng.uniform(0, np.log(n_docs)))), replace=False) for _ in range(60)]
+        lists[0] = np.arange(n_docs)
+        post = _postings(n_docs, lists, rng).load(eng)
+        for Q in (129, 200, 260):
+            terms_of = [list(rng.integers(-1, 60, int(rng.integers(1, 9)))) for _ in range(Q)]
+            ptr = np.cumsum([0] + [len(t) for t in terms_of]).astype(np.int32)
+            terms = np.asarray([x for t in terms_of for x in t], dtype=np.int32)
+            got = eng.bm25_topk(ptr, terms, 30)
+            dense = eng.bm25_scores(ptr, terms) if n_docs == 5_000 else None
+            eng.set_option("bm25_linear_grid", 1)
+            try:
+                ref = eng.bm25_topk(ptr, terms, 30)
+                dense_ref = eng.bm25_scores(ptr, terms) if n_docs == 5_000 else None
+            finally:
+                eng.set_option("bm25_linear_grid", 0)
+            for a, b in zip(got, ref):
+                np.testing.assert_array_equal(a, b)
+            if dense is not None:
+                np.testing.assert_array_equal(dense, dense_ref)
+            for qi in (0, 64, 65, 128, Q - 1):
+                raw = O.bm25_scores_csr(post.indptr, post.doc, post.tf, post.doc_len, post.idf, post.avgdl, [int(x) for x in terms_of[qi]])
+                top = O.stable_topk_desc(raw, 30)
+                np.testing.assert_array_equal(got[1][qi], top.astype(np.int32))
+                np.testing.assert_array_equal(got[2][qi], raw[top] / (raw.max() if raw.max() > 0 else 1.0))
+                if dense is not None:
+                    np.testing.assert_array_equal(dense[qi], raw)
+
