@@ -65,7 +65,7 @@ static const struct { const char* name; int rag_options::*field; } g_options[] =
     {"dense_linear_order", &rag_options::dense_linear_order},
     {"bm25_first_ranges", &rag_options::bm25_first_ranges}, {"bm25_no_staging", &rag_options::bm25_no_staging},
     {"bm25_packed", &rag_options::bm25_packed},
-    {"bm25_linear_grid", &rag_options::bm25_linear_grid},
+    {"bm25_linear_grid", &rag_options::bm25_linear_grid},            {"bm25_sort_merge", &rag_options::bm25_sort_merge},
     {"no_fork", &rag_options::no_fork},                 {"fork_max_q", &rag_options::fork_max_q},                 {"ce_no_fused_ln", &rag_options::ce_no_fused_ln},
     {"ce_no_fused_ffn", &rag_options::ce_no_fused_ffn}, {"ce_chunk_tokens", &rag_options::ce_chunk_tokens},
 };

@@ -39,6 +39,7 @@ struct rag_options {
     int bm25_first_ranges = 0;    // exact first-stage BM25 ranges (0 = BM_FIRST_RANGES)
     int bm25_no_staging = 0;      // exact per-range select for every BM25 range
     int bm25_linear_grid = 0;     // scoring workgroups range-major (the ranges of one query side by side) instead of the XCD-aware column order
+    int bm25_sort_merge = 0;      // fold the partial lists of a stage by the bitonic-sort kernel (r1-r2) instead of the per-wave selection
     int bm25_packed = 0;          // (read when postings are LOADED) 4-byte packed postings + shared impact table instead of (doc, impact)
     int no_fork = 0;              // keep the BM25 leg of a small hybrid batch in line on the caller's stream
     int fork_max_q = 0;           // largest batch whose BM25 leg runs on the side stream beside the dense leg (0 = RAG_FORK_MAX_Q)

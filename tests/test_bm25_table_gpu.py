@@ -211,3 +211,39 @@ def test_column_workgroup_order_equals_range_major(eng):
                 if dense is not None:
                     np.testing.assert_array_equal(dense[qi], raw)
 
+
+def test_selection_merge_equals_the_sorting_merge(eng):
+    """The partial lists of a stage are folded into the running top-k by a per-wave bitwise SELECTION (csrc/bm25.hip
+    bm25_merge_select_kernel; k <= 256) instead of a bitonic sort: same list bit for bit, including tie plateaus cut by the lowest
+    rows. Single-term queries over tf = 1 and one document length make every score of a list EQUAL (a plateau across all ranges:
+    the row-order cut decides everything); mixed queries give ordinary lists; k = 100 / 256 / 7; 45 ranges (three stages)."""
+    from optimized_rag_amd.bm25 import Bm25Postings
+    rng = np.random.default_rng(808)
+    n_docs = 91_000
+    lists = [rng.choice(n_docs, n, replace=False) for n in (91_000, 60_000, 30_000, 5_000, 800, 90, 9)]
+    docs = [np.sort(np.asarray(d, dtype=np.int64)).astype(np.int32) for d in lists]
+    indptr = np.concatenate([[0], np.cumsum([d.shape[0] for d in docs])]).astype(np.int64)
+    doc = np.concatenate(docs)
+    tf = np.ones(doc.shape[0], np.int32)
+    tf[indptr[2]:indptr[3]] = rng.integers(1, 3, docs[2].shape[0])                 # term 2: two score levels, two plateaus
+    doc_len = np.full(n_docs, 40, np.int32)
+    post = Bm25Postings(indptr, doc, tf, doc_len, Bm25Postings.idf_table(np.diff(indptr), n_docs), 40.0).load(eng)
+    terms_of = [[0], [1], [2], [3], [4], [5], [6], [0, 1], [2, 3], [1, 2, 3, 4], [6, 5], [4, 4]] + \
+               [list(rng.integers(0, 7, int(rng.integers(1, 5)))) for _ in range(130)]
+    ptr = np.cumsum([0] + [len(t) for t in terms_of]).astype(np.int32)
+    terms = np.asarray([x for t in terms_of for x in t], dtype=np.int32)
+    for k in (100, 256, 7):
+        got = eng.bm25_topk(ptr, terms, k)
+        eng.set_option("bm25_sort_merge", 1)
+        try:
+            ref = eng.bm25_topk(ptr, terms, k)
+        finally:
+            eng.set_option("bm25_sort_merge", 0)
+        for a, b in zip(got, ref):
+            np.testing.assert_array_equal(a, b)
+        for qi in (0, 2, 5, 6, 9, 11, 141):
+            raw = O.bm25_scores_csr(post.indptr, post.doc, post.tf, post.doc_len, post.idf, post.avgdl, [int(x) for x in terms_of[qi]])
+            top = O.stable_topk_desc(raw, k)
+            live = raw[top] > 0 if raw.max() > 0 else np.ones(k, bool)
+            np.testing.assert_array_equal(got[1][qi][live], top.astype(np.int32)[live], err_msg=f"k {k} query {qi}")
+            np.testing.assert_array_equal(got[2][qi], raw[top] / (raw.max() if raw.max() > 0 else 1.0))
