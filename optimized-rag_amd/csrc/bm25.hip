@@ -310,27 +310,37 @@ __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_num_sgpr(96))) vo
     const int lane = tid & 63, wv = tid >> 6;
     const int64_t base = (int64_t)r * BM_RANGE;
     const int lim = (int)min((int64_t)BM_RANGE, n_docs - base);
-    for (int i = tid; i < BM_SC_DOUBLES; i += BM_THREADS) sc[i] = 0.0;
-    __syncthreads();
     // per-token metadata (idf, posting sub-range of this doc range) is fetched for up to 64 tokens IN PARALLEL into
-    // LDS first: fetched inside the token loop it was ~4 dependent global round trips per token per block.
+    // LDS first: fetched inside the token loop it was ~4 dependent global round trips per token per block. The first batch's
+    // loads (the planned tokens: two adjacent plan entries each) are issued BEFORE the accumulators are cleared, so that the
+    // clearing runs under their round trip, and one barrier covers both.
     double* m_idf = reinterpret_cast<double*>(wsum + 16);              // [64]
     int64_t* m_a = reinterpret_cast<int64_t*>(m_idf + 64);             // [64]
     int* m_n = reinterpret_cast<int*>(m_a + 64);                       // [64]
     const int t0 = term_ptr[q], t1 = term_ptr[q + 1];
+    double f_first = 0.0;
+    int64_t a_first = 0;
+    int n_first = 0;
+    if (tid < min(BM_PLAN_T, t1 - t0)) {
+        const bm_plan_meta pm = plan_meta[(size_t)q * BM_PLAN_T + tid];
+        const int32_t* po = plan_off + ((size_t)q * BM_PLAN_T + tid) * (n_ranges + 1) + r;
+        const int o0 = po[0], o1 = po[1];
+        f_first = pm.idf;
+        a_first = pm.post + o0;
+        n_first = o1 - o0;
+    }
+    for (int i = tid; i < BM_SC_DOUBLES; i += BM_THREADS) sc[i] = 0.0;
+    if (t1 <= t0) __syncthreads();                           // no token at all: the select below still needs the cleared array
     for (int tb = t0; tb < t1; tb += 64) {
         const int nb = min(64, t1 - tb);
         if (tid < nb) {
             double f = 0.0;
             int64_t a = 0;
             int n = 0;
-            if (tb == t0) {                                  // planned tokens (BM_PLAN_T = one batch): two adjacent plan entries
-                const bm_plan_meta pm = plan_meta[(size_t)q * BM_PLAN_T + tid];
-                const int32_t* po = plan_off + ((size_t)q * BM_PLAN_T + tid) * (n_ranges + 1) + r;
-                const int o0 = po[0], o1 = po[1];
-                f = pm.idf;
-                a = pm.post + o0;
-                n = o1 - o0;
+            if (tb == t0) {                                  // planned tokens (BM_PLAN_T = one batch)
+                f = f_first;
+                a = a_first;
+                n = n_first;
             } else {                                         // tokens past the plan (a query of more than 64 tokens): search here
                 const int t = terms[tb + tid];
                 if (t >= 0 && t < n_terms) {
@@ -571,7 +581,6 @@ __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_num_sgpr(96))) vo
             if (u < wv) off += hist[u];
             total_in += hist[u];
         }
-        __syncthreads();                                   // hist is reused by the select below
         if (total_in <= k) {
             if (pass) {
 #pragma unroll
@@ -585,6 +594,7 @@ __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_num_sgpr(96))) vo
             if (tid == 0) part_cnt[(size_t)q * n_ranges + r] = total_in;
             return;
         }
+        __syncthreads();                                   // (uniform: total_in is the same in every thread) hist is reused by the select below
     }
     uint64_t keys[BM_SEG];
 #pragma unroll
