@@ -419,7 +419,7 @@ def hybrid_block(eng, q, N, cpu_baseline=True):
         # batch share their frequent terms and the XCD-aware workgroup order lets each XCD's L2 serve a range's postings to all of
         # them. `traffic` = the bytes that actually left L2 per batch (FETCH_SIZE x 2 + WRITE_SIZE of the plan / range / merge launches,
         # rocprofv3 --pmc passes of `bench.py --mode hybrid --only-hybrid-calls`, profiles/r03_bm25_pmc.json).
-        "roofline": {"bound": "hbm", "kernel": "bm25_plan_kernel + bm25_range_kernel + bm25_merge_stage_kernel (BM25 top-100 of one batch)",
+        "roofline": {"bound": "hbm", "kernel": "bm25_plan_kernel + bm25_range_kernel + bm25_merge_select_kernel (BM25 top-100 of one batch)",
                      "achieved": round(bm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(bm_gbs / PEAK_HBM_GBS, 4),
                      "traffic": _profile_number("r03_bm25_pmc.json", ("per_call", "hbm_traffic_bytes")) if (N == 1_000_000 and Q == 1024) else None,
                      "traffic_source": "profiles/r03_bm25_pmc.json (bytes leaving L2 per 1024-query batch; L2 hit rate 0.95)",

@@ -29,7 +29,7 @@ calls = line["steps"] + line["warmup"]
 ks = stats("r3m_hybrid_kernel_stats.csv")
 fetch, write, tcc = pmc("r3m_hybrid_pmc_FETCH_SIZE.json"), pmc("r3m_hybrid_pmc_WRITE_SIZE.json"), pmc("r3m_hybrid_pmc_TCC_HIT_sum_TCC_MISS_sum.json")
 kern = {}
-for short in ("bm25_range_kernel", "bm25_merge_stage_kernel", "bm25_plan_kernel"):
+for short in ("bm25_range_kernel", "bm25_merge_select_kernel", "bm25_plan_kernel"):
     s = pick(ks, short)
     f, w, t = pick(fetch, short)["FETCH_SIZE"], pick(write, short)["WRITE_SIZE"], pick(tcc, short)
     per_call = f["launches"] / calls
