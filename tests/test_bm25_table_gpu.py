@@ -216,7 +216,7 @@ def test_selection_merge_equals_the_sorting_merge(eng):
     """The partial lists of a stage are folded into the running top-k by a per-wave bitwise SELECTION (csrc/bm25.hip
     bm25_merge_select_kernel; k <= 256) instead of a bitonic sort: same list bit for bit, including tie plateaus cut by the lowest
     rows. Single-term queries over tf = 1 and one document length make every score of a list EQUAL (a plateau across all ranges:
-    the row-order cut decides everything); mixed queries give ordinary lists; k = 100 / 256 / 7; 45 ranges (three stages)."""
+    the row-order cut decides everything); mixed queries give ordinary lists; k = 100 / 256 / 7 / 300; 45 ranges (three stages)."""
     from optimized_rag_amd.bm25 import Bm25Postings
     rng = np.random.default_rng(808)
     n_docs = 91_000
@@ -232,7 +232,7 @@ def test_selection_merge_equals_the_sorting_merge(eng):
                [list(rng.integers(0, 7, int(rng.integers(1, 5)))) for _ in range(130)]
     ptr = np.cumsum([0] + [len(t) for t in terms_of]).astype(np.int32)
     terms = np.asarray([x for t in terms_of for x in t], dtype=np.int32)
-    for k in (100, 256, 7):
+    for k in (100, 256, 7, 300):                                               # 300 > 256: the sorting kernel is the only path
         got = eng.bm25_topk(ptr, terms, k)
         eng.set_option("bm25_sort_merge", 1)
         try:
