@@ -142,6 +142,32 @@ def shard_blocks(eng, st, device, rank=0, world=1, steps=3, pool=100, k=20, L_pa
         blocks["retrieve_rerank_q%d" % Q] = {"queries_per_sec": round(Q / t, 2), "ms_per_batch": round(t * 1e3, 2),
                                              "workload": f"hybrid top-{pool} -> MiniLM-L-6 cross-encoder (L={L_pair}, pairs split over the "
                                                          f"ranks) -> top-{k}"}
+        # BASELINE.json's second metric on this configuration: p50 latency of ONE query through retrieve + rerank (every rank
+        # searches its shard, the 100 pairs are split over the ranks), synchronised per call, max over the ranks per call
+        q1, ptr1 = q[:1].contiguous(), st["ptr_d"][:2].contiguous()
+        tok1, len1 = st["q_tok_d"][:1].contiguous(), st["q_len_d"][:1].contiguous()
+
+        def one():
+            if world == 1:
+                return eng.retrieve_rerank_dev(q1, tok1, len1, pool, k, term_ptr=ptr1, terms=st["terms_d"], L_pair=L_pair)
+            return pipe.retrieve_rerank(q1, ptr1, st["terms_d"], tok1, len1, pool, k, L_pair=L_pair)
+
+        import torch.distributed as dist
+        lat = []
+        for i in range(3 + 21):                              # 3 warm-ups
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            one()
+            torch.cuda.synchronize()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            if world > 1:
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)    # outside the timed region
+            if i >= 3:
+                lat.append(float(dt.item()))
+        lat.sort()
+        blocks["retrieve_rerank_single_query_p50_ms"] = round(lat[len(lat) // 2] * 1e3, 3)
     used, total = hbm_used_gb(device)
     blocks["hbm_used_gb"] = used
     blocks["hbm_total_gb"] = total

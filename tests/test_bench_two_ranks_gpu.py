@@ -39,6 +39,7 @@ def test_two_rank_line_and_shard_block():
     for block in ("dense_q256", "dense_q128", "hybrid_q256", "retrieve_rerank_q256"):
         assert sb[block]["queries_per_sec"] > 0, block
     assert sb["dense_q256"]["planted_neighbour_at_rank1"] == 1.0
+    assert 0 < sb["retrieve_rerank_single_query_p50_ms"] < 1000
 
 
 def test_watchdog_keeps_the_headline_line():
