@@ -52,7 +52,8 @@ struct rag_ce_model {
     // activation workspace (sized for ws_tokens)
     int64_t ws_tokens = 0;
     int ws_pairs = 0, ws_L = 0;
-    float* y32 = nullptr;                              // pre-LayerNorm sums: only the unfused fallback path allocates it
+    float* y32 = nullptr;                              // pre-LayerNorm sums of the unfused residual + LayerNorm path, grown on demand
+    int64_t y32_rows = 0;
     int64_t h16_rows = 0;                              // rows of h16 (the FFN intermediate of the two-launch form), grown on demand
     half_t *x16 = nullptr, *q16 = nullptr, *kf16 = nullptr, *vf16 = nullptr, *ctx16 = nullptr, *h16 = nullptr;
     int32_t *ids = nullptr, *tt = nullptr, *lens = nullptr;
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
 #define LNG_W_STAGE (384 * 128)                    // 48 KiB
 #define LNG_X_STAGE (128 * 128)                    // 16 KiB
 #define LNG_LDS (2 * LNG_W_STAGE + 3 * LNG_X_STAGE)    // 144 KiB
+#define LN_UNFUSED_MAX_ROWS (128 * 256)            // P x L up to which the residual + LayerNorm sites run unfused (finer tiles)
 template <int TERMS>
 __global__ __launch_bounds__(512) void ce_gemm_ln_kernel(const half_t* __restrict__ W, const half_t* __restrict__ X, int K,
                                                           const float* __restrict__ bias, const float* __restrict__ gamma,
@@ -1262,6 +1264,7 @@ static void ce_free_ws(rag_ce_model* m) {
     hipFree(m->h16); hipFree(m->ids); hipFree(m->tt); hipFree(m->lens); hipFree(m->logits); hipFree(m->pair_off); hipFree(m->row_pair); hipFree(m->m_packed); hipFree(m->sid); hipFree(m->stt);
     m->y32 = nullptr; m->x16 = m->q16 = m->kf16 = m->vf16 = m->ctx16 = m->h16 = nullptr;
     m->h16_rows = 0;
+    m->y32_rows = 0;
     m->ids = m->tt = m->lens = nullptr; m->logits = nullptr;
     m->pair_off = m->row_pair = m->m_packed = nullptr;
     m->sid = m->stt = nullptr;
@@ -1438,8 +1441,21 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     (void)terms;
  // bias + residual + LayerNorm in the GEMM epilogue when the geometry allows (hidden = 384, K a multiple of 192: the
     // MiniLM-L-6 shape); RAG_CE_NO_FUSED_LN=1 forces the stand-alone path (parity test of both)
-    const bool fused_ln = H == 384 && F % 192 == 0 && !h->opt.ce_no_fused_ln;
-    if (!fused_ln && !m->y32) HIP_TRY(h, hipMalloc(&m->y32, (size_t)Mp * H * 4));
+    // ... except for SMALL batches: the fused kernel's tiles are 128 tokens x all 384 features, so one query's 100 pairs (~140
+    // tiles) leave 45 % of the CUs without a tile, while the plain GEMM (128 features x 256 tokens: three times as many tiles) + a
+    // LayerNorm launch fills them (tools/ln_sweep.py, forward ms fused | unfused: 13 pairs 0.98 | 0.78, 25 1.09 | 0.92, 50 1.33 |
+    // 1.21, 100 1.90 | 1.77, 150 2.40 | 2.64, 400 5.97 | 6.09, 800 11.2 | 11.8). ce_no_fused_ln: 1 = never fused, -1 = always.
+    const bool fused_ln = H == 384 && F % 192 == 0 && h->opt.ce_no_fused_ln <= 0 &&
+                          (h->opt.ce_no_fused_ln < 0 || h->opt.ce_no_fused_ffn < 0 || (int64_t)P * L > LN_UNFUSED_MAX_ROWS);     // (a forced fused FFN contains a fused LayerNorm)
+    const int64_t y_rows = round_up((int64_t)P * L, CE_BN);
+    if (!fused_ln && y_rows > m->y32_rows) {                 // sized by this call (a single query after a 2M-token batch must not take 3 GB)
+        HIP_TRY(h, hipStreamSynchronize(st));
+        hipFree(m->y32);
+        m->y32 = nullptr;
+        m->y32_rows = 0;
+        HIP_TRY(h, hipMalloc(&m->y32, (size_t)y_rows * H * 4));
+        m->y32_rows = y_rows;
+    }
     if (fused_ln && !h->attr_ce_gemm_ln) {
 #define CE_ATTR_LN(T) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_ln_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LNG_LDS));
 #ifdef RAG_CE_ABLATION

@@ -574,12 +574,17 @@ def test_cross_encoder_unfused_layernorm_path_at_hidden_384(monkeypatch):
     ids = rng.integers(5, cfg["vocab_size"], (P, L)).astype(np.int32)
     ids[np.arange(L)[None, :] >= lens[:, None]] = 0
     tt = ((np.arange(L)[None, :] >= 9) & (np.arange(L)[None, :] < lens[:, None])).astype(np.int32)
-    fused = eng.ce_score(ids, tt, lens)
-    eng.set_option("ce_no_fused_ln", 1)
+    eng.set_option("ce_no_fused_ln", -1)                     # -1: fused whatever the batch size (0 = by size, see LN_UNFUSED_MAX_ROWS)
     try:
+        fused = eng.ce_score(ids, tt, lens)
+        fused_small = eng.ce_score(ids[:40], tt[:40], lens[:40])
+        eng.set_option("ce_no_fused_ln", 1)
         plain = eng.ce_score(ids, tt, lens)
     finally:
         eng.set_option("ce_no_fused_ln", 0)
+    auto_small = eng.ce_score(ids[:40], tt[:40], lens[:40])     # 40 x 128 rows: the size rule picks the unfused sites
+    np.testing.assert_array_equal(auto_small, plain[:40])
+    assert np.abs(fused_small - plain[:40]).max() < 1e-3
     assert np.abs(fused - plain).max() < 1e-3
     sel = [0, 1, 150, 299]
     exp = B.forward_logits(w, cfg, ids[sel].astype(np.int64), tt[sel].astype(np.int64), lens[sel], fast_erf=True)
