@@ -557,7 +557,7 @@ __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_num_sgpr(96))) vo
     // about k * BM_RANGE / (docs of stage one) of them, so they are compacted in doc order (the merge sorts anyway) and the
     // 8-pass radix select — 26 us per block, three quarters of this kernel's time when run for every range — is
     // skipped. More than k survivors (possible, e.g. a tie plateau) falls through to the exact select below.
-    // The test runs on the scores themselves: key(s) >= tau_key <=> s >= the double tau_key stands for (the key map is a monotone
+    // The test runs on the scores themselves: key(s) > tau_key <=> s > the double tau_key stands for (the key map is a monotone
     // bijection of the non-NaN doubles; an accumulator is never -0.0: it starts at +0.0 and x + y is -0.0 only for two -0.0),
     // one compare per document instead of a key conversion and two 64-bit compares; only survivors are converted.
     if (tau_key != nullptr) {
@@ -565,7 +565,11 @@ __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_num_sgpr(96))) vo
         const double tau_d = tk == 0ull ? -__builtin_inf() : __builtin_bit_cast(double, tb_);
         unsigned pass = 0;
 #pragma unroll
-        for (int j = 0; j < BM_SEG; ++j) pass |= (sv[j] >= tau_d ? 1u : 0u) << j;
+        // STRICTLY above tau: the running list already holds k documents with score >= tau, all of them from earlier ranges =
+        // lower document numbers, and ties go to the lower document - a document that only EQUALS tau can never displace one of
+        // them. (Scores of short queries tie in droves - same tf, same length -; with >= a plateau at tau passed whole, which is
+        // what pushed the second stage into the exact per-range select and its merge to 1.4-2.8 k entries per query.)
+        for (int j = 0; j < BM_SEG; ++j) pass |= (sv[j] > tau_d ? 1u : 0u) << j;
         pass &= valid;
         const int n_in = __builtin_popcount(pass);
         int sc_in = n_in;
