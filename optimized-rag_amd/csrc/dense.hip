@@ -447,6 +447,7 @@ __global__ __launch_bounds__(512) void dense_emit_persist_kernel(int n_vblocks, 
 // ------------------------------------------------------------------------------------------------
 #define SEL_REG 32                      // keys held in registers per lane (covers 2048 candidates)
 #define SEL_REG_SMALL 8                 // a thresholded stage usually leaves ~k x growth + k keys: 512 cover it
+#define SEL_REG_MID 16                  // ... for k = 20; a pool of 100 (the hybrid legs) leaves ~900: 1024 cover that (22 -> ~12 us per select)
 #define SELECT_LDS_BYTES (4 * (RAG_CAND_CAP - SEL_REG * 64) * 8)
 // One wave, one query. NREG = registers of keys per lane: the pivot search costs 64 bit-steps x NREG ballots whatever n_in is,
 // so the common small case runs with a quarter of the registers (3 of the 4 selects of a 1M-row search: 16 -> 5 us each).
@@ -540,6 +541,7 @@ __global__ __launch_bounds__(256) void select_kernel(uint64_t* __restrict__ cand
     const int dst_q = ex.sc_list != nullptr ? ex.sc_list[q] : 0;
     uint64_t* copy_to = (ex.sc_list != nullptr && !overflow) ? ex.sc_cand + (size_t)dst_q * RAG_CAND_CAP : nullptr;
     if (n_in <= SEL_REG_SMALL * 64) select_wave<SEL_REG_SMALL>(c, spill, n_in, k, two_eps, tau_in, lane, tau_new, n_top, copy_to);
+    else if (n_in <= SEL_REG_MID * 64) select_wave<SEL_REG_MID>(c, spill, n_in, k, two_eps, tau_in, lane, tau_new, n_top, copy_to);
     else select_wave<SEL_REG>(c, spill, n_in, k, two_eps, tau_in, lane, tau_new, n_top, copy_to);
     if (lane == 0) {
         // bound[] starts at -inf; an overflow at ANY stage lost candidates for good -> sticky +inf: the query goes to the
