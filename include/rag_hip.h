@@ -202,6 +202,13 @@ int rag_bm25_load_host(rag_handle_t h, const int64_t* indptr_host /*V+1*/, const
  * uploading it. Any of the outputs may be NULL. */
 int rag_bm25_index_bytes(const int64_t* indptr_host, int64_t n_docs, int64_t n_terms, int64_t* postings_bytes_out,
                          int64_t* meta_bytes_out, int64_t* table_bytes_out);
+/* Launch geometry of ONE scoring launch over `n_ranges_in_launch` 2048-document ranges and `n_queries` queries (host-only, no GPU
+ * call; no reference counterpart: the reference scores a query with one numpy pass, rag/retrieval.py:341). out5 = {workgroups,
+ * ranges, queries, query groups per range G, queries per group L}. L = 0: workgroup b scores (range b % ranges, query b / ranges).
+ * L > 0 (from 128 queries on): XCD-aware columns - workgroup b belongs to XCD x = b % 8 and is its s = b / 8 -th; it scores column
+ * c = x + 8 * (s / L), i.e. range c / G, query (c % G) * L + s % L, and exits if that range or query does not exist. Every (range,
+ * query) pair is scored exactly once; tests/test_bm25_table_plan.py replays the rule. linear != 0 forces L = 0. */
+int rag_bm25_grid_plan(int n_ranges_in_launch, int n_queries, int linear, int64_t* out5);
 /* term_ptr[Q+1], terms[term_ptr[Q]] (query tokens WITH repeats; -1 = out-of-vocabulary).
  * scores_out are max-normalised as the reference does; raw_max_out[Q] (may be NULL) is the divisor.
  * tenant >= 0 (needs rag_index_set_tenants_host and postings row-aligned with the index): only that tenant's documents

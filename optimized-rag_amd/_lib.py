@@ -48,6 +48,7 @@ _SIGS = {
     "rag_set_profiling": ([_P, C.c_int], C.c_int),
     "rag_set_option": ([_P, C.c_char_p, C.c_int], C.c_int),
     "rag_bm25_index_bytes": ([_P, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)], C.c_int),
+    "rag_bm25_grid_plan": ([C.c_int, C.c_int, C.c_int, _P], C.c_int),
     "rag_index_load_host": ([_P, _P, _P, C.c_int64, C.c_int64], C.c_int),
     "rag_index_load_dev": ([_P, _P, _P, C.c_int64, C.c_int64, _P], C.c_int),
     "rag_index_reserve": ([_P, C.c_int64, C.c_int64], C.c_int),
@@ -152,6 +153,15 @@ def bm25_index_bytes(indptr, n_docs):
     if rc != 0:
         raise RagError(f"rag_bm25_index_bytes failed ({rc})")
     return int(a.value), int(b.value), int(c.value)
+
+
+def bm25_grid_plan(n_ranges_in_launch, n_queries, linear=False):
+    """(workgroups, ranges, queries, query groups per range, queries per group) of one BM25 scoring launch; host-only, no GPU."""
+    out = (C.c_int64 * 5)()
+    rc = load_library().rag_bm25_grid_plan(int(n_ranges_in_launch), int(n_queries), int(bool(linear)), C.cast(out, C.c_void_p))
+    if rc != 0:
+        raise RagError(f"rag_bm25_grid_plan failed ({rc})")
+    return tuple(int(v) for v in out)
 
 
 def _np(a, dtype):

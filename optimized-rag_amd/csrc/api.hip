@@ -21,6 +21,7 @@ int bm25_scores_adhoc_host(rag_ctx* h, const int64_t* indptr, const int32_t* doc
                            const int32_t* term_ptr, const int32_t* terms, int Q, double* out);
 int64_t bm25_n_docs(const rag_ctx* h);
 int bm25_index_bytes(const int64_t* indptr, int64_t n_docs, int64_t n_terms, int64_t* postings_out, int64_t* meta_out, int64_t* table_out);
+int bm25_grid_plan(int n_ranges_in_launch, int n_queries, int linear, int64_t* out5);
 int bm25_scores_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, double* out_dev, hipStream_t st);
 int bm25_scores_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, double* out);
 int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int tenant, int64_t* ids_dev,
@@ -455,6 +456,10 @@ int rag_bm25_load_host(rag_handle_t h, const int64_t* indptr, const int32_t* doc
     LOCK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     return bm25_load_host(h, indptr, doc, tf, doc_len, idf, n_docs, n_terms, avgdl, k1, b);
+}
+
+int rag_bm25_grid_plan(int n_ranges_in_launch, int n_queries, int linear, int64_t* out5) {
+    return bm25_grid_plan(n_ranges_in_launch, n_queries, linear, out5);
 }
 
 int rag_bm25_index_bytes(const int64_t* indptr_host, int64_t n_docs, int64_t n_terms, int64_t* postings_bytes_out,

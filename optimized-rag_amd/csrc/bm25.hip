@@ -1410,6 +1410,15 @@ int64_t bm25_n_docs(const rag_ctx* h) { return h->bm25 ? h->bm25->n_docs : -1; }
 
 // HBM bytes of an index built from these postings, from the host CSR offsets alone (no device call): postings (doc + impact,
 // 12 B each), per-term metadata (32 B each) and the bracket tables (4 B per entry, <= nnz bytes by construction).
+// launch geometry of one scoring launch (bm_make_grid), for tests and capacity planning: out = {workgroups, ranges, queries, query groups
+// per range, queries per group (0: range-major order)}
+int bm25_grid_plan(int n_ranges_in_launch, int n_queries, int linear, int64_t* out5) {
+    if (!out5 || n_ranges_in_launch <= 0 || n_queries <= 0) return RAG_ERR_ARG;
+    const bm_grid g = bm_make_grid(n_ranges_in_launch, n_queries, linear);
+    out5[0] = g.blocks; out5[1] = g.nr_l; out5[2] = g.n_queries; out5[3] = g.n_groups; out5[4] = g.qgroup_len;
+    return RAG_OK;
+}
+
 int bm25_index_bytes(const int64_t* indptr, int64_t n_docs, int64_t n_terms, int64_t* postings_out, int64_t* meta_out, int64_t* table_out) {
     if (!indptr || n_docs <= 0 || n_terms < 0) return RAG_ERR_ARG;
     const int64_t n_pad = (n_docs + BM_RANGE - 1) / BM_RANGE * BM_RANGE;

@@ -55,3 +55,48 @@ def test_table_is_bounded_by_the_postings_for_any_vocabulary():
 def test_empty_and_degenerate_inputs():
     assert bm25_index_bytes(_indptr([]), 10) == (96, 0, 0)
     assert bm25_index_bytes(_indptr([0, 0, 5]), 10) == ((5 + 8) * 12, 96, 0)
+
+
+def _decode(plan, b):
+    """The scoring kernel's workgroup -> (range, query) rule (csrc/bm25.hip bm25_range_kernel), restated."""
+    blocks, nr, nq, G, L = plan
+    if L == 0:
+        return b % nr, b // nr
+    x, s = b % 8, b // 8
+    col, qi = x + 8 * (s // L), s % L
+    rl, q = col // G, (col % G) * L + qi
+    return (rl, q) if rl < nr and q < nq else None
+
+
+def test_every_range_query_pair_is_scored_exactly_once():
+    """rag_bm25_grid_plan (host side of the XCD-aware workgroup order): for every launch shape the workgroups cover each (range,
+    query) pair once and only once, the padding workgroups decode to nothing, and a column's queries share one range."""
+    from optimized_rag_amd._lib import bm25_grid_plan
+    rng = np.random.default_rng(12)
+    shapes = [(4, 1024), (28, 1024), (224, 1024), (233, 1024), (4, 128), (1, 129), (3, 200), (489, 256), (7, 1000), (28, 257), (1, 1), (5, 127),
+              (6105, 256), (9, 2048)] + [(int(rng.integers(1, 400)), int(rng.integers(1, 1500))) for _ in range(12)]
+    for nr, nq in shapes:
+        plan = bm25_grid_plan(nr, nq)
+        blocks, nr_o, nq_o, G, L = plan
+        assert (nr_o, nq_o) == (nr, nq) and blocks >= nr * nq
+        assert (L == 0) == (nq < 128) and blocks < 4.1 * nr * nq + 64
+        if nr * nq > 300_000:                               # large shapes: sampled workgroups + the counting argument
+            ids = rng.integers(0, blocks, 20_000)
+            seen = {_decode(plan, int(b)) for b in ids} - {None}
+            assert all(0 <= r < nr and 0 <= q < nq for r, q in seen)
+            assert G * L >= nq and blocks == 8 * -(-nr * G // 8) * L if L else blocks == nr * nq
+            continue
+        seen = {}
+        for b in range(blocks):
+            d = _decode(plan, b)
+            if d is not None:
+                assert d not in seen, (nr, nq, b, d)
+                seen[d] = b
+        assert len(seen) == nr * nq, (nr, nq, len(seen))
+        if L:                                               # the queries of a column sit on ONE XCD (workgroup id % 8) and one range
+            by_col = {}
+            for (r, q), b in seen.items():
+                by_col.setdefault((r, q // L), set()).add(b % 8)
+            assert all(len(v) == 1 for v in by_col.values())
+        lin = bm25_grid_plan(nr, nq, linear=True)
+        assert lin[4] == 0 and lin[0] == nr * nq
