@@ -49,7 +49,7 @@ int rag_synchronize(rag_handle_t h);
 /* Diagnostic / tuning switch of one handle (no reference counterpart). Every switch <name> takes its default from the
  * environment variable RAG_<NAME> ONCE, when rag_create runs; afterwards only this call changes it. Names: force_level,
  * stage_growth, no_smallq, no_second_pass, dense_linear_order, bm25_first_ranges, bm25_no_staging, bm25_packed, bm25_linear_grid, bm25_sort_merge, no_fork,
- * fork_max_q, ce_no_fused_ln, ce_no_fused_ffn, ce_chunk_tokens. Unknown name: RAG_ERR_ARG. */
+ * fork_max_q, ce_no_fused_ln, ce_no_fused_ffn, ce_chunk_tokens, ce_mx. Unknown name: RAG_ERR_ARG. */
 int rag_set_option(rag_handle_t h, const char* name, int value);
 
 /* ---- dense index: replaces the pgvector tables behind

@@ -68,7 +68,7 @@ static const struct { const char* name; int rag_options::*field; } g_options[] =
     {"bm25_packed", &rag_options::bm25_packed},
     {"bm25_linear_grid", &rag_options::bm25_linear_grid},            {"bm25_sort_merge", &rag_options::bm25_sort_merge},
     {"no_fork", &rag_options::no_fork},                 {"fork_max_q", &rag_options::fork_max_q},                 {"ce_no_fused_ln", &rag_options::ce_no_fused_ln},
-    {"ce_no_fused_ffn", &rag_options::ce_no_fused_ffn}, {"ce_chunk_tokens", &rag_options::ce_chunk_tokens},
+    {"ce_no_fused_ffn", &rag_options::ce_no_fused_ffn}, {"ce_chunk_tokens", &rag_options::ce_chunk_tokens}, {"ce_mx", &rag_options::ce_mx},
 };
 static void options_from_env(rag_options* o) {
     for (const auto& e : g_options) {

@@ -249,3 +249,300 @@ __device__ __forceinline__ void mx_gemm_loop(const char* __restrict__ W, const c
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // clamped tail re-loads: retire them before exit
 }
+
+// =====================================================================================================================
+// Epilogues and kernels of the MX forward (hidden = 384: one feature tile IS the hidden state, so LayerNorm stays on the CU)
+// =====================================================================================================================
+typedef unsigned mx_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned mx_u4 __attribute__((ext_vector_type(4)));
+
+// byte address of the K-step image holding (token row m, feature k) of an activation tensor with `nk` K-steps
+__device__ __forceinline__ size_t mx_img_base(int64_t m, int k, int nk) { return ((size_t)(m >> 7) * nk + (k >> 5)) * MX_B_STAGE; }
+
+// four consecutive features of one token -> 4 halfs (hi) + 4 bytes (lo8)
+__device__ __forceinline__ void mx_split4(float v0, float v1, float v2, float v3, mx_u2& hi, unsigned& lo) {
+    const half4 h = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+    hi = __builtin_bit_cast(mx_u2, h);
+    int r = __builtin_amdgcn_cvt_pk_bf8_f32((v0 - (float)h[0]) * MX_LO_SCALE, (v1 - (float)h[1]) * MX_LO_SCALE, 0, false);
+    lo = (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32((v2 - (float)h[2]) * MX_LO_SCALE, (v3 - (float)h[3]) * MX_LO_SCALE, r, true);
+}
+__device__ __forceinline__ float mx_join(half_t hi, unsigned lo8) { return (float)hi + mx_lo_decode(lo8); }
+
+// v_permlane32_swap: lane l < 32 and lane l + 32 exchange so that BOTH end up with {a of the lower lane | ... }:
+// returns (x, y) with  lower lane: x = its own a, y = the upper lane's a;  upper lane: x = the lower lane's b, y = its own b
+__device__ __forceinline__ void mx_pair_swap(unsigned a, unsigned b, unsigned& x, unsigned& y) {
+    const mx_u2 s = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    x = s[0];
+    y = s[1];
+}
+
+// Stores one 32-feature block of a NON-swapped accumulator tile (+ the values in v[16], already biased / activated) into the image
+// layout of the next GEMM's token operand: row `trow` of the tile image `img` (K-step = this block's 32 features).
+// v[4q + e] = feature 8q + 4hh + e of the block. The two lane halves exchange so that every lane stores whole 16-B chunks:
+// lane half 0 the chunks of q = 0, 2 and lo plane 4, lane half 1 those of q = 1, 3 and lo plane 5.
+__device__ __forceinline__ void mx_store_block(char* img, int trow, int hh, const float (&v)[16]) {
+    mx_u2 hi[4];
+    unsigned lo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mx_split4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3], hi[q], lo[q]);
+    // fragment (j = q >> 1, h = q & 1) is plane 2j + h; the lane's 8 B sit at byte 8 * hh of the row's 16
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        unsigned c0, c1, c2, c3;
+        mx_pair_swap(hi[2 * j][0], hi[2 * j + 1][0], c0, c2);
+        mx_pair_swap(hi[2 * j][1], hi[2 * j + 1][1], c1, c3);
+        *reinterpret_cast<mx_u4*>(img + (2 * j + hh) * MX_B_PLANE + trow * 16) = (mx_u4){c0, c1, c2, c3};
+    }
+    // lo plane 4 + h: the lane's bytes hh*8 .. +8 = (j = 0: q = h) then (j = 1: q = 2 + h)
+    unsigned c0, c1, c2, c3;
+    mx_pair_swap(lo[0], lo[1], c0, c2);
+    mx_pair_swap(lo[2], lo[3], c1, c3);
+    *reinterpret_cast<mx_u4*>(img + (4 + hh) * MX_B_PLANE + trow * 16) = (mx_u4){c0, c1, c2, c3};
+}
+
+// ---- weights: fp32 [N][K] (nn.Linear) -> image layout [N / 384][K / 32][36 KiB]
+__global__ void mx_pack_weight_kernel(const float* __restrict__ w, int N, int K, char* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * K) return;
+    const int n = (int)(i / K), k = (int)(i % K);
+    const float x = w[i];
+    const half_t hi = (half_t)x;
+    const half_t l = (half_t)((x - (float)hi) * MX_LO_SCALE);
+    char* img = out + ((size_t)(n / MX_TM) * (K >> 5) + (k >> 5)) * MX_A_STAGE;
+    *reinterpret_cast<half_t*>(img + mx_hi_off(MX_TM, n % MX_TM, k & 31)) = hi;
+    *reinterpret_cast<unsigned char*>(img + mx_lo_off(MX_TM, n % MX_TM, k & 31)) =
+        (unsigned char)mx_e5m2_rn((unsigned)__builtin_bit_cast(unsigned short, l));
+}
+
+// ---- embeddings + LayerNorm -> x8 (hidden = 384 = 48 chunks of 8 features: lanes 0..47 of the token's wave own one chunk each)
+__global__ __launch_bounds__(256) void mx_embed_ln_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ tt,
+                                                           const float* __restrict__ word, const float* __restrict__ pos,
+                                                           const float* __restrict__ type, const float* __restrict__ g,
+                                                           const float* __restrict__ b, const int32_t* __restrict__ m_packed,
+                                                           const int32_t* __restrict__ row_pair, const int32_t* __restrict__ pair_off,
+                                                           int L, int vocab, float eps, char* __restrict__ x8) {
+    constexpr int H = 384;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m_packed[0]) return;
+    const int pr = row_pair[row];
+    const int p = (int)row - pair_off[pr];
+    const size_t src = (size_t)pr * L + p;
+    int id = ids[src];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const int ty = tt[src] != 0;
+    const bool on = lane < H / 8;
+    const int c = on ? lane : 0;
+    float v[8];
+    {
+        const float4* wp = reinterpret_cast<const float4*>(word + (size_t)id * H + c * 8);
+        const float4* tp = reinterpret_cast<const float4*>(type + (size_t)ty * H + c * 8);
+        const float4* pp = reinterpret_cast<const float4*>(pos + (size_t)p * H + c * 8);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float4 a = wp[u], t4 = tp[u], q = pp[u];
+            v[u * 4] = a.x + t4.x + q.x; v[u * 4 + 1] = a.y + t4.y + q.y; v[u * 4 + 2] = a.z + t4.z + q.z; v[u * 4 + 3] = a.w + t4.w + q.w;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += on ? v[i] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / H);
+    float qd = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float d = v[i] - mean; qd += on ? d * d : 0.f; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qd += __shfl_xor(qd, o);
+    const float rstd = 1.0f / sqrtf(qd * (1.0f / H) + eps);
+    if (!on) return;
+    const float4 g0 = *reinterpret_cast<const float4*>(g + c * 8), g1 = *reinterpret_cast<const float4*>(g + c * 8 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(b + c * 8), b1 = *reinterpret_cast<const float4*>(b + c * 8 + 4);
+    mx_u2 h0, h1;
+    unsigned l0, l1;
+    mx_split4((v[0] - mean) * rstd * g0.x + b0.x, (v[1] - mean) * rstd * g0.y + b0.y, (v[2] - mean) * rstd * g0.z + b0.z,
+              (v[3] - mean) * rstd * g0.w + b0.w, h0, l0);
+    mx_split4((v[4] - mean) * rstd * g1.x + b1.x, (v[5] - mean) * rstd * g1.y + b1.y, (v[6] - mean) * rstd * g1.z + b1.z,
+              (v[7] - mean) * rstd * g1.w + b1.w, h1, l1);
+    // chunk c = features 8c..8c+7: K-step c >> 2, fragment j = (c >> 1) & 1, lane half h = c & 1
+    const int j = (c >> 1) & 1, h = c & 1, trow = (int)(row & 127);
+    char* img = x8 + mx_img_base(row, c * 8, H / 32);
+    *reinterpret_cast<mx_u4*>(img + (2 * j + h) * MX_B_PLANE + trow * 16) = (mx_u4){h0[0], h0[1], h1[0], h1[1]};
+    *reinterpret_cast<unsigned*>(img + (4 + h) * MX_B_PLANE + trow * 16 + j * 4) = l0;
+    *reinterpret_cast<unsigned*>(img + (4 + h) * MX_B_PLANE + trow * 16 + 8 + j * 4) = l1;
+}
+
+// value of (token row m, feature k) of an image-layout activation tensor
+__device__ __forceinline__ float mx_load_elem(const char* __restrict__ x8, int64_t m, int k, int nk) {
+    const char* img = x8 + mx_img_base(m, k, nk);
+    const int trow = (int)(m & 127);
+    return mx_join(*reinterpret_cast<const half_t*>(img + mx_hi_off(MX_TN, trow, k & 31)),
+                   *reinterpret_cast<const unsigned char*>(img + mx_lo_off(MX_TN, trow, k & 31)));
+}
+
+// ---- QKV projection: feature tile 0 = Q, 1 = K (MFMA fragment order of the attention kernel, split fp16), 2 = V (computed with
+// swapped operands so that a lane holds 4 consecutive KEYS of one dim: the V fragment order)
+struct mx_epi_qkv {
+    half_t *qf16, *kf16, *vf16;
+    size_t kv_plane;
+    const float* bias;
+    int m_tiles16;                 // 16-row tiles of the padded row space
+    __device__ __forceinline__ bool swap_for(int ft) const { return ft == 2; }
+    __device__ __forceinline__ void operator()(f32x16 (&acc)[6], int tt, int ft, bool swap, char*) const {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wm = wid >> 2, wn = wid & 3;
+        const int li = lane & 31, hh = lane >> 5;
+        const int m0 = tt * MX_TN + wn * 32;                       // first token row of the wave
+        if (!swap) {
+            half_t* dst = ft == 0 ? qf16 : kf16;
+            const int m = m0 + li;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const int head = wm * 6 + b;
+                half_t* tile = dst + (((size_t)head * m_tiles16 + (m >> 4)) * 64 + (m & 15)) * 8 + 4 * hh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bias + ft * MX_TM + head * 32 + 8 * q + 4 * hh);
+                    const float v0 = acc[b][q * 4] + bv.x, v1 = acc[b][q * 4 + 1] + bv.y, v2 = acc[b][q * 4 + 2] + bv.z, v3 = acc[b][q * 4 + 3] + bv.w;
+                    const half4 hi = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+                    const half4 lo = {(half_t)(v0 - (float)hi[0]), (half_t)(v1 - (float)hi[1]), (half_t)(v2 - (float)hi[2]), (half_t)(v3 - (float)hi[3])};
+                    __builtin_nontemporal_store(hi, reinterpret_cast<half4*>(tile + q * 128));
+                    __builtin_nontemporal_store(lo, reinterpret_cast<half4*>(tile + q * 128 + kv_plane));
+                }
+            }
+        } else {
+            // lane = dim li of head wm*6 + b; register 4q + e = token m0 + 8q + 4hh + e: 16-row tile (q >> 1), key slots
+            // fq = 2 (q & 1) + hh, e -> vf16[head][tile][d half][fq*16 + d%16][4]
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const int head = wm * 6 + b;
+                const float bv = bias[2 * MX_TM + head * 32 + li];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v0 = acc[b][q * 4] + bv, v1 = acc[b][q * 4 + 1] + bv, v2 = acc[b][q * 4 + 2] + bv, v3 = acc[b][q * 4 + 3] + bv;
+                    const half4 hi = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+                    const half4 lo = {(half_t)(v0 - (float)hi[0]), (half_t)(v1 - (float)hi[1]), (half_t)(v2 - (float)hi[2]), (half_t)(v3 - (float)hi[3])};
+                    half_t* o = vf16 + ((((size_t)head * m_tiles16 + (m0 >> 4) + (q >> 1)) * 2 + (li >> 4)) * 64 + (2 * (q & 1) + hh) * 16 + (li & 15)) * 4;
+                    __builtin_nontemporal_store(hi, reinterpret_cast<half4*>(o));
+                    __builtin_nontemporal_store(lo, reinterpret_cast<half4*>(o + kv_plane));
+                }
+            }
+        }
+    }
+};
+
+// ---- FFN up-projection: bias + erf-GELU -> h8 (image layout, K = ffn for the down-projection)
+__device__ __forceinline__ float mx_gelu(float x) {     // as ce_gelu (cross_encoder.hip): A&S 7.1.26, |erf error| <= 1.5e-7
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float erf_abs = fmaf(-p * t, e, 1.0f);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+struct mx_epi_gelu {
+    char* h8;
+    const float* bias;
+    int nk_out;                    // K-steps of the consumer = ffn / 32
+    __device__ __forceinline__ bool swap_for(int) const { return false; }
+    __device__ __forceinline__ void operator()(f32x16 (&acc)[6], int tt, int ft, bool, char*) const {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wm = wid >> 2, wn = wid & 3;
+        const int trow = wn * 32 + (lane & 31), hh = lane >> 5;
+        char* tile = h8 + (size_t)tt * nk_out * MX_B_STAGE;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const int f0 = ft * MX_TM + wm * 192 + b * 32;
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *reinterpret_cast<const float4*>(bias + f0 + 8 * q + 4 * hh);
+                v[q * 4] = mx_gelu(acc[b][q * 4] + bv.x);
+                v[q * 4 + 1] = mx_gelu(acc[b][q * 4 + 1] + bv.y);
+                v[q * 4 + 2] = mx_gelu(acc[b][q * 4 + 2] + bv.z);
+                v[q * 4 + 3] = mx_gelu(acc[b][q * 4 + 3] + bv.w);
+            }
+            mx_store_block(tile + (size_t)(f0 >> 5) * MX_B_STAGE, trow, hh, v);
+        }
+    }
+};
+
+// ---- out-projection / FFN down-projection: bias + residual + LayerNorm -> x8 in place (n_ft = 1: the tile is the hidden state)
+struct mx_epi_ln {
+    char* x8;                      // residual stream: read (residual) and rewritten (the new stream)
+    const float *bias, *gamma, *beta;
+    float eps;
+    __device__ __forceinline__ bool swap_for(int) const { return false; }
+    __device__ __forceinline__ void operator()(f32x16 (&acc)[6], int tt, int, bool, char* scratch) const {
+        constexpr int H = 384;
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wm = wid >> 2, wn = wid & 3;
+        const int li = lane & 31, hh = lane >> 5, trow = wn * 32 + li;
+        char* tile = x8 + (size_t)tt * (H / 32) * MX_B_STAGE;
+        float* st_sum = reinterpret_cast<float*>(scratch) + wid * 32;          // [8 waves][32 tokens]
+        float* st_sq = reinterpret_cast<float*>(scratch) + 256 + wid * 32;
+        const float* pr_sum = reinterpret_cast<const float*>(scratch) + (wid ^ 4) * 32;
+        const float* pr_sq = reinterpret_cast<const float*>(scratch) + 256 + (wid ^ 4) * 32;
+        // v = acc + bias + residual, in place in the accumulators
+        float sm = 0.f;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const int f0 = wm * 192 + b * 32;
+            const char* img = tile + (size_t)(f0 >> 5) * MX_B_STAGE;
+            // the lane's residual bytes: hi 8 B of fragment (j, h) at byte 8hh; lo 4 B of plane 4 + h at byte 8hh + 4j
+            const mx_u2 l0 = *reinterpret_cast<const mx_u2*>(img + 4 * MX_B_PLANE + trow * 16 + hh * 8);      // h = 0: q = 0 | q = 2
+            const mx_u2 l1 = *reinterpret_cast<const mx_u2*>(img + 5 * MX_B_PLANE + trow * 16 + hh * 8);      // h = 1: q = 1 | q = 3
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *reinterpret_cast<const float4*>(bias + f0 + 8 * q + 4 * hh);
+                const half4 rh = *reinterpret_cast<const half4*>(img + ((q >> 1) * 2 + (q & 1)) * MX_B_PLANE + trow * 16 + hh * 8);
+                const unsigned rl = (q & 1) ? l1[q >> 1] : l0[q >> 1];
+                acc[b][q * 4] += bv.x + mx_join(rh[0], rl & 0xFF);
+                acc[b][q * 4 + 1] += bv.y + mx_join(rh[1], (rl >> 8) & 0xFF);
+                acc[b][q * 4 + 2] += bv.z + mx_join(rh[2], (rl >> 16) & 0xFF);
+                acc[b][q * 4 + 3] += bv.w + mx_join(rh[3], rl >> 24);
+                sm += (acc[b][q * 4] + acc[b][q * 4 + 1]) + (acc[b][q * 4 + 2] + acc[b][q * 4 + 3]);
+            }
+        }
+        // row statistics: a token's 384 features = 2 lane halves x 2 feature-half waves x 96 registers; two passes (mean, centred squares)
+        sm += __shfl_xor(sm, 32);
+        if (hh == 0) st_sum[li] = sm;
+        MX_BAR
+        const float mu = (sm + pr_sum[li]) * (1.0f / H);
+        float sq = 0.f;
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = acc[b][r] - mu; sq += d * d; }
+        sq += __shfl_xor(sq, 32);
+        if (hh == 0) st_sq[li] = sq;
+        MX_BAR
+        const float rs = 1.0f / sqrtf((sq + pr_sq[li]) * (1.0f / H) + eps);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const int f0 = wm * 192 + b * 32;
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 gv = *reinterpret_cast<const float4*>(gamma + f0 + 8 * q + 4 * hh);
+                const float4 be = *reinterpret_cast<const float4*>(beta + f0 + 8 * q + 4 * hh);
+                v[q * 4] = (acc[b][q * 4] - mu) * rs * gv.x + be.x;
+                v[q * 4 + 1] = (acc[b][q * 4 + 1] - mu) * rs * gv.y + be.y;
+                v[q * 4 + 2] = (acc[b][q * 4 + 2] - mu) * rs * gv.z + be.z;
+                v[q * 4 + 3] = (acc[b][q * 4 + 3] - mu) * rs * gv.w + be.w;
+            }
+            mx_store_block(tile + (size_t)(f0 >> 5) * MX_B_STAGE, trow, hh, v);
+        }
+        MX_BAR                                                    // the statistics scratch is reused by the next tile
+    }
+};
+
+template <class EPI>
+__global__ __launch_bounds__(512) void mx_gemm_kernel(const char* __restrict__ W, const char* __restrict__ X, int nk, int n_ft,
+                                                       const int32_t* __restrict__ m_packed, EPI epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n_tt = (m_packed[0] + MX_TN - 1) / MX_TN;
+    mx_gemm_loop(W, X, nk, n_ft, n_tt, smem, epi);
+}
+#define MX_KERNEL_LDS (MX_LDS + 4096)

@@ -46,6 +46,7 @@ struct rag_options {
     int ce_no_fused_ln = 0;       // unfused residual + LayerNorm path of the cross-encoder
     int ce_no_fused_ffn = 0;      // FFN as two GEMM launches (up-projection, then the fused-LN down-projection)
     int ce_chunk_tokens = 0;      // activation chunk size in tokens (0 = sized from the model)
+    int ce_mx = 0;                // cross-encoder forward on hi16 + lo8 operands (ce_mx.h): 0 = from MX_MIN_ROWS padded rows on, 1 = always, -1 = never
 };
 
 struct rag_ctx {
@@ -134,6 +135,8 @@ struct rag_ctx {
     // hipFuncSetAttribute (dynamic LDS above 64 KiB) is per device: remembered per handle, not per process
     bool attr_dense = false, attr_bm25 = false, attr_ce_gemm = false, attr_ce_gemm_ln = false, attr_ce_ffn = false;
     int attr_ce_attn_lds[3] = {0, 0, 0};
+    int attr_ce_attn_mx_lds[3] = {0, 0, 0};
+    bool attr_ce_mx = false;
     rag_ce_model* ce = nullptr;
     rag_ce_model* emb = nullptr;             // sentence-embedding encoder (rag_embed_load_host): the K7 kernels behind a mean-pooling head
 };

@@ -29,6 +29,7 @@
 //   ce_layernorm       one wave per token (384 = 6/lane), fp32 statistics, eps from config
 //   ce_pool_classify   tanh(Wp.x_cls + bp) -> wc.pooled + bc, fp32
 #include "common.h"
+#include "ce_mx.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -43,6 +44,7 @@ struct rag_ce_model {
     float *word = nullptr, *pos = nullptr, *type = nullptr, *emb_ln_g = nullptr, *emb_ln_b = nullptr;
     struct Layer {
         half_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;      // fp16 [out][in]
+        char *wqkv8 = nullptr, *wo8 = nullptr, *w18 = nullptr, *w28 = nullptr;     // the same matrices as hi16 + lo8 images (ce_mx.h), when the shape allows
         float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
         float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
     };
@@ -62,6 +64,18 @@ struct rag_ce_model {
     int32_t *pair_off = nullptr, *row_pair = nullptr, *m_packed = nullptr;
     int32_t *sid = nullptr, *stt = nullptr;          // staging of one chunk's [pairs][L_in] token / type ids
     float* logits = nullptr;
+    // the MX forward (ce_mx.h: hi16 + lo8 operands) has a workspace of its own: it runs the large batches, the split-fp16 kernels
+    // above the small ones (their tiles are finer), and neither path must size or evict the other's buffers
+    bool mx_ok = false;                                // the shape allows the MX path (hidden 384, ffn a multiple of 384) and its weights are loaded
+    struct MxWs {
+        int pairs = 0, L = 0;
+        int64_t tokens = 0;                            // padded rows (a multiple of 256)
+        char *x8 = nullptr, *ctx8 = nullptr, *h8 = nullptr;              // residual stream, attention output, FFN intermediate (image layout)
+        half_t *qf16 = nullptr, *kf16 = nullptr, *vf16 = nullptr;       // Q, K, V in the attention kernel's fragment order (hi | lo planes)
+        int32_t *ids = nullptr, *tt = nullptr, *lens = nullptr, *pair_off = nullptr, *row_pair = nullptr, *m_packed = nullptr;
+        int32_t *sid = nullptr, *stt = nullptr;
+        float* logits = nullptr;
+    } mx;
 };
 
 #define CE_BM 128     // output features per tile (MFMA rows)
@@ -667,6 +681,7 @@ __global__ __launch_bounds__(512) void ce_gemm_ln_kernel(const half_t* __restric
 #define FFN_LDS (FFN_RING + FFN_HBUF)
 #define FFN_CH 128                                // intermediate features per chunk
 #define FFN_FUSED_MIN_ROWS (5120 * 256)            // P x L from which the fused kernel is used (below: the two-launch form)
+#define MX_MIN_ROWS (512 * 256)                    // P x L from which the MX forward (ce_mx.h) runs instead of the split-fp16 kernels
 template <int TERMS>
 __global__ __launch_bounds__(512) void ce_ffn_ln_kernel(const half_t* __restrict__ W1, const float* __restrict__ b1,
                                                          const half_t* __restrict__ W2, const float* __restrict__ b2, int F,
@@ -1058,7 +1073,9 @@ __device__ __forceinline__ void ce_dma_at(const half_t* __restrict__ g, char* ld
                                      (__attribute__((address_space(3))) void*)lds_uniform, 16, 0, 0);
 }
 
-template <int QB>
+// MX = true (the hi16 + lo8 forward, ce_mx.h): Q arrives in the same fragment order as K (q16 = qf16[head][16-row tile][lane][8], lo
+// plane kv_plane further) and the context leaves in the image layout of the out-projection's token operand (ctx16 = ctx8 bytes).
+template <int QB, bool MX = false>
 __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __restrict__ q16,
                                                              const half_t* __restrict__ kf16, const half_t* __restrict__ vf16,
                                                              size_t kv_plane, const int32_t* __restrict__ lens,
@@ -1096,9 +1113,15 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
     for (int b = 0; b < QB; ++b) {
         // split-row layout: a head's 32 dims are one K group = [hi 32 | lo 32] halfs
         const int qb = (qb0 + b) * 16 < Lp ? qb0 + b : qb0;           // a block past the pair's rows is computed but not stored
-        const half_t* qp = q16 + (row0 + qb * 16 + fr) * (2 * hidden) + head * 64 + fq * 8;
-        qh[b] = *reinterpret_cast<const half8*>(qp);
-        ql[b] = *reinterpret_cast<const half8*>(qp + 32);
+        if (MX) {
+            const half_t* qp = q16 + (((size_t)head * (m_pad >> 4) + (po >> 4) + qb) * 64 + lane) * 8;
+            qh[b] = *reinterpret_cast<const half8*>(qp);
+            ql[b] = *reinterpret_cast<const half8*>(qp + kv_plane);
+        } else {
+            const half_t* qp = q16 + (row0 + qb * 16 + fr) * (2 * hidden) + head * 64 + fq * 8;
+            qh[b] = *reinterpret_cast<const half8*>(qp);
+            ql[b] = *reinterpret_cast<const half8*>(qp + 32);
+        }
     }
     f32x4 c0[QB], c1[QB];
     float mrun[QB], lsum[QB];
@@ -1187,12 +1210,26 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
         l += __shfl_xor(l, 32);
         const float inv = 1.0f / l;
         if ((qb0 + b) * 16 >= Lp) break;
+        if (MX) {
+            // K-step = head; c0 = dims 4fq..4fq+3 (fragment j = 0), c1 = 16 + the same (j = 1); lane half h = fq >> 1, i = 4 (fq & 1) + r
+            const int64_t mrow = (int64_t)row0 + (qb0 + b) * 16 + fr;
+            char* img = reinterpret_cast<char*>(ctx16) + mx_img_base(mrow, head * 32, hidden >> 5) + (int)(mrow & 127) * 16 + (fq & 1) * 8;
+            mx_u2 h0, h1;
+            unsigned l0, l1;
+            mx_split4(c0[b][0] * inv, c0[b][1] * inv, c0[b][2] * inv, c0[b][3] * inv, h0, l0);
+            mx_split4(c1[b][0] * inv, c1[b][1] * inv, c1[b][2] * inv, c1[b][3] * inv, h1, l1);
+            *reinterpret_cast<mx_u2*>(img + (fq >> 1) * MX_B_PLANE) = h0;
+            *reinterpret_cast<mx_u2*>(img + (2 + (fq >> 1)) * MX_B_PLANE) = h1;
+            *reinterpret_cast<mx_u2*>(img + (4 + (fq >> 1)) * MX_B_PLANE) = (mx_u2){l0, l1};
+            continue;
+        }
         half_t* o = ctx16 + (row0 + (qb0 + b) * 16 + fr) * (2 * hidden) + head * 64 + fq * 4;
         store_split4(o, 32, c0[b][0] * inv, c0[b][1] * inv, c0[b][2] * inv, c0[b][3] * inv);
         store_split4(o + 16, 32, c1[b][0] * inv, c1[b][1] * inv, c1[b][2] * inv, c1[b][3] * inv);
     }
 }
 
+template <bool MX>
 __global__ __launch_bounds__(256) void ce_pool_classify_kernel(const half_t* __restrict__ x16, const float* __restrict__ wp,
                                                                 const float* __restrict__ bp, const float* __restrict__ wc,
                                                                 const float* __restrict__ bc, const int32_t* __restrict__ pair_off,
@@ -1201,7 +1238,8 @@ __global__ __launch_bounds__(256) void ce_pool_classify_kernel(const half_t* __r
     __shared__ float part[4];
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const half_t* x = x16 + (size_t)pair_off[pair] * 2 * hidden;     // [CLS] = the pair's first packed row (split layout)
-    for (int i = tid; i < hidden; i += 256) xs[i] = (float)x[SPLIT_IDX(i)] + (float)x[SPLIT_IDX(i) + 32];
+    for (int i = tid; i < hidden; i += 256)
+        xs[i] = MX ? mx_load_elem(reinterpret_cast<const char*>(x16), pair_off[pair], i, hidden >> 5) : (float)x[SPLIT_IDX(i)] + (float)x[SPLIT_IDX(i) + 32];
     __syncthreads();
     float acc = 0.f;
     for (int n = tid; n < hidden; n += 256) {
@@ -1219,6 +1257,7 @@ __global__ __launch_bounds__(256) void ce_pool_classify_kernel(const half_t* __r
 
 // Sentence embedding head (sentence-transformers' Pooling(mean) + Normalize): mean of the last hidden state over the pair's
 // real tokens, optionally L2-normalised. One workgroup per sequence; float32 sums over the split-fp16 stream (hi + lo).
+template <bool MX>
 __global__ __launch_bounds__(256) void ce_meanpool_kernel(const half_t* __restrict__ x16, const int32_t* __restrict__ pair_off,
                                                            const int32_t* __restrict__ lens, int L, int hidden, int normalize,
                                                            float* __restrict__ out) {
@@ -1231,6 +1270,7 @@ __global__ __launch_bounds__(256) void ce_meanpool_kernel(const half_t* __restri
     for (int e = 0, c = tid; c < hidden; c += 256, ++e) {
         float s = 0.f;
         for (int t = 0; t < len; ++t) {
+            if (MX) { s += mx_load_elem(reinterpret_cast<const char*>(x16), (int64_t)pair_off[pair] + t, c, hidden >> 5); continue; }
             const half_t* r = x + (size_t)t * 2 * hidden + SPLIT_IDX(c);
             s += (float)r[0] + (float)r[32];
         }
@@ -1271,10 +1311,19 @@ static void ce_free_ws(rag_ce_model* m) {
     m->ws_tokens = 0; m->ws_pairs = 0; m->ws_L = 0;
 }
 
+static void mx_free_ws(rag_ce_model* m) {
+    auto& w = m->mx;
+    hipFree(w.x8); hipFree(w.ctx8); hipFree(w.h8); hipFree(w.qf16); hipFree(w.kf16); hipFree(w.vf16);
+    hipFree(w.ids); hipFree(w.tt); hipFree(w.lens); hipFree(w.pair_off); hipFree(w.row_pair); hipFree(w.m_packed);
+    hipFree(w.sid); hipFree(w.stt); hipFree(w.logits);
+    w = rag_ce_model::MxWs();
+}
+
 static void ce_free_model(rag_ce_model** slot) {
     if (!*slot) return;
     for (void* p : (*slot)->allocs) hipFree(p);
     ce_free_ws(*slot);
+    mx_free_ws(*slot);
     delete *slot;
     *slot = nullptr;
 }
@@ -1306,6 +1355,22 @@ static int up_f16_concat(rag_ctx* h, rag_ce_model* m, std::vector<const float*> 
     return RAG_OK;
 }
 
+// rows of several fp32 host matrices (same `cols`) concatenated -> one hi16 + lo8 image tensor (ce_mx.h)
+static int up_mx_concat(rag_ctx* h, rag_ce_model* m, std::vector<const float*> srcs, size_t rows_each, size_t cols, char** dst) {
+    const size_t n_each = rows_each * cols, total = n_each * srcs.size();
+    float* tmp = nullptr;
+    HIP_TRY(h, hipMalloc(&tmp, total * sizeof(float)));
+    HIP_TRY(h, hipMalloc(dst, 3 * total));
+    m->allocs.push_back(*dst);
+    for (size_t i = 0; i < srcs.size(); ++i)
+        HIP_TRY(h, hipMemcpyAsync(tmp + i * n_each, srcs[i], n_each * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(mx_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, tmp, (int)(rows_each * srcs.size()),
+                       (int)cols, *dst);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    hipFree(tmp);
+    return RAG_OK;
+}
+
 // Tensor order (HF state-dict names), see optimized-rag_amd/cross_encoder.py::flatten_state_dict:
 //  0 word, 1 position, 2 token_type, 3 emb LN weight, 4 emb LN bias,
 //  per layer (16): q.w q.b k.w k.b v.w v.b attn.out.w attn.out.b attn.LN.w attn.LN.b inter.w inter.b out.w out.b out.LN.w out.LN.b
@@ -1331,9 +1396,16 @@ static int ce_load_model(rag_ctx* h, const rag_ce_config* cfg, const float* cons
     if ((rc = up_f32(h, m, T[3], H, &m->emb_ln_g))) return rc;
     if ((rc = up_f32(h, m, T[4], H, &m->emb_ln_b))) return rc;
     m->layers.resize(cfg->layers);
+    m->mx_ok = H == MX_TM && F % MX_TM == 0;           // one feature tile = the hidden state (LayerNorm in the epilogue)
     for (int l = 0; l < cfg->layers; ++l) {
         const float* const* t = T + 5 + 16 * l;
         auto& ly = m->layers[l];
+        if (m->mx_ok) {
+            if ((rc = up_mx_concat(h, m, {t[0], t[2], t[4]}, H, H, &ly.wqkv8))) return rc;
+            if ((rc = up_mx_concat(h, m, {t[6]}, H, H, &ly.wo8))) return rc;
+            if ((rc = up_mx_concat(h, m, {t[10]}, F, H, &ly.w18))) return rc;
+            if ((rc = up_mx_concat(h, m, {t[12]}, H, F, &ly.w28))) return rc;
+        }
         if ((rc = up_f16_concat(h, m, {t[0], t[2], t[4]}, H, H, &ly.wqkv))) return rc;
         std::vector<float> bq(3 * H);
         std::memcpy(bq.data(), t[1], H * 4); std::memcpy(bq.data() + H, t[3], H * 4); std::memcpy(bq.data() + 2 * H, t[5], H * 4);
@@ -1549,10 +1621,10 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     }
     (void)nullh;
     if (m->embed)
-        hipLaunchKernelGGL(ce_meanpool_kernel, dim3(P), dim3(256), 0, st, (const half_t*)m->x16, (const int32_t*)m->pair_off, lens_dev, L, H,
+        hipLaunchKernelGGL(ce_meanpool_kernel<false>, dim3(P), dim3(256), 0, st, (const half_t*)m->x16, (const int32_t*)m->pair_off, lens_dev, L, H,
                            m->normalize, logits_dev);
     else
-        hipLaunchKernelGGL(ce_pool_classify_kernel, dim3(P), dim3(256), 0, st, m->x16, m->wp, m->bp, m->wc, m->bc, m->pair_off, H, logits_dev);
+        hipLaunchKernelGGL(ce_pool_classify_kernel<false>, dim3(P), dim3(256), 0, st, m->x16, m->wp, m->bp, m->wc, m->bc, m->pair_off, H, logits_dev);
     HIP_TRY(h, hipGetLastError());
     return RAG_OK;
 }
@@ -1592,6 +1664,103 @@ static int ce_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t s
     return RAG_OK;
 }
 
+// ---- the MX forward (ce_mx.h): every GEMM on 384-feature x 128-token tiles with hi16 + lo8 operands ---------------------
+static int mx_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t st) {
+    auto& w = m->mx;
+    if (P <= w.pairs && L == w.L) return RAG_OK;
+    HIP_TRY(h, hipStreamSynchronize(st));
+    mx_free_ws(m);
+    const size_t H = m->cfg.hidden, F = m->cfg.ffn;
+    const int64_t Mp = round_up((int64_t)P * L, 256);
+    const size_t kv = (size_t)Mp * H + 2048;                       // halfs per plane of qf16 / kf16 / vf16
+    HIP_TRY(h, hipMalloc(&w.x8, (size_t)Mp * H * 3));
+    HIP_TRY(h, hipMalloc(&w.ctx8, (size_t)Mp * H * 3));
+    HIP_TRY(h, hipMalloc(&w.h8, (size_t)Mp * F * 3));
+    HIP_TRY(h, hipMalloc(&w.qf16, 2 * kv * 2));
+    HIP_TRY(h, hipMalloc(&w.kf16, 2 * kv * 2));
+    HIP_TRY(h, hipMalloc(&w.vf16, 2 * kv * 2));
+    HIP_TRY(h, hipMalloc(&w.ids, (size_t)Mp * 4));
+    HIP_TRY(h, hipMalloc(&w.tt, (size_t)Mp * 4));
+    HIP_TRY(h, hipMalloc(&w.lens, (size_t)P * 4));
+    HIP_TRY(h, hipMalloc(&w.pair_off, (size_t)(P + 1) * 4));
+    HIP_TRY(h, hipMalloc(&w.row_pair, (size_t)Mp * 4));
+    HIP_TRY(h, hipMalloc(&w.m_packed, 4));
+    HIP_TRY(h, hipMalloc(&w.sid, (size_t)P * L * 4));
+    HIP_TRY(h, hipMalloc(&w.stt, (size_t)P * L * 4));
+    HIP_TRY(h, hipMalloc(&w.logits, (size_t)P * m->out_width * 4));
+    // rows past a chunk's packed rows are read by the last token tile of every GEMM: keep them finite (zero is a valid image)
+    HIP_TRY(h, hipMemsetAsync(w.x8, 0, (size_t)Mp * H * 3, st));
+    HIP_TRY(h, hipMemsetAsync(w.ctx8, 0, (size_t)Mp * H * 3, st));
+    HIP_TRY(h, hipMemsetAsync(w.h8, 0, (size_t)Mp * F * 3, st));
+    HIP_TRY(h, hipMemsetAsync(w.qf16, 0, 2 * kv * 2, st));
+    HIP_TRY(h, hipMemsetAsync(w.kf16, 0, 2 * kv * 2, st));
+    HIP_TRY(h, hipMemsetAsync(w.vf16, 0, 2 * kv * 2, st));
+    w.pairs = P;
+    w.L = L;
+    w.tokens = Mp;
+    return RAG_OK;
+}
+
+template <int QB>
+static int mx_launch_attention(rag_ctx* h, rag_ce_model* m, int P, int L, size_t kv_plane, hipStream_t st, const int32_t* lens_dev) {
+    const int lds = L * 256;
+    int& attr_lds = h->attr_ce_attn_mx_lds[QB];
+    if (lds > attr_lds) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_attention_kernel<QB, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_lds = lds;
+    }
+    auto& w = m->mx;
+    hipLaunchKernelGGL((ce_attention_kernel<QB, true>), dim3(m->cfg.heads, P), dim3(64 * (L / (16 * QB))), lds, st, (const half_t*)w.qf16,
+                       (const half_t*)w.kf16, (const half_t*)w.vf16, kv_plane, lens_dev, (const int32_t*)w.pair_off, L, m->cfg.hidden,
+                       m->cfg.heads, (int)w.tokens, reinterpret_cast<half_t*>(w.ctx8));
+    return RAG_OK;
+}
+
+static int mx_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t st, const int32_t* lens_dev, float* logits_dev) {
+    auto& w = m->mx;
+    const int H = m->cfg.hidden, F = m->cfg.ffn;
+    const int64_t M = (int64_t)P * L, Mp = w.tokens;
+    const float eps = (float)m->cfg.ln_eps;
+    const size_t kv_plane = (size_t)Mp * H + 2048;
+    if (!h->attr_ce_mx) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(mx_gemm_kernel<mx_epi_qkv>), hipFuncAttributeMaxDynamicSharedMemorySize, MX_KERNEL_LDS));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(mx_gemm_kernel<mx_epi_gelu>), hipFuncAttributeMaxDynamicSharedMemorySize, MX_KERNEL_LDS));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(mx_gemm_kernel<mx_epi_ln>), hipFuncAttributeMaxDynamicSharedMemorySize, MX_KERNEL_LDS));
+        h->attr_ce_mx = true;
+    }
+    hipLaunchKernelGGL(ce_pack_scan_kernel, dim3(1), dim3(1024), 0, st, lens_dev, P, L, w.pair_off, w.m_packed);
+    hipLaunchKernelGGL(ce_pack_rows_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, st, (const int32_t*)w.pair_off, P, L, Mp, w.row_pair);
+    hipLaunchKernelGGL(mx_embed_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const int32_t*)w.ids, (const int32_t*)w.tt,
+                       (const float*)m->word, (const float*)m->pos, (const float*)m->type, (const float*)m->emb_ln_g, (const float*)m->emb_ln_b,
+                       (const int32_t*)w.m_packed, (const int32_t*)w.row_pair, (const int32_t*)w.pair_off, L, m->cfg.vocab_size, eps, w.x8);
+    static const unsigned n_cu = [] { int d = 0, n = 0; hipGetDevice(&d); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return (unsigned)(n >= 8 ? n / 8 * 8 : 256); }();
+    const dim3 blk(512);
+    for (int l = 0; l < m->cfg.layers; ++l) {
+        auto& ly = m->layers[l];
+        hipLaunchKernelGGL((mx_gemm_kernel<mx_epi_qkv>), dim3(n_cu), blk, MX_KERNEL_LDS, st, (const char*)ly.wqkv8, (const char*)w.x8, H / 32, 3,
+                           (const int32_t*)w.m_packed, mx_epi_qkv{w.qf16, w.kf16, w.vf16, kv_plane, ly.bqkv, (int)(Mp >> 4)});
+        {
+            const int rc = L == 32 ? mx_launch_attention<1>(h, m, P, L, kv_plane, st, lens_dev) : mx_launch_attention<2>(h, m, P, L, kv_plane, st, lens_dev);
+            if (rc != RAG_OK) return rc;
+        }
+        hipLaunchKernelGGL((mx_gemm_kernel<mx_epi_ln>), dim3(n_cu), blk, MX_KERNEL_LDS, st, (const char*)ly.wo8, (const char*)w.ctx8, H / 32, 1,
+                           (const int32_t*)w.m_packed, mx_epi_ln{w.x8, ly.bo, ly.ln1_g, ly.ln1_b, eps});
+        hipLaunchKernelGGL((mx_gemm_kernel<mx_epi_gelu>), dim3(n_cu), blk, MX_KERNEL_LDS, st, (const char*)ly.w18, (const char*)w.x8, H / 32, F / MX_TM,
+                           (const int32_t*)w.m_packed, mx_epi_gelu{w.h8, ly.b1, F / 32});
+        hipLaunchKernelGGL((mx_gemm_kernel<mx_epi_ln>), dim3(n_cu), blk, MX_KERNEL_LDS, st, (const char*)ly.w28, (const char*)w.h8, F / 32, 1,
+                           (const int32_t*)w.m_packed, mx_epi_ln{w.x8, ly.b2, ly.ln2_g, ly.ln2_b, eps});
+    }
+    if (m->embed)
+        hipLaunchKernelGGL(ce_meanpool_kernel<true>, dim3(P), dim3(256), 0, st, reinterpret_cast<const half_t*>(w.x8), (const int32_t*)w.pair_off, lens_dev,
+                           L, H, m->normalize, logits_dev);
+    else
+        hipLaunchKernelGGL(ce_pool_classify_kernel<true>, dim3(P), dim3(256), 0, st, reinterpret_cast<const half_t*>(w.x8), (const float*)m->wp,
+                           (const float*)m->bp, (const float*)m->wc, (const float*)m->bc, (const int32_t*)w.pair_off, H, logits_dev);
+    HIP_TRY(h, hipGetLastError());
+    return RAG_OK;
+}
+
 // pads [P][L_in] token arrays to the supported attention length L (>= L_in), pad id 0 / type 0
 __global__ void ce_pad_tokens_kernel(const int32_t* __restrict__ in_ids, const int32_t* __restrict__ in_tt, int P, int L_in, int L,
                                      int32_t* __restrict__ ids, int32_t* __restrict__ tt) {
@@ -1614,10 +1783,16 @@ static int ce_run(rag_ctx* h, rag_ce_model* m, const int32_t* ids, const int32_t
     // the multi-chunk loop on small inputs.
     const int64_t chunk_tokens = h->opt.ce_chunk_tokens >= 32 ? h->opt.ce_chunk_tokens : 2'000'000;
     const int chunk = std::max(1, std::min(P, (int)(chunk_tokens / L)));
-    int rc = ce_ensure_ws(h, m, chunk, L, st);
+    // Which forward: the MX kernels (hi16 + lo8 operands, 384 x 128 tiles; ce_mx.h) from MX_MIN_ROWS padded rows on - a single query's
+    // 100 pairs fill the CUs better with the split-fp16 kernels' finer tiles. Option ce_mx: 1 = always (when the shape allows), -1 = never.
+    const bool use_mx = m->mx_ok && L >= 32 && h->opt.ce_mx >= 0 && (h->opt.ce_mx > 0 || (int64_t)P * L >= MX_MIN_ROWS);
+    int rc = use_mx ? mx_ensure_ws(h, m, chunk, L, st) : ce_ensure_ws(h, m, chunk, L, st);
     if (rc) return rc;
     const hipMemcpyKind kin = hipMemcpyHostToDevice, kout = hipMemcpyDeviceToHost;
-    int32_t *sid = m->sid, *stt = m->stt;
+    int32_t *sid = use_mx ? m->mx.sid : m->sid, *stt = use_mx ? m->mx.stt : m->stt;
+    int32_t* const lens_stage = use_mx ? m->mx.lens : m->lens;
+    float* const logits_stage = use_mx ? m->mx.logits : m->logits;
+    int32_t *const ids_pad = use_mx ? m->mx.ids : m->ids, *const tt_pad = use_mx ? m->mx.tt : m->tt;
     if ((rc = prof_begin(h, 2, st))) return rc;
     for (int p0 = 0; p0 < P; p0 += chunk) {
         const int pc = std::min(chunk, P - p0);
@@ -1628,14 +1803,14 @@ static int ce_run(rag_ctx* h, rag_ce_model* m, const int32_t* ids, const int32_t
         if (host_ptrs) {
             HIP_TRY(h, hipMemcpyAsync(sid, src_ids, (size_t)pc * L_in * 4, kin, st));
             HIP_TRY(h, hipMemcpyAsync(stt, src_tt, (size_t)pc * L_in * 4, kin, st));
-            HIP_TRY(h, hipMemcpyAsync(m->lens, lens_dev, (size_t)pc * 4, kin, st));
-            src_ids = sid; src_tt = stt; lens_dev = m->lens; logits_dev = m->logits;
+            HIP_TRY(h, hipMemcpyAsync(lens_stage, lens_dev, (size_t)pc * 4, kin, st));
+            src_ids = sid; src_tt = stt; lens_dev = lens_stage; logits_dev = logits_stage;
         }
         const int64_t n = (int64_t)pc * L;
-        hipLaunchKernelGGL(ce_pad_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src_ids, src_tt, pc, L_in, L, m->ids, m->tt);
-        rc = ce_forward_chunk(h, m, pc, L, st, lens_dev, logits_dev);
+        hipLaunchKernelGGL(ce_pad_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src_ids, src_tt, pc, L_in, L, ids_pad, tt_pad);
+        rc = use_mx ? mx_forward_chunk(h, m, pc, L, st, lens_dev, logits_dev) : ce_forward_chunk(h, m, pc, L, st, lens_dev, logits_dev);
         if (rc) break;
-        if (host_ptrs) HIP_TRY(h, hipMemcpyAsync(out + (size_t)p0 * ow, m->logits, (size_t)pc * ow * 4, kout, st));
+        if (host_ptrs) HIP_TRY(h, hipMemcpyAsync(out + (size_t)p0 * ow, logits_stage, (size_t)pc * ow * 4, kout, st));
     }
     if (!rc) rc = prof_end(h, 2, st);
     // device-pointer calls stay asynchronous on the caller's stream (all buffers belong to the model workspace);
