@@ -276,6 +276,9 @@ __device__ __forceinline__ void mx_pair_swap(unsigned a, unsigned b, unsigned& x
     y = s[1];
 }
 
+#ifndef MX_STORE16
+#define MX_STORE16(p, v) *reinterpret_cast<mx_u4*>(p) = (v)
+#endif
 // Stores one 32-feature block of a NON-swapped accumulator tile (+ the values in v[16], already biased / activated) into the image
 // layout of the next GEMM's token operand: row `trow` of the tile image `img` (K-step = this block's 32 features).
 // v[4q + e] = feature 8q + 4hh + e of the block. The two lane halves exchange so that every lane stores whole 16-B chunks:
@@ -291,13 +294,13 @@ __device__ __forceinline__ void mx_store_block(char* img, int trow, int hh, cons
         unsigned c0, c1, c2, c3;
         mx_pair_swap(hi[2 * j][0], hi[2 * j + 1][0], c0, c2);
         mx_pair_swap(hi[2 * j][1], hi[2 * j + 1][1], c1, c3);
-        *reinterpret_cast<mx_u4*>(img + (2 * j + hh) * MX_B_PLANE + trow * 16) = (mx_u4){c0, c1, c2, c3};
+        MX_STORE16(img + (2 * j + hh) * MX_B_PLANE + trow * 16, ((mx_u4){c0, c1, c2, c3}));
     }
     // lo plane 4 + h: the lane's bytes hh*8 .. +8 = (j = 0: q = h) then (j = 1: q = 2 + h)
     unsigned c0, c1, c2, c3;
     mx_pair_swap(lo[0], lo[1], c0, c2);
     mx_pair_swap(lo[2], lo[3], c1, c3);
-    *reinterpret_cast<mx_u4*>(img + (4 + hh) * MX_B_PLANE + trow * 16) = (mx_u4){c0, c1, c2, c3};
+    MX_STORE16(img + (4 + hh) * MX_B_PLANE + trow * 16, ((mx_u4){c0, c1, c2, c3}));
 }
 
 // ---- weights: fp32 [N][K] (nn.Linear) -> image layout [N / 384][K / 32][36 KiB]

@@ -681,7 +681,7 @@ __global__ __launch_bounds__(512) void ce_gemm_ln_kernel(const half_t* __restric
 #define FFN_LDS (FFN_RING + FFN_HBUF)
 #define FFN_CH 128                                // intermediate features per chunk
 #define FFN_FUSED_MIN_ROWS (5120 * 256)            // P x L from which the fused kernel is used (below: the two-launch form)
-#define MX_MIN_ROWS (512 * 256)                    // P x L from which the MX forward (ce_mx.h) runs instead of the split-fp16 kernels
+#define MX_MIN_ROWS (20 * 256)                     // P x L from which the MX forward (ce_mx.h) runs instead of the split-fp16 kernels (tools/ce_mx_sweep.py: 13 pairs tie, 25 pairs and up MX is 10-19 % faster)
 template <int TERMS>
 __global__ __launch_bounds__(512) void ce_ffn_ln_kernel(const half_t* __restrict__ W1, const float* __restrict__ b1,
                                                          const half_t* __restrict__ W2, const float* __restrict__ b2, int F,

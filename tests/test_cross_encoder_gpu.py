@@ -16,10 +16,15 @@ LOGIT_TOL = 4e-3
 SCORE_TOL = 1e-3
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=["mx", "split16"])
+def eng(request):
+    """Every test of this file runs on both forwards: the MX kernels (hi16 + lo8 operands, csrc/ce_mx.h; option ce_mx = 1 forces
+    them for every batch size the shape allows - by default they run from 20 x 256 padded rows on) and the split-fp16 kernels of
+    rounds 1-3 (ce_mx = -1), which remain the path of other hidden sizes and of very small batches."""
     from optimized_rag_amd import RagEngine
     e = RagEngine(dim=1536, device=0)
+    e.ce_mode = 1 if request.param == "mx" else -1
+    e.set_option("ce_mx", e.ce_mode)
     yield e
     e.close()
 
@@ -100,6 +105,33 @@ def test_bench_path_persistent_handover_and_two_chunks(eng):
     assert np.abs(sg - se).max() < SCORE_TOL
     # the host-pointer entry walks the same chunk loop with H2D staging per chunk: same bits
     np.testing.assert_array_equal(eng.ce_score(ids[7700:7900], tt[7700:7900], lens[7700:7900]), got[7700:7900])
+
+
+def test_mx_and_split16_forwards_agree_and_default_threshold(eng):
+    """The two forwards on the same pairs: both within the bar of the float64 oracle, hence within twice the bar of each other; with
+    the option at its default (0) a 64-pair batch at L = 128 takes the MX kernels (bit-identical to the forced MX run) and a
+    3-pair batch the split-fp16 kernels (bit-identical to the forced split-fp16 run)."""
+    cfg = B.minilm_config()
+    w = B.seeded_weights(cfg, 2024)
+    load_model(eng, cfg, w)
+    rng = np.random.default_rng(77)
+    P, L = 64, 128
+    lens = rng.integers(2, L + 1, P).astype(np.int32)
+    ids, tt = _random_pairs(rng, cfg, P, L, lens)
+    res = {}
+    try:
+        for mode in (1, -1, 0):
+            eng.set_option("ce_mx", mode)
+            res[mode] = (eng.ce_score(ids, tt, lens), eng.ce_score(ids[:3], tt[:3], lens[:3]))
+    finally:
+        eng.set_option("ce_mx", eng.ce_mode)
+    exp = B.forward_logits(w, cfg, ids[:12].astype(np.int64), tt[:12].astype(np.int64), lens[:12], fast_erf=True)
+    assert np.abs(res[1][0][:12] - exp).max() < LOGIT_TOL
+    assert np.abs(res[-1][0][:12] - exp).max() < LOGIT_TOL
+    assert np.abs(res[1][0] - res[-1][0]).max() < 2 * LOGIT_TOL
+    assert np.abs(res[1][0] - res[-1][0]).max() > 0            # they ARE different arithmetic
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[-1][1])
 
 
 def test_small_multi_chunk_loop(eng, monkeypatch):

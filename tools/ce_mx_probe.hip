@@ -6,6 +6,7 @@
 // the scheme is worth), then times the launch with a store-nothing epilogue and with the image-layout epilogue.
 #include "../optimized-rag_amd/csrc/ce_mx.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -41,7 +42,7 @@ struct epi_none {         // timing: main loop only
     }
 };
 
-struct epi_img {          // timing + layout check: + bias -> image layout of the NEXT GEMM's token operand (K = N)
+struct epi_img {          // timing + layout check: + bias -> image layout of the NEXT GEMM's token operand (K = N): the product's store path
     char* out;            // [token tile][N / 32][12 KiB image]
     const float* bias;
     int N;
@@ -53,36 +54,32 @@ struct epi_img {          // timing + layout check: + bias -> image layout of th
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             const int f0 = ft * MX_TM + wm * 192 + b * 32;
-            char* img = tile + (size_t)(f0 >> 5) * MX_B_STAGE;
-            unsigned lo[4];
+            float v[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                // the lane's 4 values of group q: elements e = 8q + 4hh + r -> fragment (j = q>>1, h = q&1), i = 4hh + r
+#ifdef PROBE_NO_BIAS
+                const float4 bv = make_float4(0.5f, 0.25f, 0.125f, 1.0f);
+#else
                 const float4 bv = *reinterpret_cast<const float4*>(bias + f0 + 8 * q + 4 * hh);
-                half4 hi;
-                unsigned l8 = 0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    half_t h_;
-                    unsigned l_;
-                    mx_split(acc[b][q * 4 + r] + (r == 0 ? bv.x : r == 1 ? bv.y : r == 2 ? bv.z : bv.w), h_, l_);
-                    hi[r] = h_;
-                    l8 |= l_ << (8 * r);
-                }
-                lo[q] = l8;
-                *reinterpret_cast<half4*>(img + ((q >> 1) * 2 + (q & 1)) * MX_B_PLANE + t * 16 + hh * 8) = hi;
+#endif
+                v[q * 4] = acc[b][q * 4] + bv.x; v[q * 4 + 1] = acc[b][q * 4 + 1] + bv.y; v[q * 4 + 2] = acc[b][q * 4 + 2] + bv.z; v[q * 4 + 3] = acc[b][q * 4 + 3] + bv.w;
             }
-            // lo plane 4 + h: bytes hh*8 + j*4 + r: (q = h, j = 0) then (q = 2 + h, j = 1)
-            *reinterpret_cast<uint2*>(img + 4 * MX_B_PLANE + t * 16 + hh * 8) = make_uint2(lo[0], lo[2]);
-            *reinterpret_cast<uint2*>(img + 5 * MX_B_PLANE + t * 16 + hh * 8) = make_uint2(lo[1], lo[3]);
+            mx_store_block(tile + (size_t)(f0 >> 5) * MX_B_STAGE, t, hh, v);
         }
     }
 };
 
+__device__ unsigned long long g_stamp[256][2];          // per workgroup: shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) of the launch
+
 template <class EPI>
 __global__ __launch_bounds__(512) void probe_kernel(const char* W, const char* X, int nk, int n_ft, int n_tt, EPI epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     mx_gemm_loop(W, X, nk, n_ft, n_tt, smem, epi);
+    if (threadIdx.x == 0 && blockIdx.x < 256) {
+        g_stamp[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - c0;
+        g_stamp[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 
 static float e5m2_val(unsigned b) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(b << 8)); }
@@ -183,22 +180,30 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int mode = 0; mode < 2; ++mode) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_kernel<mx_epi_gelu>), hipFuncAttributeMaxDynamicSharedMemorySize, MX_KERNEL_LDS));
+    for (int mode = 0; mode < 3; ++mode) {
         float best = 1e9f;
         for (int itr = 0; itr < 6; ++itr) {
             CK(hipEventRecord(e0));
             if (mode == 0) hipLaunchKernelGGL(probe_kernel<epi_none>, dim3(256), dim3(512), MX_LDS, 0, dW, dX, nk, n_ft, n_tt, epi_none{dC});
-            else hipLaunchKernelGGL(probe_kernel<epi_img>, dim3(256), dim3(512), MX_LDS, 0, dW, dX, nk, n_ft, n_tt, epi_img{dO, dB, N});
+            else if (mode == 1) hipLaunchKernelGGL(probe_kernel<epi_img>, dim3(256), dim3(512), MX_LDS, 0, dW, dX, nk, n_ft, n_tt, epi_img{dO, dB, N});
+            else hipLaunchKernelGGL(probe_kernel<mx_epi_gelu>, dim3(256), dim3(512), MX_KERNEL_LDS, 0, dW, dX, nk, n_ft, n_tt, mx_epi_gelu{dO, dB, N / 32});
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             float ms;
             CK(hipEventElapsedTime(&ms, e0, e1));
             if (itr) best = std::min(best, ms);
         }
+        unsigned long long hs[256][2];
+        CK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_stamp), sizeof(hs)));
+        std::vector<double> ghz;
+        for (int b = 0; b < 256; ++b) if (hs[b][1]) ghz.push_back((double)hs[b][0] / (double)hs[b][1] * 0.1);
+        std::sort(ghz.begin(), ghz.end());
+        const double clk = ghz.empty() ? 0.0 : ghz[ghz.size() / 2];
         const double prod = 2.0 * M * N * K;
         const double steps = (double)n_tt * n_ft * nk / 256.0;
-        printf("%s: %.3f ms | %.1f TFLOP/s of products (x2 units issued: %.1f) | %.3f us per K-step per CU | LDS fill %.2f TB/s (%.1f B/clk/CU at 2.4 GHz)\n",
-               mode == 0 ? "main loop only " : "image epilogue", best, prod / best * 1e-9, 2 * prod / best * 1e-9, best * 1e3 / steps,
+        printf("[in-kernel clock %.2f GHz] %s: %.3f ms | %.1f TFLOP/s of products (x2 units issued: %.1f) | %.3f us per K-step per CU | LDS fill %.2f TB/s (%.1f B/clk/CU at 2.4 GHz)\n",
+               clk, mode == 0 ? "main loop only " : mode == 1 ? "image epilogue" : "gelu epilogue ", best, prod / best * 1e-9, 2 * prod / best * 1e-9, best * 1e3 / steps,
                (double)n_tt * n_ft * nk * MX_STAGE / best * 1e-9, (double)MX_STAGE / (best * 1e-3 / steps * 2.4e9));
     }
     return 0;
