@@ -172,3 +172,120 @@ def shard_blocks(eng, st, device, rank=0, world=1, steps=3, pool=100, k=20, L_pa
     blocks["hbm_used_gb"] = used
     blocks["hbm_total_gb"] = total
     return blocks
+
+
+def token_lengths(rows, total_rows, device, vocab_size, with_tokens=False):
+    """Lengths (and optionally the token rows) of the given documents of the replicated store, regenerated chunk by chunk with the
+    store's own generator (the store itself lives inside the library)."""
+    rows = np.asarray(rows, dtype=np.int64)
+    lens = np.zeros(rows.shape, dtype=np.int64)
+    toks = np.zeros(rows.shape + (TOK_L,), dtype=np.int32) if with_tokens else None
+    for c in np.unique(rows // TOK_CHUNK):
+        tok, ln = gen_tokens_chunk(int(c), min(TOK_CHUNK, total_rows - int(c) * TOK_CHUNK), device, vocab_size)
+        sel = (rows // TOK_CHUNK) == c
+        idx = torch.from_numpy(rows[sel] - c * TOK_CHUNK).to(device)
+        lens[sel] = ln[idx].cpu().numpy()
+        if with_tokens:
+            toks[sel] = tok[idx].cpu().numpy()
+        del tok, ln
+    return lens, toks
+
+
+def headline_rerank(eng, device, rows_total, rank=0, world=1, steps=20, warmup=3, cpu_baseline=True, pool=100, k=20, L_pair=256, phase=None):
+    """BASELINE.json configs[3], the configuration its metric is quoted on: hybrid top-100 -> MiniLM-L-6 cross-encoder -> top-20,
+    256-query batches over a `rows_total` x 1536-d corpus, row-sharded over `world` ranks (strong scaling: the same corpus and
+    batch at every N; one rank: the one-call entry rag_retrieve_rerank_dev, several: ShardedPipeline - per-shard candidate lists,
+    one all-gather, fusion, the 25,600 pairs split over the ranks, one gather of the logits). bench.py's timing contract:
+    `warmup` untimed batches, exactly `steps` timed ones between barrier + synchronize, MAX over ranks. Returns the fields of the
+    bench line (value, ms_per_step, latencies, roofline, cpu_baseline)."""
+    import torch.distributed as dist
+    from optimized_rag_amd.sharded import ShardedPipeline
+    say = phase or (lambda s: None)
+    Q, Lq = 256, 16
+    say("headline: build_shard")
+    st = build_shard(eng, device, rows_total // world, rank=rank, world=world, Q=Q)
+    q = st["queries"]
+    pipe = ShardedPipeline(eng, rank=rank, world=world)
+
+    def run(nq=Q):
+        if world == 1:
+            return eng.retrieve_rerank_dev(q[:nq], st["q_tok_d"][:nq], st["q_len_d"][:nq], pool, k, term_ptr=st["ptr_d"][:nq + 1], terms=st["terms_d"], L_pair=L_pair)
+        return pipe.retrieve_rerank(q[:nq].contiguous(), st["ptr_d"][:nq + 1].contiguous(), st["terms_d"], st["q_tok_d"][:nq].contiguous(),
+                                    st["q_len_d"][:nq].contiguous(), pool, k, L_pair=L_pair)
+
+    say("headline: warmup")
+    for _ in range(max(1, warmup)):
+        run()
+    torch.cuda.synchronize()
+    eng.set_profiling(True)
+    say("headline: timed steps")
+    t = BM.timed_all_ranks(run, steps, 0, world)
+    ce_ms, ce_spans = eng.stage_kernel_ms(2)
+    eng.set_profiling(False)
+    say("headline: latencies")
+    lat_b, lat_1 = [], []
+    for which, n_it, warm, nq in ((lat_b, 5, 0, Q), (lat_1, 60, 6, 1)):
+        for i in range(warm + n_it):
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            run(nq)
+            torch.cuda.synchronize()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            if world > 1:
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            if i >= warm:
+                which.append(float(dt.item()) * 1e3)
+    res = run()
+    torch.cuda.synchronize()
+    ids, sc, cand = res[0], res[1], res[3]
+    ok = bool((ids >= 0).all().item() and (sc[:, :-1] >= sc[:, 1:]).all().item())
+    cand_h = cand.cpu().numpy()
+    cfg = st["cfg"]
+    # algorithmic FLOPs of one batch: SURVEY 8d per-pair formula 6 * len * (3.539e6 + 1536 * len) on the REAL token counts of the
+    # pairs that were scored ([CLS] q [SEP] passage [SEP], longest_first to L); padding is neither computed nor counted
+    plens, _ = token_lengths(cand_h.reshape(-1), rows_total, device, cfg["vocab_size"])
+    plen = np.minimum(Lq + plens.astype(np.float64) + 3, L_pair)
+    flops = float((6.0 * plen * (3.539e6 + 1536.0 * plen)).sum())
+    fwd_ms = ce_ms / max(1, ce_spans)
+    ce_tf = flops / world / (fwd_ms * 1e-3) / 1e12            # this rank's forward scores 1 / world of the pairs
+    out = {
+        "value": round(Q / t, 2), "ms_per_step": round(t * 1e3, 3),
+        "p50_batch_latency_ms": round(float(np.median(lat_b)), 3), "p50_single_query_latency_ms": round(float(np.median(lat_1)), 3),
+        "pairs_per_sec": round(Q * pool / t, 1), "mean_pair_tokens": round(float(plen.mean()), 1),
+        "roofline": {"bound": "mfma", "kernel": "cross-encoder forward of one batch on rank 0 (mx_gemm_kernel<qkv | ln | gelu> + ce_attention_kernel + "
+                                                  "embedding / pooler), all chunks; dominant kernel mx_gemm_kernel<mx_epi_gelu> (FFN up-projection)",
+                     "achieved": round(ce_tf, 2), "peak": BE.PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ce_tf / BE.PEAK_MFMA_TFLOPS, 4),
+                     "avg_forward_ms": round(fwd_ms, 3), "algorithmic_flops_per_forward": flops / world,
+                     "share_of_batch_time": round(fwd_ms / (t * 1e3), 4),
+                     "note": "algorithmic FLOPs / device time of the forward (HIP events on the launch stream). Operands are hi16 + lo8: per "
+                             "algorithmic product the matrix pipe issues one fp16 MFMA + one block-scaled bf8 MFMA at twice the rate = 2 "
+                             "fp16-equivalent units (rounds 1-3: 3), so the pipe sees twice this rate"},
+        "sanity": {"all_slots_filled_and_sorted": ok},
+        "hbm_used_gb": hbm_used_gb(device)[0],
+    }
+    if cpu_baseline and rank == 0:
+        say("headline: cpu baseline")
+        from oracle.cpu_baseline import bert_cpu_pairs
+        ns = 64                                              # 2 batches of 32 pairs = the first 64 candidates of query 0
+        rows = cand_h[0, :ns]
+        tl, tk = token_lengths(rows, rows_total, device, cfg["vocab_size"], with_tokens=True)
+        q_tok = st["q_tok"]
+        pid = np.zeros((ns, L_pair), dtype=np.int64)
+        ptt = np.zeros((ns, L_pair), dtype=np.int64)
+        pl = np.zeros(ns, dtype=np.int64)
+        for j in range(ns):
+            dlen = int(min(tl[j], L_pair - 3 - Lq))
+            row = [101] + q_tok[0].tolist() + [102] + tk[j, :dlen].tolist() + [102]
+            pid[j, :len(row)] = row
+            ptt[j, Lq + 2:len(row)] = 1
+            pl[j] = len(row)
+        cl, cdt, threads = bert_cpu_pairs(cfg, st["tensors"], pid, ptt, pl, batch=32)
+        out["cpu_baseline"] = {"value": round(ns / cdt / pool, 4), "unit": "queries/sec", "cores": threads, "kind": "port",
+                               "pairs_per_sec": round(ns / cdt, 2),
+                               "sample": f"rerank stage only (the retrieval legs have their own baselines in the `dense` and `hybrid` blocks): {ns} of "
+                                         f"the batch's {Q * pool} pairs (the first {ns} candidates of query 0), torch-CPU "
+                                         f"BertForSequenceClassification fp32, batch 32 padded to the longest pair (what sentence-transformers' "
+                                         f"CrossEncoder.predict does on CPU), {cdt:.2f}s; value = pairs/s / {pool} pairs per query"}
+    return out

@@ -325,6 +325,9 @@ int rag_rerank_topk_dev(rag_handle_t h, const float* logits_dev, const int64_t* 
 int rag_comm_unique_id(void* id128_out);
 int rag_comm_init(rag_handle_t h, int rank, int world, const void* id128);
 int rag_comm_allgather_dev(rag_handle_t h, const void* send_dev, void* recv_dev, size_t bytes, void* stream);
+/* ranks of the communicator the gathers run on, as RCCL itself counts them (ncclCommCount): what bench.py reports next to the
+ * rank count of torch's own collective layer */
+int rag_comm_count(rag_handle_t h, int* count_out);
 int rag_comm_destroy(rag_handle_t h);
 
 #ifdef __cplusplus

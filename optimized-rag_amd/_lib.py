@@ -67,6 +67,7 @@ _SIGS = {
     "rag_comm_unique_id": ([_P], C.c_int),
     "rag_comm_init": ([_P, C.c_int, C.c_int, _P], C.c_int),
     "rag_comm_allgather_dev": ([_P, _P, _P, C.c_size_t, _P], C.c_int),
+    "rag_comm_count": ([_P, _P], C.c_int),
     "rag_comm_destroy": ([_P], C.c_int),
     "rag_pairwise_cosine_host": ([_P, _P, C.c_int, _P, C.c_int, C.c_int, _P], C.c_int),
     "rag_rrf_fuse_host": ([_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P], C.c_int),
@@ -356,6 +357,12 @@ class RagEngine:
         st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
         self._check(self.lib.rag_comm_allgather_dev(self.h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), nbytes, st),
                     "rag_comm_allgather_dev")
+
+    def comm_count(self):
+        """Ranks of the RCCL communicator behind rag_comm_allgather_dev (ncclCommCount)."""
+        n = C.c_int(0)
+        self._check(self.lib.rag_comm_count(self.h, C.byref(n)), "rag_comm_count")
+        return int(n.value)
 
     def comm_destroy(self):
         self._check(self.lib.rag_comm_destroy(self.h), "rag_comm_destroy")

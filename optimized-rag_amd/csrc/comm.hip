@@ -17,6 +17,7 @@ struct rccl_api {
     int (*comm_init_rank)(nccl_comm*, int, nccl_uid, int) = nullptr;
     int (*all_gather)(const void*, void*, size_t, int, nccl_comm, hipStream_t) = nullptr;
     int (*comm_destroy)(nccl_comm) = nullptr;
+    int (*comm_count)(nccl_comm, int*) = nullptr;
     const char* (*error_string)(int) = nullptr;
     bool ok = false;
 };
@@ -34,6 +35,7 @@ rccl_api& rccl() {
         a.comm_init_rank = reinterpret_cast<decltype(a.comm_init_rank)>(dlsym(lib, "ncclCommInitRank"));
         a.all_gather = reinterpret_cast<decltype(a.all_gather)>(dlsym(lib, "ncclAllGather"));
         a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(dlsym(lib, "ncclCommDestroy"));
+        a.comm_count = reinterpret_cast<decltype(a.comm_count)>(dlsym(lib, "ncclCommCount"));
         a.error_string = reinterpret_cast<decltype(a.error_string)>(dlsym(lib, "ncclGetErrorString"));
         a.ok = a.get_unique_id && a.comm_init_rank && a.all_gather && a.comm_destroy;
         return a;
@@ -90,6 +92,17 @@ int rag_comm_allgather_dev(rag_handle_t h, const void* send_dev, void* recv_dev,
     HIP_TRY(h, hipSetDevice(h->device));
     const int rc = rccl().all_gather(send_dev, recv_dev, bytes, 0 /* ncclInt8 */, h->comm, (hipStream_t)stream);
     if (rc != 0) return rccl_fail(h, "ncclAllGather", rc);
+    return RAG_OK;
+}
+
+int rag_comm_count(rag_handle_t h, int* count_out) {
+    if (!h) return RAG_ERR_ARG;
+    std::lock_guard<std::mutex> lock_(h->mu);
+    ARG_CHECK(h, count_out != nullptr, "comm_count: null");
+    ARG_CHECK(h, h->comm != nullptr, "comm_count: rag_comm_init has not run");
+    ARG_CHECK(h, rccl().comm_count != nullptr, "comm_count: ncclCommCount not found in librccl");
+    const int rc = rccl().comm_count(h->comm, count_out);
+    if (rc != 0) return rccl_fail(h, "ncclCommCount", rc);
     return RAG_OK;
 }
 
