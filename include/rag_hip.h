@@ -49,7 +49,7 @@ int rag_synchronize(rag_handle_t h);
 /* Diagnostic / tuning switch of one handle (no reference counterpart). Every switch <name> takes its default from the
  * environment variable RAG_<NAME> ONCE, when rag_create runs; afterwards only this call changes it. Names: force_level,
  * stage_growth, no_smallq, no_second_pass, dense_linear_order, bm25_first_ranges, bm25_no_staging, bm25_packed, bm25_linear_grid, bm25_sort_merge, no_fork,
- * fork_max_q, ce_no_fused_ln, ce_no_fused_ffn, ce_chunk_tokens, ce_mx. Unknown name: RAG_ERR_ARG. */
+ * fork_max_q, bm25_plan_slots, bm25_ws_mb, ce_no_fused_ln, ce_no_fused_ffn, ce_chunk_tokens, ce_mx. Unknown name: RAG_ERR_ARG. */
 int rag_set_option(rag_handle_t h, const char* name, int value);
 
 /* ---- dense index: replaces the pgvector tables behind
@@ -138,6 +138,11 @@ int rag_hybrid_fuse_gathered_dev(rag_handle_t h, const int64_t* gathered_dev, in
  *      rag/nodes/helpers.py:232-243, rag/retrieval.py:253-256.  out[m*n] row-major, 0.0 on zero norm. */
 int rag_pairwise_cosine_host(rag_handle_t h, const float* a_host, int m, const float* b_host, int n, int dim,
                              double* out_host);
+/* the same on float64 inputs: the reference multiplies Python doubles (rag/retrieval.py:362-371), so the mirror classes hand the
+ * agent's List[float] over unrounded - a pair sitting exactly on ConsistencyChecker's `>= 0.85` (rag/consistency_checker.py:179)
+ * must not flip because its inputs were cast to float32 first. */
+int rag_pairwise_cosine_f64_host(rag_handle_t h, const double* a_host, int m, const double* b_host, int n, int dim,
+                                 double* out_host);
 
 /* ---- reciprocal rank fusion: replaces ReciprocalRankFusion.fuse (rag/reranker.py:224-271).
  * lists_host: [Q][n_lists][list_len] int64 keys, -1 = padding (only at the tail of a list).

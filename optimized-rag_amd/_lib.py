@@ -70,6 +70,7 @@ _SIGS = {
     "rag_comm_count": ([_P, _P], C.c_int),
     "rag_comm_destroy": ([_P], C.c_int),
     "rag_pairwise_cosine_host": ([_P, _P, C.c_int, _P, C.c_int, C.c_int, _P], C.c_int),
+    "rag_pairwise_cosine_f64_host": ([_P, _P, C.c_int, _P, C.c_int, C.c_int, _P], C.c_int),
     "rag_rrf_fuse_host": ([_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P], C.c_int),
     "rag_bm25_load_host": ([_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double], C.c_int),
     "rag_bm25_topk_host": ([_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P], C.c_int),
@@ -370,14 +371,18 @@ class RagEngine:
 
     # ---- small ops --------------------------------------------------------------------------------
     def pairwise_cosine(self, a, b=None):
-        a = _np(a, np.float32)
-        b = a if b is None else _np(b, np.float32)
+        """float64 cosine matrix. float64 inputs (what engine.as_matrix builds from the agent's List[float]) go to the device
+        unrounded (rag_pairwise_cosine_f64_host); anything else is taken as float32."""
+        f64 = getattr(a, "dtype", None) == np.float64 and (b is None or getattr(b, "dtype", None) == np.float64)
+        dt = np.float64 if f64 else np.float32
+        a = _np(a, dt)
+        b = a if b is None else _np(b, dt)
         if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
             raise RagError(f"pairwise_cosine: shapes {a.shape} {b.shape}")
         out = np.zeros((a.shape[0], b.shape[0]), dtype=np.float64)
         if out.size:
-            self._check(self.lib.rag_pairwise_cosine_host(self.h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1],
-                                                          _ptr(out)), "rag_pairwise_cosine_host")
+            fn = self.lib.rag_pairwise_cosine_f64_host if f64 else self.lib.rag_pairwise_cosine_host
+            self._check(fn(self.h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1], _ptr(out)), "rag_pairwise_cosine_host")
         return out
 
     def chunk_chain(self, embs, sent_len, threshold, max_chunk, min_chunk):

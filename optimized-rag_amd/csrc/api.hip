@@ -65,7 +65,7 @@ static const struct { const char* name; int rag_options::*field; } g_options[] =
     {"no_smallq", &rag_options::no_smallq},             {"no_second_pass", &rag_options::no_second_pass},
     {"dense_linear_order", &rag_options::dense_linear_order},
     {"bm25_first_ranges", &rag_options::bm25_first_ranges}, {"bm25_no_staging", &rag_options::bm25_no_staging},
-    {"bm25_packed", &rag_options::bm25_packed},
+    {"bm25_packed", &rag_options::bm25_packed},         {"bm25_plan_slots", &rag_options::bm25_plan_slots},       {"bm25_ws_mb", &rag_options::bm25_ws_mb},
     {"bm25_linear_grid", &rag_options::bm25_linear_grid},            {"bm25_sort_merge", &rag_options::bm25_sort_merge},
     {"no_fork", &rag_options::no_fork},                 {"fork_max_q", &rag_options::fork_max_q},                 {"ce_no_fused_ln", &rag_options::ce_no_fused_ln},
     {"ce_no_fused_ffn", &rag_options::ce_no_fused_ffn}, {"ce_chunk_tokens", &rag_options::ce_chunk_tokens}, {"ce_mx", &rag_options::ce_mx},
@@ -78,6 +78,32 @@ static void options_from_env(rag_options* o) {
     }
 }
 #define LOCK(h) std::lock_guard<std::mutex> lock_((h)->mu)
+
+template <class T>
+static int pairwise_cosine_host_t(rag_handle_t h, const T* a, int m, const T* b, int n, int dim, double* out) {
+    if (!h) return RAG_ERR_ARG;
+    LOCK(h);
+    ARG_CHECK(h, m >= 0 && n >= 0 && dim > 0, "bad sizes");
+    if (m == 0 || n == 0) return RAG_OK;
+    ARG_CHECK(h, a && b && out, "null pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const bool same = (a == b && m == n);
+    hipStream_t st = h->stream;
+    int rc = stage_reserve(h, stage_size((size_t)m * dim, sizeof(T)) + stage_size(same ? 0 : (size_t)n * dim, sizeof(T)) + stage_size((size_t)m * n, 8));
+    if (rc) return rc;
+    char* p = (char*)h->stage;
+    T* ad = stage_take<T>(p, (size_t)m * dim);
+    T* bd = same ? ad : stage_take<T>(p, (size_t)n * dim);
+    double* od = stage_take<double>(p, (size_t)m * n);
+    HIP_TRY(h, hipMemcpyAsync(ad, a, (size_t)m * dim * sizeof(T), hipMemcpyHostToDevice, st));
+    if (!same) HIP_TRY(h, hipMemcpyAsync(bd, b, (size_t)n * dim * sizeof(T), hipMemcpyHostToDevice, st));
+    if constexpr (sizeof(T) == 8) rc = pairwise_cosine_f64(h, ad, m, bd, n, dim, od, st);
+    else rc = pairwise_cosine(h, ad, m, bd, n, dim, od, st);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(out, od, (size_t)m * n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return RAG_OK;
+}
 
 extern "C" {
 
@@ -411,27 +437,11 @@ int rag_hybrid_fuse_gathered_dev(rag_handle_t h, const int64_t* gathered_dev, in
 }
 
 int rag_pairwise_cosine_host(rag_handle_t h, const float* a, int m, const float* b, int n, int dim, double* out) {
-    if (!h) return RAG_ERR_ARG;
-    LOCK(h);
-    ARG_CHECK(h, m >= 0 && n >= 0 && dim > 0, "bad sizes");
-    if (m == 0 || n == 0) return RAG_OK;
-    ARG_CHECK(h, a && b && out, "null pointer");
-    HIP_TRY(h, hipSetDevice(h->device));
-    const bool same = (a == b && m == n);
-    hipStream_t st = h->stream;
-    int rc = stage_reserve(h, stage_size((size_t)m * dim, 4) + stage_size(same ? 0 : (size_t)n * dim, 4) + stage_size((size_t)m * n, 8));
-    if (rc) return rc;
-    char* p = (char*)h->stage;
-    float* ad = stage_take<float>(p, (size_t)m * dim);
-    float* bd = same ? ad : stage_take<float>(p, (size_t)n * dim);
-    double* od = stage_take<double>(p, (size_t)m * n);
-    HIP_TRY(h, hipMemcpyAsync(ad, a, (size_t)m * dim * sizeof(float), hipMemcpyHostToDevice, st));
-    if (!same) HIP_TRY(h, hipMemcpyAsync(bd, b, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, st));
-    rc = pairwise_cosine(h, ad, m, bd, n, dim, od, st);
-    if (rc) return rc;
-    HIP_TRY(h, hipMemcpyAsync(out, od, (size_t)m * n * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipStreamSynchronize(st));
-    return RAG_OK;
+    return pairwise_cosine_host_t<float>(h, a, m, b, n, dim, out);
+}
+
+int rag_pairwise_cosine_f64_host(rag_handle_t h, const double* a, int m, const double* b, int n, int dim, double* out) {
+    return pairwise_cosine_host_t<double>(h, a, m, b, n, dim, out);
 }
 
 int rag_rrf_fuse_host(rag_handle_t h, const int64_t* lists, int Q, int L, int len, int rrf_k, int top_k, int64_t* keys_out,

@@ -93,6 +93,7 @@ struct rag_bm25_index {
     bm_plan_meta* ws_plan_meta = nullptr;
     size_t ws_plan_entries = 0;
     int ws_plan_q = 0;
+    int plan_t = 64;                   // planned token slots per query of the CURRENT call (bm25_pick_plan_t), <= BM_PLAN_T
     double avgdl = 0, k1 = 1.5, b = 0.75;
     int normalize = 1;                 // 0: top-k scores stay raw (row-sharded search divides by the GLOBAL max after the merge)
 };
@@ -221,26 +222,30 @@ __device__ __forceinline__ void bm_bracket(const bm_term_meta& m, const int32_t*
 // (query, range edge), looping over the query's tokens: bracket lookup + in-bracket search, all independent - the searches the
 // two-level table needs run here, massively parallel, instead of at the head of every scoring workgroup's dependent chain.
 // The scoring kernel then reads two adjacent plan entries per token, exactly as it read r2's dense per-term table.
+// The plan holds plan_t <= BM_PLAN_T token slots per query, chosen per call so that the table stays under BM_PLAN_BUDGET bytes
+// (64 slots x 6,104 ranges x 4 B = 1.56 MB per query on a 12.5M-document shard whatever the queries' real token counts,
+// 1.6 GB at 1,024 queries); tokens past the plan are searched inside the scoring kernel, so results do not depend on plan_t.
 #define BM_PLAN_T 64
+#define BM_PLAN_BUDGET ((size_t)512 << 20)
 struct __attribute__((aligned(16))) bm_plan_meta { int64_t post; double idf; };
 
 __global__ __launch_bounds__(256) void bm25_plan_kernel(const bm_term_meta* __restrict__ meta, const int32_t* __restrict__ doc,
                                                          const int32_t* __restrict__ range_tab, int n_ranges, int64_t n_terms,
                                                          const int32_t* __restrict__ term_ptr, const int32_t* __restrict__ terms,
-                                                         int32_t* __restrict__ plan_off, bm_plan_meta* __restrict__ plan_meta) {
+                                                         int32_t* __restrict__ plan_off, bm_plan_meta* __restrict__ plan_meta, int plan_t) {
     const int q = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
-    const int t0 = term_ptr[q], nt = min(BM_PLAN_T, term_ptr[q + 1] - t0);
+    const int t0 = term_ptr[q], nt = min(plan_t, term_ptr[q + 1] - t0);
     const int64_t tg = (int64_t)r * BM_RANGE;
     for (int s = 0; s < nt; ++s) {
         const int t = terms[t0 + s];
         const bool ok = t >= 0 && t < n_terms;               // out-of-vocabulary token: idf.get(q) is None -> 0
         bm_term_meta m = {0, 0, 0.0, 0, BM_NO_TAB};
         if (ok) m = meta[t];
-        if (r == 0) plan_meta[(size_t)q * BM_PLAN_T + s] = {m.post, ok ? m.idf : 0.0};
+        if (r == 0) plan_meta[(size_t)q * plan_t + s] = {m.post, ok ? m.idf : 0.0};
         if (r <= n_ranges) {
             int lo, hi;
             bm_bracket(m, range_tab, tg, lo, hi);
-            plan_off[((size_t)q * BM_PLAN_T + s) * (n_ranges + 1) + r] = bm_search(doc + m.post, lo, hi, tg);
+            plan_off[((size_t)q * plan_t + s) * (n_ranges + 1) + r] = bm_search(doc + m.post, lo, hi, tg);
         }
     }
 }
@@ -251,9 +256,9 @@ __global__ __launch_bounds__(256) void bm25_plan_kernel(const bm_term_meta* __re
 // that L2. n_groups splits the queries of a range into several columns when a launch has few ranges (the opening stages), so
 // that every XCD owns >= 16 columns or so and the XCDs finish together. Few queries (qgroup_len = 0): range-major, the ranges
 // of one query spread over the chip. The id -> XCD rule is a performance assumption only; any placement gives the same result.
-struct bm_grid { unsigned blocks; int nr_l, n_queries, n_groups, qgroup_len; };
+struct bm_grid { unsigned blocks; int nr_l, n_queries, n_groups, qgroup_len, plan_t; };
 static bm_grid bm_make_grid(int nr_l, int Q, int linear) {
-    bm_grid g{(unsigned)((int64_t)nr_l * Q), nr_l, Q, 1, 0};
+    bm_grid g{(unsigned)((int64_t)nr_l * Q), nr_l, Q, 1, 0, BM_PLAN_T};
     if (linear || Q < 128) return g;
     int G = 1;
     while (nr_l * G < 128 && G < 8 && Q / (2 * G) >= 64) G <<= 1;
@@ -321,9 +326,9 @@ __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_num_sgpr(96))) vo
     double f_first = 0.0;
     int64_t a_first = 0;
     int n_first = 0;
-    if (tid < min(BM_PLAN_T, t1 - t0)) {
-        const bm_plan_meta pm = plan_meta[(size_t)q * BM_PLAN_T + tid];
-        const int32_t* po = plan_off + ((size_t)q * BM_PLAN_T + tid) * (n_ranges + 1) + r;
+    if (tid < min(gm.plan_t, t1 - t0)) {
+        const bm_plan_meta pm = plan_meta[(size_t)q * gm.plan_t + tid];
+        const int32_t* po = plan_off + ((size_t)q * gm.plan_t + tid) * (n_ranges + 1) + r;
         const int o0 = po[0], o1 = po[1];
         f_first = pm.idf;
         a_first = pm.post + o0;
@@ -337,11 +342,11 @@ __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_num_sgpr(96))) vo
             double f = 0.0;
             int64_t a = 0;
             int n = 0;
-            if (tb == t0) {                                  // planned tokens (BM_PLAN_T = one batch)
+            if (tb == t0 && tid < gm.plan_t) {               // planned tokens (at most one batch)
                 f = f_first;
                 a = a_first;
                 n = n_first;
-            } else {                                         // tokens past the plan (a query of more than 64 tokens): search here
+            } else {                                         // tokens past the plan (more than plan_t tokens in the query): search here
                 const int t = terms[tb + tid];
                 if (t >= 0 && t < n_terms) {
                     const bm_term_meta m = meta[t];
@@ -1037,7 +1042,8 @@ struct bm25_topk_out {
 // the scoring launch: packed 4-byte postings when the index has them, the 12-byte form otherwise
 #define BM_RANGE_LAUNCH(H, IX, NR_L, NQ, ST, NR, TP, TM, K, MODE, ...)                                                             \
     {                                                                                                                              \
-        const bm_grid gm_ = bm_make_grid(NR_L, NQ, (H)->opt.bm25_linear_grid);                                                     \
+        bm_grid gm_ = bm_make_grid(NR_L, NQ, (H)->opt.bm25_linear_grid);                                                           \
+        gm_.plan_t = (IX)->plan_t;                                                                                                 \
         if ((IX)->packed != nullptr)                                                                                               \
             hipLaunchKernelGGL(bm25_range_kernel<true>, dim3(gm_.blocks), dim3(BM_THREADS), BM_LDS_BYTES, ST, (IX)->meta, (IX)->doc, (IX)->w, \
                                (IX)->packed, (IX)->gtab, (IX)->range_tab, NR, TP, TM, (IX)->n_docs, (IX)->n_terms, K, MODE, __VA_ARGS__, gm_); \
@@ -1045,11 +1051,16 @@ struct bm25_topk_out {
             hipLaunchKernelGGL(bm25_range_kernel<false>, dim3(gm_.blocks), dim3(BM_THREADS), BM_LDS_BYTES, ST, (IX)->meta, (IX)->doc, (IX)->w, \
                                (IX)->packed, (IX)->gtab, (IX)->range_tab, NR, TP, TM, (IX)->n_docs, (IX)->n_terms, K, MODE, __VA_ARGS__, gm_); \
     }
-static size_t bm25_plan_off_entries(const rag_bm25_index* ix, int Q) { return (size_t)Q * BM_PLAN_T * (ix->n_ranges + 1); }
+static int bm25_pick_plan_t(const rag_ctx* h, const rag_bm25_index* ix, int Q) {
+    if (h->opt.bm25_plan_slots > 0) return std::min(BM_PLAN_T, h->opt.bm25_plan_slots);
+    const size_t per_slot = (size_t)Q * (ix->n_ranges + 1) * sizeof(int32_t);
+    return (int)std::min<size_t>(BM_PLAN_T, std::max<size_t>(8, BM_PLAN_BUDGET / std::max<size_t>(1, per_slot)));
+}
+static size_t bm25_plan_off_entries(const rag_bm25_index* ix, int Q) { return (size_t)Q * ix->plan_t * (ix->n_ranges + 1); }
 static void bm25_launch_plan(const rag_bm25_index* ix, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, const bm25_plan_ws& p,
                              hipStream_t st) {
     hipLaunchKernelGGL(bm25_plan_kernel, dim3((ix->n_ranges + 1 + 255) / 256, Q), dim3(256), 0, st, ix->meta, ix->doc, ix->range_tab,
-                       ix->n_ranges, ix->n_terms, term_ptr_dev, terms_dev, p.off, p.meta);
+                       ix->n_ranges, ix->n_terms, term_ptr_dev, terms_dev, p.off, p.meta, ix->plan_t);
 }
 
 static void bm25_launch_topk(const rag_ctx* h, const rag_bm25_index* ix, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k,
@@ -1263,6 +1274,11 @@ static int bm25_run(rag_ctx* h, rag_bm25_index* ix, const int32_t* term_ptr, con
     const int nr = ix->n_ranges;
     const size_t n_part = mode == 0 ? (size_t)Q * nr * k : 0, n_out = mode == 0 ? (size_t)Q * k : 0;
     const size_t n_dense = mode == 1 ? (size_t)Q * ix->n_docs : 0;
+    {   // plan slots: the batch's longest query (term_ptr is on the host here), within the per-call budget
+        int max_nt = 1;
+        for (int q = 0; q < Q; ++q) max_nt = std::max(max_nt, term_ptr[q + 1] - term_ptr[q]);
+        ix->plan_t = std::min(bm25_pick_plan_t(h, ix, Q), std::min(BM_PLAN_T, max_nt));
+    }
     size_t total = stage_size(Q + 1, 4) + stage_size(std::max(1, n_terms_q), 4) + stage_size(n_part, 8) + stage_size(n_part, 4) +
                    stage_size((size_t)Q * nr, 4) + 2 * stage_size(n_out, 8) + 2 * stage_size(n_out, 4) + 2 * stage_size(Q, 8) +
                    stage_size(n_out, 8) + stage_size(n_dense, 8) + stage_size(bm25_plan_off_entries(ix, Q), 4) +
@@ -1284,7 +1300,7 @@ static int bm25_run(rag_ctx* h, rag_bm25_index* ix, const int32_t* term_ptr, con
     double* scd = stage_take<double>(p, n_out);
     double* dd = stage_take<double>(p, n_dense);
     w.plan.off = stage_take<int32_t>(p, bm25_plan_off_entries(ix, Q));
-    w.plan.meta = stage_take<bm_plan_meta>(p, (size_t)Q * BM_PLAN_T);
+    w.plan.meta = stage_take<bm_plan_meta>(p, (size_t)Q * BM_PLAN_T);       // (sized for the largest plan_t)
     HIP_TRY(h, hipMemcpyAsync(tp, term_ptr, (size_t)(Q + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
     if (n_terms_q) HIP_TRY(h, hipMemcpyAsync(tm, terms, (size_t)n_terms_q * sizeof(int32_t), hipMemcpyHostToDevice, st));
     if (mode == 0) {
@@ -1310,6 +1326,7 @@ static int bm25_run(rag_ctx* h, rag_bm25_index* ix, const int32_t* term_ptr, con
 }
 
 static int bm25_ensure_plan(rag_ctx* h, rag_bm25_index* ix, int Q) {
+    ix->plan_t = bm25_pick_plan_t(h, ix, Q);
     const size_t need = bm25_plan_off_entries(ix, Q);
     if (need > ix->ws_plan_entries) {
         hipFree(ix->ws_plan_off);
@@ -1329,8 +1346,32 @@ static int bm25_ensure_plan(rag_ctx* h, rag_bm25_index* ix, int Q) {
 }
 
 // device-pointer entry: everything stays in HBM, asynchronous on `st` (workspace grows on first use / larger Q)
+static int bm25_topk_dev_batch(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int tenant, int64_t* ids_dev,
+                               int32_t* rows_dev, double* scores_dev, double* raw_max_dev, hipStream_t st);
+
+// The per-call workspace (partial lists [Q][n_ranges][k] x 12 B + the plan) grows with Q x shard size: on a 12.5M-document shard a
+// query takes ~9 MB at k = 100. Batches are therefore run in sub-batches whose workspace stays under BM_WS_BUDGET (queries are
+// independent: same results; the 1M-document bench index runs 1,024 queries in one piece, the 12.5M-document shard 256).
+#define BM_WS_BUDGET ((size_t)6 << 30)
 int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int tenant, int64_t* ids_dev,
                   int32_t* rows_dev, double* scores_dev, double* raw_max_dev, hipStream_t st) {
+    ARG_CHECK(h, h->bm25 != nullptr, "no BM25 index loaded");
+    ARG_CHECK(h, Q > 0 && Q <= 65535 && k > 0, "bm25_topk_dev: bad arguments");
+    const size_t per_query = (size_t)h->bm25->n_ranges * ((size_t)k * 12 + 4 + 8 * 4) + (size_t)k * 12;
+    const size_t budget = h->opt.bm25_ws_mb > 0 ? (size_t)h->opt.bm25_ws_mb << 20 : BM_WS_BUDGET;
+    const int qb = (int)std::max<size_t>(1, std::min<size_t>((size_t)Q, budget / std::max<size_t>(1, per_query)));
+    for (int q0 = 0; q0 < Q; q0 += qb) {
+        const int nq = std::min(qb, Q - q0);
+        const int rc = bm25_topk_dev_batch(h, term_ptr_dev + q0, terms_dev, nq, k, tenant, ids_dev + (size_t)q0 * k,
+                                           rows_dev ? rows_dev + (size_t)q0 * k : nullptr, scores_dev + (size_t)q0 * k,
+                                           raw_max_dev ? raw_max_dev + q0 : nullptr, st);
+        if (rc) return rc;
+    }
+    return RAG_OK;
+}
+
+static int bm25_topk_dev_batch(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int tenant, int64_t* ids_dev,
+                               int32_t* rows_dev, double* scores_dev, double* raw_max_dev, hipStream_t st) {
     ARG_CHECK(h, h->bm25 != nullptr, "no BM25 index loaded");
     ARG_CHECK(h, Q > 0 && Q <= 65535 && term_ptr_dev && ids_dev && scores_dev, "bm25_topk_dev: bad arguments");
     ARG_CHECK(h, k > 0 && k <= BM_MERGE / 2 && k <= BM_RANGE, "bm25: 0 < k <= 1024");

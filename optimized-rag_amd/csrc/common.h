@@ -40,6 +40,8 @@ struct rag_options {
     int bm25_no_staging = 0;      // exact per-range select for every BM25 range
     int bm25_linear_grid = 0;     // scoring workgroups range-major (the ranges of one query side by side) instead of the XCD-aware column order
     int bm25_sort_merge = 0;      // fold the partial lists of a stage by the bitonic-sort kernel (r1-r2) instead of the per-wave selection
+    int bm25_plan_slots = 0;      // planned token slots per query of a BM25 call (0 = sized by the per-call budget, bm25_pick_plan_t); tests force 8
+    int bm25_ws_mb = 0;           // workspace budget of a device-pointer BM25 call in MiB (0 = 6 GiB): batches beyond it run in sub-batches
     int bm25_packed = 0;          // (read when postings are LOADED) 4-byte packed postings + shared impact table instead of (doc, impact)
     int no_fork = 0;              // keep the BM25 leg of a small hybrid batch in line on the caller's stream
     int fork_max_q = 0;           // largest batch whose BM25 leg runs on the side stream beside the dense leg (0 = RAG_FORK_MAX_Q)
@@ -250,3 +252,4 @@ int merge_topk(rag_ctx* h, const int64_t* ids, const double* scores, int n_lists
                int64_t* ids_out, double* scores_out, hipStream_t st, int normalize = 0);
 int pairwise_cosine(rag_ctx* h, const float* a_dev, int m, const float* b_dev, int n, int dim, double* out_dev,
                     hipStream_t st);
+int pairwise_cosine_f64(rag_ctx* h, const double* a_dev, int m, const double* b_dev, int n, int dim, double* out_dev, hipStream_t st);

@@ -1324,7 +1324,8 @@ int merge_topk(rag_ctx* h, const int64_t* ids, const double* scores, int n_lists
                int64_t* ids_out, double* scores_out, hipStream_t st, int normalize) {
     ARG_CHECK(h, n_lists > 0 && Q > 0 && k > 0, "merge: sizes must be positive");
     const size_t lds = (size_t)n_lists * k * 16;
-    ARG_CHECK(h, lds <= 64 * 1024, "merge: n_lists*k too large (max 4096 entries)");
+    // the kernel's static LDS (per-wave maxima of the normalisation, 32 B) comes on top of the dynamic entries: 64 KiB in all
+    ARG_CHECK(h, lds + 64 <= 64 * 1024, "merge: n_lists*k too large (max 4092 entries)");
     ARG_CHECK(h, list_stride >= (int64_t)Q * k, "merge: list_stride < Q*k");
     hipLaunchKernelGGL(merge_topk_kernel, dim3(Q), dim3(256), lds, st, ids, scores, n_lists, list_stride, Q, k, ids_out,
                        scores_out, normalize);
@@ -1335,14 +1336,15 @@ int merge_topk(rag_ctx* h, const int64_t* ids, const double* scores, int n_lists
 // ------------------------------------------------------------------------------------------------
 // K8: small pairwise cosine in float64. One wave per output element block.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pairwise_cosine_kernel(const float* __restrict__ a, int m, const float* __restrict__ b,
+template <class T>     // float (embeddings as stored) or double (the agent's List[float]: no rounding before the float64 arithmetic)
+__global__ __launch_bounds__(256) void pairwise_cosine_kernel(const T* __restrict__ a, int m, const T* __restrict__ b,
                                                                int n, int dim, double* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pair >= (int64_t)m * n) return;
     const int i = (int)(pair / n), j = (int)(pair % n);
-    const float* x = a + (size_t)i * dim;
-    const float* y = b + (size_t)j * dim;
+    const T* x = a + (size_t)i * dim;
+    const T* y = b + (size_t)j * dim;
     double dot = 0.0, nx = 0.0, ny = 0.0;
     for (int t = lane; t < dim; t += 64) {
         const double u = x[t], v = y[t];
@@ -1366,7 +1368,16 @@ int pairwise_cosine(rag_ctx* h, const float* a_dev, int m, const float* b_dev, i
                     hipStream_t st) {
     const int64_t pairs = (int64_t)m * n;
     if (pairs == 0) return RAG_OK;
-    hipLaunchKernelGGL(pairwise_cosine_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, st, a_dev, m, b_dev, n, dim,
+    hipLaunchKernelGGL(pairwise_cosine_kernel<float>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, st, a_dev, m, b_dev, n, dim,
+                       out_dev);
+    HIP_TRY(h, hipGetLastError());
+    return RAG_OK;
+}
+
+int pairwise_cosine_f64(rag_ctx* h, const double* a_dev, int m, const double* b_dev, int n, int dim, double* out_dev, hipStream_t st) {
+    const int64_t pairs = (int64_t)m * n;
+    if (pairs == 0) return RAG_OK;
+    hipLaunchKernelGGL(pairwise_cosine_kernel<double>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, st, a_dev, m, b_dev, n, dim,
                        out_dev);
     HIP_TRY(h, hipGetLastError());
     return RAG_OK;

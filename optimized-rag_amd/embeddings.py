@@ -11,6 +11,7 @@ text-embedding-3-small. An index has to be built and queried with the same servi
 import json
 import os
 import threading
+from collections import OrderedDict
 
 import numpy as np
 
@@ -19,7 +20,8 @@ from .engine import get_engine
 
 
 class LocalEmbeddingService:
-    def __init__(self, cfg, tensors, tokenizer, max_length=256, engine=None, batch_size=2048, normalize=True, model="local-bert-mean-pool"):
+    def __init__(self, cfg, tensors, tokenizer, max_length=256, engine=None, batch_size=2048, normalize=True, model="local-bert-mean-pool",
+                 cache_size=1000):
         self.cfg = cfg
         self.model = model
         self.dimensions = int(cfg["hidden"])
@@ -28,8 +30,23 @@ class LocalEmbeddingService:
         self.max_length = min(int(max_length), cfg["max_pos"], 512)
         self.batch_size = int(batch_size)
         self.engine.embed_load(cfg, tensors, normalize=normalize)
-        self._cache, self._cache_lock = {}, threading.Lock()
+        # LRU cache of `cache_size` texts (the reference: cachetools.LRUCache(maxsize=EMBEDDING_CACHE_SIZE), default 1000 -
+        # memory/embeddings.py:50, config.py:77): ingesting a large corpus must not keep every text in host memory
+        self._cache, self._cache_lock = OrderedDict(), threading.Lock()
+        self._cache_max = max(1, int(cache_size))
         self._cache_hits = self._cache_misses = 0
+
+    def _cache_get(self, text):                      # caller holds the lock
+        hit = self._cache.get(text)
+        if hit is not None:
+            self._cache.move_to_end(text)
+        return hit
+
+    def _cache_put(self, text, emb):                 # caller holds the lock
+        self._cache[text] = emb
+        self._cache.move_to_end(text)
+        while len(self._cache) > self._cache_max:
+            self._cache.popitem(last=False)
 
     @classmethod
     def from_dir(cls, path, max_length=256, engine=None, **kw):
@@ -75,7 +92,7 @@ class LocalEmbeddingService:
             raise ValueError("Text cannot be empty")                              # memory/embeddings.py:75-76
         if use_cache:
             with self._cache_lock:
-                hit = self._cache.get(text)
+                hit = self._cache_get(text)
                 if hit is not None:
                     self._cache_hits += 1
                     return list(hit)
@@ -83,19 +100,22 @@ class LocalEmbeddingService:
         emb = [float(x) for x in self._embed_uncached([text])[0]]
         if use_cache:
             with self._cache_lock:
-                self._cache[text] = tuple(emb)
+                self._cache_put(text, tuple(emb))
         return emb
 
     def generate_embeddings_batch(self, texts, use_cache=True):
-        """List[str] -> List[List[float]] in input order; cached texts are not recomputed (memory/embeddings.py:154-224)."""
+        """List[str] -> List[List[float]] in input order; cached texts are not recomputed; an empty or whitespace-only text gets [] in
+        its slot and touches neither the cache nor its counters (memory/embeddings.py:154-224, :164-168)."""
         if not texts:
             return []
-        out, todo = [None] * len(texts), []
+        out, todo = [[] for _ in texts], []
         for i, t in enumerate(texts):
+            if not t or not t.strip():
+                continue
             hit = None
             if use_cache:
                 with self._cache_lock:
-                    hit = self._cache.get(t)
+                    hit = self._cache_get(t)
                     if hit is not None:
                         self._cache_hits += 1
                     else:
@@ -105,12 +125,12 @@ class LocalEmbeddingService:
             else:
                 todo.append(i)
         if todo:
-            vecs = self._embed_uncached([texts[i] if (texts[i] and texts[i].strip()) else " " for i in todo])
+            vecs = self._embed_uncached([texts[i] for i in todo])
             for i, v in zip(todo, vecs):
                 out[i] = [float(x) for x in v]
                 if use_cache:
                     with self._cache_lock:
-                        self._cache[texts[i]] = tuple(out[i])
+                        self._cache_put(texts[i], tuple(out[i]))
         return out
 
     def get_embedding_dimension(self):
@@ -119,8 +139,9 @@ class LocalEmbeddingService:
     def get_cache_stats(self):
         with self._cache_lock:
             total = self._cache_hits + self._cache_misses
-            rate = 100.0 * self._cache_hits / total if total else 0.0
-            return {"hits": self._cache_hits, "misses": self._cache_misses, "hit_rate_percent": f"{rate:.1f}%", "current_size": len(self._cache)}
+            rate = self._cache_hits / total if total else 0.0
+            return {"hits": self._cache_hits, "misses": self._cache_misses, "hit_rate": rate, "hit_rate_percent": f"{rate * 100:.1f}%",
+                    "current_size": len(self._cache), "max_size": self._cache_max, "cache_full": len(self._cache) >= self._cache_max}
 
     def clear_cache(self):
         with self._cache_lock:

@@ -80,6 +80,19 @@ def test_local_embedding_service_surface_and_index_round_trip(eng, tmp_path):
         assert svc.generate_embedding(texts[7]) == [float(x) for x in vecs[7]] and svc.get_cache_stats()["hits"] >= 1
         with pytest.raises(ValueError):
             svc.generate_embedding("   ")
+        # ADVICE r3, the reference's surface (memory/embeddings.py:164-168, :50, :270-290): an empty item of a batch gets [] in its
+        # slot and counts as neither hit nor miss; the cache is an LRU of max_size entries
+        before = svc.get_cache_stats()
+        mixed = svc.generate_embeddings_batch([texts[0], "", "   ", texts[1]])
+        after = svc.get_cache_stats()
+        assert mixed[1] == [] and mixed[2] == [] and mixed[0] == [float(x) for x in vecs[0]] and mixed[3] == [float(x) for x in vecs[1]]
+        assert after["hits"] - before["hits"] == 2 and after["misses"] == before["misses"]
+        assert after["max_size"] == 1000 and after["current_size"] <= 1000 and "hit_rate" in after and after["cache_full"] is False
+        small = LocalEmbeddingService.from_dir(str(d), engine=e128, cache_size=4)
+        small.generate_embeddings_batch(texts[:10])
+        st = small.get_cache_stats()
+        assert st["current_size"] == 4 and st["max_size"] == 4 and st["cache_full"] is True
+        assert small.generate_embedding(texts[9]) == [float(x) for x in vecs[9]] and small.get_cache_stats()["hits"] == 1   # most recent kept
         ids, tt, lens = svc.tokenize(texts[:4])
         exp = B.sentence_embeddings(w, cfg, ids.astype(np.int64), tt.astype(np.int64), lens)
         assert np.abs(vecs[:4] - exp).max() < 1e-3

@@ -555,6 +555,57 @@ def test_bm25_staged_threshold_path_vs_oracle(eng, k):
         assert mx[qi] == m
 
 
+def test_bm25_bounded_plan_and_sub_batched_device_call(eng):
+    """the per-call plan takes plan_t <= 64 token slots per query sized by a byte budget (tokens past it are searched inside
+    the scoring kernel) and a device-pointer call whose workspace would exceed its budget runs in query sub-batches. Both are
+    forced here on a small index (8 slots against queries of up to 30 tokens; a 1 MiB budget = a handful of queries per sub-batch):
+    rows, scores and maxima must be bit-identical to the default call and to the oracle."""
+    import torch
+    from optimized_rag_amd.bm25 import Bm25Postings
+    rng = np.random.default_rng(404)
+    n_docs = 60_000                                               # 30 doc ranges: staged path
+    lens = rng.poisson(7, n_docs)
+    toks = (rng.zipf(1.25, int(lens.sum())) - 1) % 2500
+    ptr_d = np.concatenate([[0], np.cumsum(lens)])
+    corpus = [" ".join(f"t{t}" for t in toks[ptr_d[i]:ptr_d[i + 1]]) for i in range(n_docs)]
+    post = Bm25Postings.from_corpus(corpus).load(eng)
+    queries = []
+    for n_tok in (1, 3, 8, 9, 17, 30, 5, 12, 30, 2, 64, 70):
+        queries.append(" ".join(f"t{t}" for t in (rng.zipf(1.25, n_tok) - 1) % 2500))
+    queries = queries * 3                                         # 36 queries
+    ptr, terms = post.encode_queries(queries)
+    k = 10
+    ref = eng.bm25_topk(ptr, terms, k)
+    obm = O.BM25Okapi([O.tokenize(c) for c in corpus])
+    for qi in (0, 5, 10, 11):
+        raw = obm.get_scores(O.tokenize(queries[qi]))
+        np.testing.assert_array_equal(ref[1][qi], O.stable_topk_desc(raw, k).astype(np.int32))
+    ptr_t, terms_t = torch.from_numpy(ptr).cuda(), torch.from_numpy(terms).cuda()
+
+    def dev_call():
+        ids = torch.empty((len(queries), k), dtype=torch.int64, device="cuda")
+        rows = torch.empty((len(queries), k), dtype=torch.int32, device="cuda")
+        sc = torch.empty((len(queries), k), dtype=torch.float64, device="cuda")
+        eng.bm25_topk_dev(ptr_t, terms_t, k, ids, rows, sc)
+        torch.cuda.synchronize()
+        return rows.cpu().numpy(), sc.cpu().numpy()
+
+    base = dev_call()
+    np.testing.assert_array_equal(base[0], ref[1])
+    np.testing.assert_array_equal(base[1], ref[2])
+    for opt, val in (("bm25_plan_slots", 8), ("bm25_ws_mb", 1)):
+        eng.set_option(opt, val)
+        try:
+            got = dev_call()
+            host = eng.bm25_topk(ptr, terms, k)
+        finally:
+            eng.set_option(opt, 0)
+        np.testing.assert_array_equal(got[0], ref[1], err_msg=opt)
+        np.testing.assert_array_equal(got[1], ref[2], err_msg=opt)
+        np.testing.assert_array_equal(host[1], ref[1], err_msg=opt)
+        np.testing.assert_array_equal(host[2], ref[2], err_msg=opt)
+
+
 def _sparse_postings(rng, n_docs, n_terms, per_term):
     """Term-major CSR with a few thousand postings per term spread over ALL doc ranges (cheap to build at millions of docs)."""
     from optimized_rag_amd.bm25 import Bm25Postings
