@@ -97,10 +97,19 @@ __device__ __forceinline__ void mx_bdma(__amdgpu_buffer_rsrc_t rs, unsigned voff
 }
 
 #define MX_BAR __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
-// MX_DIAG is defined by tools/ce_mx_probe.hip only (timing experiments with wrong results): 1 = no DMA, 2 = no MFMA, 4 = no weight
-// DMA, 8 = no token DMA. The product build compiles none of it.
-#ifndef MX_DIAG
-#define MX_DIAG 0
+// The three things a K-step does go through these names so that tools/ce_mx_probe.hip can time the loop with one of them taken out
+// (it defines them before including this file; such builds compute wrong results and exist only there). Nothing else overrides them.
+#ifndef MX_ISSUE_W
+#define MX_ISSUE_W(...) mx_bdma(__VA_ARGS__)                  // one 1-KiB piece of the weight image
+#endif
+#ifndef MX_ISSUE_X
+#define MX_ISSUE_X(...) mx_bdma(__VA_ARGS__)                  // one 1-KiB piece of the token image
+#endif
+#ifndef MX_BLOCK
+#define MX_BLOCK(SWAP, ...) mx_block<SWAP>(__VA_ARGS__)       // the three MFMAs of one 32 x 32 block
+#endif
+#ifndef MX_STEP_WAIT
+#define MX_STEP_WAIT "s_waitcnt vmcnt(6)"                     // own pieces of the step have landed (six per wave and step in flight)
 #endif
 
 // The main loop shared by every MX GEMM: a persistent 512-thread workgroup owns tiles of 384 weight rows x 128 tokens and walks K
@@ -132,9 +141,8 @@ struct mx_stream {
 #define MX_PIECE(S, k, st_, ws_, xrs_, ks_)                                                                               \
     {                                                                                                                     \
         const int p_ = (S).wid + 8 * (k);                                                                                 \
-        if (MX_DIAG & 1) {}                                                                                              \
-        else if (p_ < 36) { if (!(MX_DIAG & 4)) mx_bdma((S).w_rs, (S).voff, (ws_) + (ks_) * MX_A_STAGE + p_ * 1024, (st_) + p_ * 1024); } \
-        else if (!(MX_DIAG & 8)) mx_bdma(xrs_, (S).voff, (ks_) * MX_B_STAGE + (p_ - 36) * 1024, (st_) + p_ * 1024);        \
+        if (p_ < 36) { MX_ISSUE_W((S).w_rs, (S).voff, (ws_) + (ks_) * MX_A_STAGE + p_ * 1024, (st_) + p_ * 1024); }         \
+        else { MX_ISSUE_X(xrs_, (S).voff, (ks_) * MX_B_STAGE + (p_ - 36) * 1024, (st_) + p_ * 1024); }                     \
     }
 
 template <bool SWAP>
@@ -143,8 +151,7 @@ __device__ __forceinline__ void mx_ksteps(f32x16 (&acc)[6], const mx_stream& S, 
     for (int t = 0; t < nk; ++t) {
         // own pieces of step t have landed once at most the six of step t+1 are outstanding (a continued tile's steps 0 and 1
         // were waited for before the previous epilogue's stores)
-        if (MX_DIAG & 13) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (first || t > 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (first || t > 0) asm volatile(MX_STEP_WAIT ::: "memory");
         MX_BAR
         const char* st = S.smem + ((S.ring + t) % MX_STAGES) * MX_STAGE;
         // what this step owes the ring: step t+2 of this tile, or step t+2-nk of the next one (a harmless re-load at the very end)
@@ -173,8 +180,7 @@ __device__ __forceinline__ void mx_ksteps(f32x16 (&acc)[6], const mx_stream& S, 
             const mx_v8i w8 = SWAP ? mx_cat(w8h, wl[b & 1]) : mx_cat(wl[b & 1], w8h);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
-            if (MX_DIAG & 2) acc[b][0] += (float)wh0[b & 1][0] + (float)wh1[b & 1][7] + (float)w8[0] + (float)w8[7] + (float)xh0[1] + (float)xh1[2] + (float)x8[3];
-            else mx_block<SWAP>(acc[b], wh0[b & 1], wh1[b & 1], w8, xh0, xh1, x8);
+            MX_BLOCK(SWAP, acc[b], wh0[b & 1], wh1[b & 1], w8, xh0, xh1, x8);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (b + 2 < 6) { MX_READ_A(b + 2, b & 1) }

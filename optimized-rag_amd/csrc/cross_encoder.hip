@@ -255,9 +255,7 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
                 bh[j] = *reinterpret_cast<const half8*>(st + b_base + j * 16 * 128 + off);
                 if (TERMS & 2) bl[j] = *reinterpret_cast<const half8*>(st + b_base + j * 16 * 128 + off_lo);
             }
-#ifndef CE_PROBE_NO_DMA          // timing experiments only (tools/ce_probe_build.sh): results are wrong without the stream
             CE_ISSUE(t + 2)
-#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // step t+1 must have landed before the next I-part. On a continued tile steps 0 and 1 were resident before the
             // loop started (see below), so its first wait is skipped: it would only wait for the previous epilogue's stores.
@@ -265,7 +263,6 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
             if (lag && need_wait) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             CE_BAR
             __builtin_amdgcn_s_setprio(1);
-#ifndef CE_PROBE_NO_MFMA
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -274,9 +271,6 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
                     if (TERMS & 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
-#else
-            acc[0][0][0] += (float)ah[0][0] + (float)bh[0][0] + (float)al[3][7] + (float)bl[3][7];    // keep the reads alive
-#endif
             __builtin_amdgcn_s_setprio(0);
             if (!lag && need_wait) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             CE_BAR
@@ -292,10 +286,6 @@ __global__ __launch_bounds__(512) void ce_gemm_kernel(const half_t* __restrict__
         // outputs are streamed with non-temporal stores: they are read again only by a later kernel (GBs later), and as
         // ordinary stores they pushed the shared token tile and the weights out of the XCD's 4 MiB L2
         char* wl = smem + ((sbase + nt + 2) % 3) * CE_STAGE_BYTES + wid * CE_EPI_WAVE_BYTES;
-#ifdef CE_PROBE_NO_EPI
-        if (acc[0][0][0] == 12345.678f) out32[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];
-        else if (false)
-#endif
         if (EPI == EPI_RESID) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {                       // fp32 [16 tokens][64 features], row stride 272 B
@@ -711,12 +701,7 @@ __global__ __launch_bounds__(512) void ce_ffn_ln_kernel(const half_t* __restrict
     // phase A: this wave's 64 intermediate features (rows of the W1 slice) x 32 tokens; phase B: 192 output features x 32 tokens
     const int a_base_A = wm * 64 * 128, b_base_A = 16384 + wn * 32 * 128;
     const int a_base_B = wm * 192 * 128, b_base_B = wn * 32 * 128;
-#ifdef CE_PROBE_FFN_SHARED_X      // timing experiment only (tools/ce_probe_build.sh): every workgroup streams tile 0's tokens (L2-hot) - results are wrong
-    const __amdgpu_buffer_rsrc_t x0_rs = __builtin_amdgcn_make_buffer_rsrc(stream16, 0, (int)(128 * row_a), 0x00020000);
-#define FFN_XSRC(x) x0_rs
-#else
 #define FFN_XSRC(x) x
-#endif
     // one 8-KiB piece (64 rows x 128 B) at a time, so that the issue cost of a transfer (60-180 cycles per piece per wave) is
     // spread behind the MFMA groups of a step instead of standing in front of them
 #define FFN_PIECE_A(c, t, xrs, k)  /* piece k of step t of chunk c: 0, 1 = W1 slice halves, 2, 3 = token slice halves -> A slot t % 3 */ \
@@ -1484,32 +1469,15 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     const size_t lds = CE_GEMM_LDS;
     if (!attr) {
 #define CE_ATTR(E, T) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_kernel<E, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-#ifdef RAG_CE_ABLATION
-#define CE_ATTR4(E) CE_ATTR(E, 0) CE_ATTR(E, 1) CE_ATTR(E, 2) CE_ATTR(E, 3)
-#else
 #define CE_ATTR4(E) CE_ATTR(E, 3)
-#endif
         CE_ATTR4(EPI_QKV) CE_ATTR4(EPI_GELU) CE_ATTR4(EPI_RESID)
         attr = true;
     }
-    // Correction terms per GEMM site (qkv, out-proj, ffn-up, ffn-down). The product library ships ONLY the full form (both
-    // terms everywhere: profiles/r02_b shows that dropping any one of them spends the whole logit-error budget). The reduced
-    // instances and the RAG_CE_TERMS switch exist only in diagnostic builds (-DRAG_CE_ABLATION, tools/ce_probe_build.sh),
-    // loaded through RAG_HIP_LIB by tools/ce_ablation.py.
+    // Correction terms per GEMM site (qkv, out-proj, ffn-up, ffn-down): the split-fp16 kernels run the full form (both terms
+    // everywhere: profiles/r02_b_ce_term_ablation.md shows that dropping any one of them spends the whole logit-error budget;
+    // the per-site ablation build that produced that table lives in the round-3 history, commit e52b089, not in the product).
     int terms[4] = {3, 3, 3, 3};
-#ifdef RAG_CE_ABLATION
-    if (const char* te = getenv("RAG_CE_TERMS"))
-        for (int i = 0; i < 4 && te[i] >= '0' && te[i] <= '3'; ++i) terms[i] = te[i] - '0';
-#define CE_GEMM(E, T, ...)                                                                                        \
-    switch (T) {                                                                                                  \
-        case 0: hipLaunchKernelGGL((ce_gemm_kernel<E, 0>), dim3(n_cu), blk, lds, st, __VA_ARGS__); break;        \
-        case 1: hipLaunchKernelGGL((ce_gemm_kernel<E, 1>), dim3(n_cu), blk, lds, st, __VA_ARGS__); break;        \
-        case 2: hipLaunchKernelGGL((ce_gemm_kernel<E, 2>), dim3(n_cu), blk, lds, st, __VA_ARGS__); break;        \
-        default: hipLaunchKernelGGL((ce_gemm_kernel<E, 3>), dim3(n_cu), blk, lds, st, __VA_ARGS__); break;       \
-    }
-#else
 #define CE_GEMM(E, T, ...) hipLaunchKernelGGL((ce_gemm_kernel<E, 3>), dim3(n_cu), blk, lds, st, __VA_ARGS__);
-#endif
     (void)terms;
  // bias + residual + LayerNorm in the GEMM epilogue when the geometry allows (hidden = 384, K a multiple of 192: the
     // MiniLM-L-6 shape); RAG_CE_NO_FUSED_LN=1 forces the stand-alone path (parity test of both)
@@ -1530,23 +1498,10 @@ static int ce_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     }
     if (fused_ln && !h->attr_ce_gemm_ln) {
 #define CE_ATTR_LN(T) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ce_gemm_ln_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LNG_LDS));
-#ifdef RAG_CE_ABLATION
-        CE_ATTR_LN(0) CE_ATTR_LN(1) CE_ATTR_LN(2)
-#endif
         CE_ATTR_LN(3)
         h->attr_ce_gemm_ln = true;
     }
-#ifdef RAG_CE_ABLATION
-#define CE_GEMM_LN(T, ...)                                                                                        \
-    switch (T) {                                                                                                  \
-        case 0: hipLaunchKernelGGL((ce_gemm_ln_kernel<0>), dim3(n_cu), blk, LNG_LDS, st, __VA_ARGS__); break;    \
-        case 1: hipLaunchKernelGGL((ce_gemm_ln_kernel<1>), dim3(n_cu), blk, LNG_LDS, st, __VA_ARGS__); break;    \
-        case 2: hipLaunchKernelGGL((ce_gemm_ln_kernel<2>), dim3(n_cu), blk, LNG_LDS, st, __VA_ARGS__); break;    \
-        default: hipLaunchKernelGGL((ce_gemm_ln_kernel<3>), dim3(n_cu), blk, LNG_LDS, st, __VA_ARGS__); break;   \
-    }
-#else
 #define CE_GEMM_LN(T, ...) hipLaunchKernelGGL((ce_gemm_ln_kernel<3>), dim3(n_cu), blk, LNG_LDS, st, __VA_ARGS__);
-#endif
     // the whole FFN in one kernel (ce_ffn_ln_kernel) when the geometry allows; option ce_no_fused_ffn keeps the two-launch form
     // ... from FFN_FUSED_MIN_ROWS padded rows on (tools/ffn_sweep.py, forward ms fused | two-launch: 100 pairs 2.03 | 1.92, 400
     // 6.51 | 5.99, 1600 23.2 | 22.7, 3200 44.8 | 44.6, 6400 88.2 | 88.9): a small batch (one query's 100 pairs = ~140 tiles of 128

@@ -127,40 +127,17 @@ __device__ __forceinline__ void load_fragB(FragB& f, const char* base, const int
         acc[(SA) * 4 + i][(SB) * 2 + j] =                                                                   \
             __builtin_amdgcn_mfma_f32_16x16x32_f16(FA.v[kk][i], FB.v[kk][j], acc[(SA) * 4 + i][(SB) * 2 + j], 0, 0, 0);
 
-// tools/gemm_probe.hip builds this file with DENSE_STAMP to split a phase into I-part / M-part / waits
-// (s_memtime stamps at points where lgkmcnt is already 0; diagnostic build only, never shipped).
-#ifdef DENSE_STAMP
-#define STAMP(IDX)                                                                                          \
-    {                                                                                                       \
-        unsigned long long _t;                                                                              \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                         \
-        stamp_acc[IDX] += _t - stamp_prev;                                                                  \
-        stamp_prev = _t;                                                                                    \
-    }
-#define STAMP_ARG , (unsigned long long*)nullptr
-#else
-#define STAMP(IDX)
-#define STAMP_ARG
-#endif
-
-#ifdef PROBE_NOWAIT      // timing experiment only (tools/gemm_probe.hip): results are wrong without the wait
-#define DMA_WAIT asm volatile("s_waitcnt vmcnt(12)" ::: "memory")
-#else
 #define DMA_WAIT                                                                                            \
     if (SMALLQ) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                           \
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#endif
 #define BARRIER                                                                                             \
     __builtin_amdgcn_s_barrier();                                                                           \
     __builtin_amdgcn_sched_barrier(0);
 // I-part: the caller has just written this phase's fragment reads and its DMA issue. WAIT = 1 on phase 3 only.
 #define I_END(WAIT)                                                                                         \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
-    STAMP(0)                                                                                                \
     if ((WAIT) && lag) { DMA_WAIT }                                                                         \
-    STAMP(1)                                                                                                \
-    BARRIER                                                                                                 \
-    STAMP(2)
+    BARRIER
 #define M_PART(FA0, FB0, SA0, SB0, FA1, FB1, SA1, SB1, WAIT)                                               \
     if (active) {                                                                                           \
         __builtin_amdgcn_s_setprio(1);                                                                      \
@@ -168,12 +145,8 @@ __device__ __forceinline__ void load_fragB(FragB& f, const char* base, const int
         MFMA_QUAD(FA1, FB1, SA1, SB1)                                                                       \
         __builtin_amdgcn_s_setprio(0);                                                                      \
     }                                                                                                       \
-    STAMP(3)                                                                                                \
     if ((WAIT) && !lag) { DMA_WAIT }                                                                        \
-    STAMP(1)                                                                                                \
-    BARRIER                                                                                                 \
-    STAMP(2)
-
+    BARRIER
 // SMALLQ (batches of <= 128 queries, one query tile): the pass is HBM-bound, so the LDS that the unused query half-tile
 // would take buys a THIRD corpus stage instead and the corpus DMA runs three K-steps ahead (queries two, in three
 // half-tile slots): A(t+3) issued in IB(t), B(t+2) in IA(t); the per-step wait is vmcnt(10) = {A(t+2), B(t+2), A(t+3)}
@@ -182,22 +155,15 @@ __device__ __forceinline__ void load_fragB(FragB& f, const char* base, const int
 // FUSED (rag_hybrid_linear_dev): the score that is thresholded and keyed is the weighted LINEAR fusion
 // alpha * cosine + bias[q][row], bias = beta * bm25_normalised + gamma * temporal precomputed per (query, row) in float32
 // (rag/retrieval.py:302); everything downstream (select, float64 rescoring, ranking) is unchanged.
-#ifdef DENSE_STAMP
-#define STAMP_PARAM , unsigned long long* __restrict__ stamp_out
-#define STAMP_PASS , stamp_out
-#else
-#define STAMP_PARAM
-#define STAMP_PASS
-#endif
 #define EMIT_PARAMS                                                                                                   \
     const half_t *__restrict__ corpus16, const half_t *__restrict__ q16, int Dp, int rtile_begin, int n_rtiles, int n_qtiles,  \
         int n_rows_valid, int q_valid, const float *__restrict__ tau, unsigned *__restrict__ cnt, uint64_t *__restrict__ cand, \
         const int32_t *__restrict__ tenants, int tenant, const int32_t *__restrict__ tile_list, int tile_mul, int tile_mod,    \
         int tile_cnt, const int *__restrict__ active_count, const float *__restrict__ bias, int64_t bias_ld, float alpha,      \
-        const int *__restrict__ qmap STAMP_PARAM
+        const int *__restrict__ qmap
 #define EMIT_PASS                                                                                                     \
     corpus16, q16, Dp, rtile_begin, n_rtiles, n_qtiles, n_rows_valid, q_valid, tau, cnt, cand, tenants, tenant, tile_list,    \
-        tile_mul, tile_mod, tile_cnt, active_count, bias, bias_ld, alpha, qmap STAMP_PASS
+        tile_mul, tile_mod, tile_cnt, active_count, bias, bias_ld, alpha, qmap
 // one 256 x 256 tile; vb = the (virtual) block index that selects it
 template <bool DENSE0, bool SMALLQ, bool FUSED>
 __device__ __forceinline__ void dense_emit_tile(const int vb, EMIT_PARAMS) {
@@ -211,9 +177,6 @@ __device__ __forceinline__ void dense_emit_tile(const int vb, EMIT_PARAMS) {
     // their fragment reads and MFMAs (they still issue DMA and meet every barrier), the MFMA time per K-step halves and
     // the small-batch case becomes purely HBM-bound.
     const int wm = wid & 1, wn = ((wid >> 1) & 1) + 2 * (wid >> 2);
-#ifdef DENSE_STAMP
-    unsigned long long stamp_acc[4] = {0ull, 0ull, 0ull, 0ull}, stamp_prev = 0ull;
-#endif
 
     // second-pass launches (re-emission for queries whose buffer overflowed) cover the whole corpus but usually have
     // nothing to do: the device-side count of such queries decides, no host round trip
@@ -288,9 +251,6 @@ __device__ __forceinline__ void dense_emit_tile(const int vb, EMIT_PARAMS) {
     BARRIER
     FragA ax, ay;
     FragB bx, by;
-#ifdef DENSE_STAMP
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
-#endif
     if (lag) { BARRIER }
 
     for (int t = 0; t < nt; ++t) {
@@ -305,10 +265,6 @@ __device__ __forceinline__ void dense_emit_tile(const int vb, EMIT_PARAMS) {
     }
     if (!lag) { BARRIER }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // clamped tail re-loads still in flight: retire them
-#ifdef DENSE_STAMP
-    if (lane == 0 && stamp_out)
-        for (int i = 0; i < 4; ++i) stamp_out[((size_t)vb * 8 + wid) * 4 + i] = stamp_acc[i];
-#endif
 
     // ---- epilogue: C layout col = lane&15 (query), row = (lane>>4)*4 + reg (corpus row) ----------
     const float scale = 1.0f / (float)(1 << (2 * RAG_SCALE_LOG2));
@@ -1155,7 +1111,7 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
         }
 #define EMIT_ARGS(QP, NQT, QV, TAU, CNT, CAND, ACT, QMAP)                                                        \
     h->emb16, QP, h->dim_pad, begin_, n_rt_, NQT, (int)h->n_rows, QV, TAU, CNT, CAND, tenants, tenant, tile_list, tile_mul, tile_mod, \
-        n_tiles, (const int*)(ACT), bias, bias_ld, alpha_f, (const int*)(QMAP) STAMP_ARG
+        n_tiles, (const int*)(ACT), bias, bias_ld, alpha_f, (const int*)(QMAP)
         const int begin_ = begin, n_rt_ = n_rt;
         if (stage == 0 && fz)
             hipLaunchKernelGGL((dense_emit_kernel<true, false, true>), dim3(grid), dim3(512), DENSE_LDS_BYTES, st,

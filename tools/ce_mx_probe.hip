@@ -4,6 +4,23 @@
 // Checks (a) the kernel against a float64 emulation of ITS OWN arithmetic (hi.hi + 2^-11 (lo8.hi8 + hi8.lo8) on the rounded
 // operands: validates the layout, the lane maps of both MFMA forms and the K-slot pairing) and (b) against the exact W.X^T (what
 // the scheme is worth), then times the launch with a store-nothing epilogue and with the image-layout epilogue.
+// timing experiments (WRONG results; -DMX_DIAG=<bits>): 1 = no DMA, 2 = no MFMA, 4 = no weight DMA, 8 = no token DMA
+#ifndef MX_DIAG
+#define MX_DIAG 0
+#endif
+#if MX_DIAG & 5
+#define MX_ISSUE_W(...)
+#endif
+#if MX_DIAG & 9
+#define MX_ISSUE_X(...)
+#endif
+#if MX_DIAG & 2
+#define MX_BLOCK(SWAP, acc, wh0, wh1, w8, xh0, xh1, x8) \
+    acc[0] += (float)(wh0)[0] + (float)(wh1)[7] + (float)(w8)[0] + (float)(w8)[7] + (float)(xh0)[1] + (float)(xh1)[2] + (float)(x8)[3]
+#endif
+#if MX_DIAG & 13
+#define MX_STEP_WAIT "s_waitcnt vmcnt(0)"
+#endif
 #include "../optimized-rag_amd/csrc/ce_mx.h"
 
 #include <algorithm>

@@ -1,6 +1,6 @@
 // Diagnostic harness (NOT product): runs dense_emit_kernel<false> alone on random fp16 operands with tau = +inf
-// (nothing is emitted), times it with HIP events and prints the per-phase s_memtime split of the DENSE_STAMP build.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DDENSE_STAMP] tools/gemm_probe.hip -o gpurun_out/gemm_probe
+// (nothing is emitted), times it with HIP events.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/gemm_probe.hip -o gpurun_out/gemm_probe
 #include "../optimized-rag_amd/csrc/dense.hip"
 
 #include <cstdio>
@@ -37,14 +37,7 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_emit_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                            DENSE_LDS_BYTES));
     const int grid = (int)round_up(n_rt, 8) * n_qt;
-#ifdef DENSE_STAMP
-    unsigned long long* st;
-    CK(hipMalloc(&st, (size_t)grid * 8 * 4 * 8));
-    CK(hipMemset(st, 0, (size_t)grid * 8 * 4 * 8));
-#define EXTRA , st
-#else
 #define EXTRA
-#endif
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -94,19 +87,5 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(hc0, cnt, 16, hipMemcpyDeviceToHost));
     printf("N=%d Q=%d tau=%.4f  best %.3f ms  %.1f TFLOP/s  (%d WGs)  emitted/query ~ %u %u %u\n", N, Q, tau_v, best, tf, n_rt * n_qt,
            hc0[0], hc0[1], hc0[2]);
-#ifdef DENSE_STAMP
-    std::vector<unsigned long long> hs((size_t)grid * 8 * 4);
-    CK(hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost));
-    double s[4] = {0, 0, 0, 0};
-    size_t n = 0;
-    for (size_t w = 0; w < (size_t)grid * 8; ++w) {
-        if (hs[w * 4] == 0) continue;
-        for (int i = 0; i < 4; ++i) s[i] += (double)hs[w * 4 + i];
-        ++n;
-    }
-    const double phases = (double)(D / 64) * 4;
-    printf("per phase (s_memtime ticks, mean over %zu waves): I-part %.0f | M-part %.0f | vmcnt wait %.0f | barriers %.0f | total %.0f\n", n,
-           s[0] / n / phases, s[3] / n / phases, s[1] / n / phases, s[2] / n / phases, (s[0] + s[1] + s[2] + s[3]) / n / phases);
-#endif
     return 0;
 }
