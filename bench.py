@@ -106,6 +106,39 @@ def gen_queries(Q, total_rows, n_chunks, chunk_rows, device, kind="iid"):
     return (q / q.norm(dim=1, keepdim=True)).contiguous(), rows
 
 
+def choose_exchange(eng, rank, world, device, backend, torch_comm=False):
+    """Which gather the sharded classes use, decided COLLECTIVELY: RCCL behind the C-ABI (rag_comm_allgather_dev) when every rank
+    could create its communicator, torch.distributed otherwise. The 128-byte id travels through the process group that launched
+    the ranks; a failure on ANY rank (librccl not loadable, ncclCommInitRank failing) sends ALL of them to the torch path - a
+    rank that did succeed destroys its communicator again, so no rank is left alone inside a collective. Returns the label the
+    bench line reports as `config.exchange` (tests/test_bench_launcher.py drives this with a failing rank on gloo)."""
+    if world <= 1:
+        return "single process"
+    label = "torch.distributed (%s)" % backend
+    if backend != "nccl" or torch_comm:
+        return label
+    ok = 1
+    try:
+        uid = [eng.comm_unique_id() if rank == 0 else None]
+    except Exception:
+        uid, ok = [None], 0
+    dist.broadcast_object_list(uid, src=0)
+    try:
+        if uid[0] is not None and ok:
+            eng.comm_init(rank, world, uid[0])
+        else:
+            ok = 0
+    except Exception:
+        ok = 0
+    flag = torch.tensor([ok], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return "rag_comm_allgather_dev (RCCL behind the C-ABI)"
+    if ok:
+        eng.comm_destroy()
+    return label
+
+
 def launcher_command(n_gpus, port, argv):
     """The command the driver itself uses for N > 1 (one rank per GPU, rendezvous on 127.0.0.1)."""
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
@@ -229,31 +262,7 @@ def main():
     torch.cuda.empty_cache()
 
     from optimized_rag_amd.sharded import ShardedDenseIndex
-    comm = "single process"
-    if world > 1:
-        comm = "torch.distributed (%s)" % backend
-        if backend == "nccl" and not args.torch_comm:
-            # RCCL behind the C-ABI: the 128-byte id travels through the process group that launched the ranks. Every rank must
-            # agree on the path, so a failure anywhere (librccl not loadable) sends all of them back to torch.distributed.
-            ok = 1
-            try:
-                uid = [eng.comm_unique_id() if rank == 0 else None]
-            except Exception:
-                uid, ok = [None], 0
-            dist.broadcast_object_list(uid, src=0)
-            try:
-                if uid[0] is not None and ok:
-                    eng.comm_init(rank, world, uid[0])
-                else:
-                    ok = 0
-            except Exception:
-                ok = 0
-            flag = torch.tensor([ok], device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                comm = "rag_comm_allgather_dev (RCCL behind the C-ABI)"
-            elif ok:
-                eng.comm_destroy()
+    comm = choose_exchange(eng, rank, world, device, backend, args.torch_comm)
     index = ShardedDenseIndex(eng, rank=rank, world=world)
 
     def step():

@@ -39,3 +39,66 @@ def test_launched_rank_does_not_relaunch():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+
+
+_EXCHANGE_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+import bench
+
+class FakeEngine:
+    # the C-ABI's communicator calls, as far as choose_exchange uses them; rank FAIL_RANK cannot create its communicator
+    def __init__(self, rank, fail_rank):
+        self.rank, self.fail_rank, self.inited, self.destroyed = rank, fail_rank, False, False
+    def comm_unique_id(self):
+        return b"u" * 128
+    def comm_init(self, rank, world, uid):
+        assert uid == b"u" * 128
+        if rank == self.fail_rank:
+            raise RuntimeError("ncclCommInitRank failed")
+        self.inited = True
+    def comm_destroy(self):
+        self.destroyed = True
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+out = {}
+for name, fail in (("one_rank_fails", 1), ("all_ok", -1)):
+    e = FakeEngine(rank, fail)
+    # backend label "nccl": the decision logic of the real runs; the collectives themselves run on this gloo group
+    out[name] = dict(label=bench.choose_exchange(e, rank, world, torch.device("cpu"), "nccl"), inited=e.inited, destroyed=e.destroyed)
+out["torch_comm"] = bench.choose_exchange(FakeEngine(rank, -1), rank, world, torch.device("cpu"), "nccl", torch_comm=True)
+print("RANK%d %s" % (rank, json.dumps(out)), flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_one_rank_failing_comm_init_sends_every_rank_to_the_torch_path(tmp_path):
+    """the exchange is chosen collectively. Two gloo ranks drive bench.choose_exchange with a stand-in for the engine's
+    communicator calls: when rank 1 cannot create its communicator BOTH ranks report the torch path and rank 0 destroys the
+    communicator it had created; when every rank succeeds both report RCCL behind the C-ABI; --torch-comm never tries."""
+    import socket
+    script = tmp_path / "worker.py"
+    script.write_text(_EXCHANGE_WORKER)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = {}
+    for ln in p.stdout.splitlines():
+        if ln.startswith("RANK"):
+            res[int(ln[4])] = json.loads(ln[6:])
+    assert set(res) == {0, 1}
+    for r in (0, 1):
+        assert res[r]["one_rank_fails"]["label"] == "torch.distributed (nccl)"
+        assert res[r]["all_ok"]["label"].startswith("rag_comm_allgather_dev") and res[r]["all_ok"]["inited"] and not res[r]["all_ok"]["destroyed"]
+        assert res[r]["torch_comm"] == "torch.distributed (nccl)"
+    assert res[0]["one_rank_fails"]["inited"] and res[0]["one_rank_fails"]["destroyed"]        # the rank that succeeded backs out
+    assert not res[1]["one_rank_fails"]["inited"] and not res[1]["one_rank_fails"]["destroyed"]
