@@ -560,7 +560,8 @@ def test_cross_encoder_other_hidden_sizes_take_the_unfused_path(seed, hidden, ff
 
 def test_cross_encoder_unfused_layernorm_path_at_hidden_384(monkeypatch):
     """Option ce_no_fused_ln sends the MiniLM shape through the residual GEMM + stand-alone LayerNorm kernels: same logits as
-    the fused path to rounding, both within 4e-3 of the float64 forward."""
+    the fused path to rounding, both within 4e-3 of the float64 forward. These are variants of the SPLIT-FP16 forward (ce_mx = -1:
+    since round 4 the MX kernels run this shape by default, tests/test_cross_encoder_gpu.py covers both)."""
     from oracle import bert_oracle as B
     from optimized_rag_amd.cross_encoder import flatten_state_dict
     cfg = dict(vocab_size=3000, hidden=384, layers=2, heads=12, ffn=1536, max_pos=128, type_vocab=2, eps=1e-12)
@@ -574,21 +575,26 @@ def test_cross_encoder_unfused_layernorm_path_at_hidden_384(monkeypatch):
     ids = rng.integers(5, cfg["vocab_size"], (P, L)).astype(np.int32)
     ids[np.arange(L)[None, :] >= lens[:, None]] = 0
     tt = ((np.arange(L)[None, :] >= 9) & (np.arange(L)[None, :] < lens[:, None])).astype(np.int32)
+    eng.set_option("ce_mx", -1)
     eng.set_option("ce_no_fused_ln", -1)                     # -1: fused whatever the batch size (0 = by size, see LN_UNFUSED_MAX_ROWS)
     try:
         fused = eng.ce_score(ids, tt, lens)
         fused_small = eng.ce_score(ids[:40], tt[:40], lens[:40])
         eng.set_option("ce_no_fused_ln", 1)
         plain = eng.ce_score(ids, tt, lens)
+        eng.set_option("ce_no_fused_ln", 0)
+        auto_small = eng.ce_score(ids[:40], tt[:40], lens[:40])     # 40 x 128 rows: the size rule picks the unfused sites
     finally:
         eng.set_option("ce_no_fused_ln", 0)
-    auto_small = eng.ce_score(ids[:40], tt[:40], lens[:40])     # 40 x 128 rows: the size rule picks the unfused sites
+        eng.set_option("ce_mx", 0)
+    mx = eng.ce_score(ids, tt, lens)                                # the default forward of this shape and size
+    assert np.abs(mx - plain).max() < 8e-3 and np.abs(mx - plain).max() > 0
     np.testing.assert_array_equal(auto_small, plain[:40])
     assert np.abs(fused_small - plain[:40]).max() < 1e-3
     assert np.abs(fused - plain).max() < 1e-3
     sel = [0, 1, 150, 299]
     exp = B.forward_logits(w, cfg, ids[sel].astype(np.int64), tt[sel].astype(np.int64), lens[sel], fast_erf=True)
-    assert np.abs(plain[sel] - exp).max() < 4e-3 and np.abs(fused[sel] - exp).max() < 4e-3
+    assert np.abs(plain[sel] - exp).max() < 4e-3 and np.abs(fused[sel] - exp).max() < 4e-3 and np.abs(mx[sel] - exp).max() < 4e-3
 
 
 @settings(**{**COMMON, "max_examples": max(8, N_EX // 25)})
