@@ -370,6 +370,36 @@ def _p50_ms(fn, n, warm):
     return float(np.median(lat))
 
 
+PEAK_L2_GBS = 34500.0            # aggregate L2 bandwidth, MI355X_MICROARCH.md (L2 per XCD)
+
+
+def bm25_roofline(call_ms, algorithmic_bytes, bench_shape):
+    """The three roofs of the BM25 top-100 leg (see the comment in hybrid_block). Counter figures come from the committed profile of
+    the same command (they cannot be collected inside the timed run): the newest of profiles/r04_bm25_pmc.json, r03_bm25_pmc.json."""
+    traffic, valu, src = None, None, None
+    if bench_shape:
+        for name in ("r04_bm25_pmc.json", "r03_bm25_pmc.json"):
+            t = _profile_number(name, ("per_call", "hbm_traffic_bytes"))
+            if t is not None:
+                traffic, src = t, name
+                valu = _profile_number(name, ("sq_counters_range_kernel", "valu_busy_per_simd"))
+                break
+    l2_gbs = algorithmic_bytes / (call_ms * 1e-3) / 1e9
+    hbm_gbs = None if traffic is None else traffic / (call_ms * 1e-3) / 1e9
+    return {"bound": "issue", "kernel": "bm25_plan_kernel + bm25_range_kernel + bm25_merge_select_kernel (BM25 top-100 of one batch)",
+            "achieved": None if valu is None else round(valu, 4), "peak": 1.0, "unit": "vector-ALU busy share per SIMD (bm25_range_kernel)",
+            "frac": None if valu is None else round(valu, 4),
+            "hbm": {"achieved": None if hbm_gbs is None else round(hbm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": None if hbm_gbs is None else round(hbm_gbs / PEAK_HBM_GBS, 4), "bytes": "counter: left L2 per call"},
+            "l2": {"achieved": round(l2_gbs, 1), "peak": PEAK_L2_GBS, "unit": "GB/s", "frac": round(l2_gbs / PEAK_L2_GBS, 4),
+                   "bytes": "algorithmic: postings of the batch's query terms x 12 B"},
+            "traffic": traffic, "traffic_source": None if src is None else f"profiles/{src} (bytes leaving L2 per 1024-query batch)",
+            "avg_call_ms": round(call_ms, 4), "algorithmic_bytes_per_call": algorithmic_bytes,
+            "note": "the posting stream is served by the L2s (hit rate 0.95): neither byte roof binds (HBM and L2 fractions above); the "
+                    "scoring kernel is bound by instruction issue - `frac` is its vector-ALU busy share, with the scalar ALU at 0.59 and "
+                    "waves parked 48 % of their lifetime beside it (profiles/r03_bm25_pmc.json)"}
+
+
 def hybrid_block(eng, q, N, cpu_baseline=True):
     """BASELINE.json configs[2]: dense top-100 + BM25(CSR) top-100 + RRF(k=60) -> top-20, one rag_hybrid_rrf_dev call per
     batch. Loads the postings into `eng` (they stay resident for the retrieve_rerank block). Returns (block, state)."""
@@ -404,7 +434,6 @@ def hybrid_block(eng, q, N, cpu_baseline=True):
     eng.set_profiling(False)
     counts = np.diff(indptr)
     nnz_touched = float(counts[terms[terms >= 0]].sum())
-    bm_gbs = nnz_touched * 12.0 / (bm_ms / bm_spans * 1e-3) / 1e9
     p50_1 = _p50_ms(lambda: hybrid(1), 100, 10)
     # the reference's OTHER fusion (rag/retrieval.py:294-322: weighted linear sum over every document), index-level
     t_lin = timed(lambda: eng.hybrid_linear_dev(q[:256], ptr_d[:257], terms_d, k, 0.55, 0.35, 0.10), 3, 1)
@@ -414,20 +443,14 @@ def hybrid_block(eng, q, N, cpu_baseline=True):
         "value": round(Q / t_1024, 1), "unit": "queries/sec", "batch_queries": Q, "ms_per_batch": round(t_1024 * 1e3, 3),
         "queries_per_sec_batch256": round(256 / t_256, 1), "p50_single_query_latency_ms": round(p50_1, 4),
         "linear_fusion_queries_per_sec_batch256": round(256 / t_lin, 1),
-        # BM25 is a gather over postings, priced against the HBM roof as SURVEY 8d asks: `achieved` = algorithmic bytes (postings of the
-        # batch's query terms x 12 B) / device time of the BM25 launches (HIP events). It EXCEEDS what HBM delivers: the queries of a
-        # batch share their frequent terms and the XCD-aware workgroup order lets each XCD's L2 serve a range's postings to all of
-        # them. `traffic` = the bytes that actually left L2 per batch (FETCH_SIZE x 2 + WRITE_SIZE of the plan / range / merge launches,
-        # rocprofv3 --pmc passes of `bench.py --mode hybrid --only-hybrid-calls`, profiles/r03_bm25_pmc.json).
-        "roofline": {"bound": "hbm", "kernel": "bm25_plan_kernel + bm25_range_kernel + bm25_merge_select_kernel (BM25 top-100 of one batch)",
-                     "achieved": round(bm_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(bm_gbs / PEAK_HBM_GBS, 4),
-                     "traffic": _profile_number("r03_bm25_pmc.json", ("per_call", "hbm_traffic_bytes")) if (N == 1_000_000 and Q == 1024) else None,
-                     "traffic_source": "profiles/r03_bm25_pmc.json (bytes leaving L2 per 1024-query batch; L2 hit rate 0.95)",
-                     "avg_call_ms": round(bm_ms / bm_spans, 4), "algorithmic_bytes_per_call": nnz_touched * 12.0,
-                     "note": "frac > 1: 95 % of the posting requests hit L2 (the batch shares its frequent terms; each XCD scores one "
-                             "2048-document range for a column of queries at a time), so 1.5 GB leave L2 per batch against 27 GB algorithmic "
-                             "and the HBM roof no longer binds. The scoring kernel is bound by instruction issue: vector ALU 66 %, scalar ALU "
-                             "59 % busy per SIMD, waves parked 48 % of their lifetime (SQ counters in profiles/r03_bm25_pmc.json)"},
+        # BM25 is a gather over postings. SURVEY 8d prices it as algorithmic bytes (postings of the batch's query terms x 12 B) against
+        # the HBM roof - but the queries of a batch share their frequent terms and the XCD-aware workgroup order lets each XCD's L2
+        # serve a range's postings to a whole column of queries, so that quotient exceeds 1 (r3 reported frac 1.23) and binds nothing.
+        # Reported instead, each against the roof it belongs to: (1) HBM: the bytes that actually LEFT L2 per batch (rocprofv3 --pmc
+        # passes of `bench.py --mode hybrid --only-hybrid-calls`: FETCH_SIZE x 2 + WRITE_SIZE of the plan / range / merge launches)
+        # over the measured device time; (2) L2: the algorithmic bytes over 34.5 TB/s (MI355X_MICROARCH.md, L2 section) - the roof
+        # the posting stream is served from; (3) instruction issue: vector-ALU busy share of the scoring kernel (SQ counters).
+        "roofline": bm25_roofline(bm_ms / bm_spans, nnz_touched * 12.0, N == 1_000_000 and Q == 1024),
         "index_build_s": round(build_s, 1),
     }
     if cpu_baseline:
