@@ -5,8 +5,9 @@ top-100 (exact rescoring of a float32 shortlist), CSR BM25Okapi top-100, RRF ran
 'longest_first' pair assembly, float64 BERT forward, sigmoid, stable sort (scores <= 1e-3, logits <= 4e-3).
 Reference path: /root/reference/rag/document_store.py:448-460, rag/retrieval.py:324-347, rag/reranker.py:224-271,346-359.
 
-The default suite runs it at 250,000 rows (same code path, seconds). RAG_TEST_SHARD_ROWS=12500000 selects the real share
-(115 GB of embeddings, ~1.2e9 postings; several minutes - tools/r3_shard.sh runs it and keeps the lines in profiles/)."""
+Since round 4 the default suite runs it at the REAL size (12,500,000 rows = 115 GB of embeddings, ~1.07e9 postings, the
+share's own 12.5M passages: ~160 GB of HBM, about half a minute on an MI355X); RAG_TEST_SHARD_ROWS=250000 is the quick form of the same
+code path for development boxes."""
 import os
 
 import numpy as np
@@ -14,7 +15,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-ROWS = int(os.environ.get("RAG_TEST_SHARD_ROWS", "250000"))
+ROWS = int(os.environ.get("RAG_TEST_SHARD_ROWS", "12500000"))
 
 
 def test_per_gpu_share_hybrid_and_rerank_vs_oracle_composition():
