@@ -382,6 +382,22 @@ __global__ __launch_bounds__(256) void mx_embed_ln_kernel(const int32_t* __restr
     *reinterpret_cast<unsigned*>(img + (4 + h) * MX_B_PLANE + trow * 16 + 8 + j * 4) = l1;
 }
 
+// Row pair_off[p] of one or two (b may be null) image-layout tensors with nk K-steps -> row p of their compact counterparts (one row per pair); also
+// publishes the compact row count. One thread per (pair, 16-B chunk): a row is nk x 6 chunks.
+__global__ void mx_gather_rows_kernel(const char* __restrict__ a, const char* __restrict__ b, const int32_t* __restrict__ pair_off, int P, int nk,
+                                      char* __restrict__ a_out, char* __restrict__ b_out, int32_t* __restrict__ rows_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) rows_out[0] = P;
+    const int per = nk * 6;
+    if (i >= (int64_t)P * per) return;
+    const int p = (int)(i / per), c = (int)(i % per), s = c / 6, pl = c % 6;
+    const int64_t m = pair_off[p];
+    const size_t src = ((size_t)(m >> 7) * nk + s) * MX_B_STAGE + (size_t)pl * MX_B_PLANE + (size_t)(m & 127) * 16;
+    const size_t dst = ((size_t)(p >> 7) * nk + s) * MX_B_STAGE + (size_t)pl * MX_B_PLANE + (size_t)(p & 127) * 16;
+    *reinterpret_cast<mx_u4*>(a_out + dst) = *reinterpret_cast<const mx_u4*>(a + src);
+    if (b != nullptr) *reinterpret_cast<mx_u4*>(b_out + dst) = *reinterpret_cast<const mx_u4*>(b + src);
+}
+
 // value of (token row m, feature k) of an image-layout activation tensor
 __device__ __forceinline__ float mx_load_elem(const char* __restrict__ x8, int64_t m, int k, int nk) {
     const char* img = x8 + mx_img_base(m, k, nk);
@@ -392,19 +408,29 @@ __device__ __forceinline__ float mx_load_elem(const char* __restrict__ x8, int64
 
 // ---- QKV projection: feature tile 0 = Q, 1 = K (MFMA fragment order of the attention kernel, split fp16), 2 = V (computed with
 // swapped operands so that a lane holds 4 consecutive KEYS of one dim: the V fragment order)
+// ft_base: the launch's feature tile 0 is tile ft_base of the QKV matrix (the last layer of a classifier projects K and V for every
+// token, ft_base = 1, and Q for the [CLS] rows alone). row_map (Q of compact rows only): token row of compact row p.
 struct mx_epi_qkv {
     half_t *qf16, *kf16, *vf16;
     size_t kv_plane;
     const float* bias;
     int m_tiles16;                 // 16-row tiles of the padded row space
-    __device__ __forceinline__ bool swap_for(int ft) const { return ft == 2; }
-    __device__ __forceinline__ void operator()(f32x16 (&acc)[6], int tt, int ft, bool swap, char*) const {
+    int ft_base;
+    const int32_t* row_map;
+    int n_map;
+    __device__ __forceinline__ bool swap_for(int ft) const { return ft + ft_base == 2; }
+    __device__ __forceinline__ void operator()(f32x16 (&acc)[6], int tt, int ft_launch, bool swap, char*) const {
+        const int ft = ft_launch + ft_base;
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wm = wid >> 2, wn = wid & 3;
         const int li = lane & 31, hh = lane >> 5;
         const int m0 = tt * MX_TN + wn * 32;                       // first token row of the wave
         if (!swap) {
             half_t* dst = ft == 0 ? qf16 : kf16;
-            const int m = m0 + li;
+            int m = m0 + li;
+            if (row_map != nullptr) {
+                if (m >= n_map) return;
+                m = row_map[m];
+            }
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
                 const int head = wm * 6 + b;

@@ -50,6 +50,7 @@ struct rag_ce_model {
     };
     std::vector<Layer> layers;
     float *wp = nullptr, *bp = nullptr, *wc = nullptr, *bc = nullptr;            // pooler / classifier fp32
+    float* wpT = nullptr;                                                         // pooler matrix transposed (mx_pool_classify_kernel)
     std::vector<void*> allocs;
     // activation workspace (sized for ws_tokens)
     int64_t ws_tokens = 0;
@@ -71,6 +72,8 @@ struct rag_ce_model {
         int pairs = 0, L = 0;
         int64_t tokens = 0;                            // padded rows (a multiple of 256)
         char *x8 = nullptr, *ctx8 = nullptr, *h8 = nullptr;              // residual stream, attention output, FFN intermediate (image layout)
+        char *xc8 = nullptr, *cc8 = nullptr, *hc8 = nullptr;             // the same three for ONE row per pair: the [CLS] rows through the last layer's tail
+        int32_t* m_cls = nullptr;                                        // device scalar: rows of the compact tensors (= pairs of the chunk)
         half_t *qf16 = nullptr, *kf16 = nullptr, *vf16 = nullptr;       // Q, K, V in the attention kernel's fragment order (hi | lo planes)
         int32_t *ids = nullptr, *tt = nullptr, *lens = nullptr, *pair_off = nullptr, *row_pair = nullptr, *m_packed = nullptr;
         int32_t *sid = nullptr, *stt = nullptr;
@@ -1060,12 +1063,14 @@ __device__ __forceinline__ void ce_dma_at(const half_t* __restrict__ g, char* ld
 
 // MX = true (the hi16 + lo8 forward, ce_mx.h): Q arrives in the same fragment order as K (q16 = qf16[head][16-row tile][lane][8], lo
 // plane kv_plane further) and the context leaves in the image layout of the out-projection's token operand (ctx16 = ctx8 bytes).
-template <int QB, bool MX = false>
+// DIRECT (the [CLS]-only last layer: one 16-query block per pair): ONE wave per (head, pair) reads the K / V fragment tiles straight
+// from global memory - every tile is used by that one wave, so staging it in LDS only costs a 64-KiB allocation per workgroup.
+template <int QB, bool MX = false, bool DIRECT = false>
 __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __restrict__ q16,
                                                              const half_t* __restrict__ kf16, const half_t* __restrict__ vf16,
                                                              size_t kv_plane, const int32_t* __restrict__ lens,
                                                              const int32_t* __restrict__ pair_off, int L, int hidden,
-                                                             int heads, int m_pad, half_t* __restrict__ ctx16) {
+                                                             int heads, int m_pad, half_t* __restrict__ ctx16, int max_qblocks = 1 << 20) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
@@ -1076,22 +1081,30 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
     const int nt = Lp >> 4;                                           // the pair's 16-row tiles; an odd count leaves the second
     const int nkb = (len + 31) >> 5;                                  // half of the last 32-key block outside the pair (masked)
     const size_t plane_b = (size_t)L * 64;                            // bytes of one K (or V) plane of this (pair, head)
-    char* const k_hi = smem;
-    char* const k_lo = smem + plane_b;
-    char* const v_hi = smem + 2 * plane_b;
-    char* const v_lo = smem + 3 * plane_b;
-    {
+    const size_t t0 = ((size_t)head * (m_pad >> 4) + (po >> 4)) * 512;                      // first tile of this (head, pair), in halfs
+    // fragment reads below address tile c of a plane at byte c * 1024 + (lane's offset): the same bytes in LDS and in global memory
+    const char* const k_hi = DIRECT ? reinterpret_cast<const char*>(kf16 + t0) : smem;
+    const char* const k_lo = DIRECT ? reinterpret_cast<const char*>(kf16 + t0 + kv_plane) : smem + plane_b;
+    const char* const v_hi = DIRECT ? reinterpret_cast<const char*>(vf16 + t0) : smem + 2 * plane_b;
+    const char* const v_lo = DIRECT ? reinterpret_cast<const char*>(vf16 + t0 + kv_plane) : smem + 3 * plane_b;
+    if (!DIRECT) {
+        char* const sk_hi = smem;
+        char* const sk_lo = smem + plane_b;
+        char* const sv_hi = smem + 2 * plane_b;
+        char* const sv_lo = smem + 3 * plane_b;
         const size_t g0 = (((size_t)head * (m_pad >> 4) + (po >> 4)) * 64 + lane) * 8;   // K and V tiles are both 1 KiB per plane
         for (int c = wv; c < nt; c += nwaves) {
-            ce_dma_at(kf16 + g0 + (size_t)c * 512, k_hi + c * 1024);
-            ce_dma_at(kf16 + g0 + kv_plane + (size_t)c * 512, k_lo + c * 1024);
-            ce_dma_at(vf16 + g0 + (size_t)c * 512, v_hi + c * 1024);
-            ce_dma_at(vf16 + g0 + kv_plane + (size_t)c * 512, v_lo + c * 1024);
+            ce_dma_at(kf16 + g0 + (size_t)c * 512, sk_hi + c * 1024);
+            ce_dma_at(kf16 + g0 + kv_plane + (size_t)c * 512, sk_lo + c * 1024);
+            ce_dma_at(vf16 + g0 + (size_t)c * 512, sv_hi + c * 1024);
+            ce_dma_at(vf16 + g0 + kv_plane + (size_t)c * 512, sv_lo + c * 1024);
         }
     }
     const size_t row0 = (size_t)po;
     const int qb0 = wv * QB;
-    const bool has_rows = qb0 * 16 < Lp;                              // waves past the pair's rows only helped with the DMA
+    // max_qblocks: only the first max_qblocks 16-query blocks of a pair are computed (the last layer of a classifier needs the [CLS]
+    // row alone; the other waves still help with the K / V DMA)
+    const bool has_rows = qb0 * 16 < Lp && qb0 < max_qblocks;         // waves past the pair's rows only helped with the DMA
     // B operand = Q rows (query fr of block b, dims 8*fq..+8)
     half8 qh[QB], ql[QB];
 #pragma unroll
@@ -1118,8 +1131,10 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
         lsum[b] = 0.f;
     }
     const float cs = (float)(0.17677669529663687 * 1.4426950408889634);    // 32^-0.5 * log2(e)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!DIRECT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     if (!has_rows) return;
     for (int kb = 0; kb < nkb; ++kb) {
         const int fo = kb * 2048 + lane * 16;
@@ -1194,7 +1209,7 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
         const float inv = 1.0f / l;
-        if ((qb0 + b) * 16 >= Lp) break;
+        if ((qb0 + b) * 16 >= Lp || qb0 + b >= max_qblocks) break;
         if (MX) {
             // K-step = head; c0 = dims 4fq..4fq+3 (fragment j = 0), c1 = 16 + the same (j = 1); lane half h = fq >> 1, i = 4 (fq & 1) + r
             const int64_t mrow = (int64_t)row0 + (qb0 + b) * 16 + fr;
@@ -1222,9 +1237,11 @@ __global__ __launch_bounds__(256) void ce_pool_classify_kernel(const half_t* __r
     __shared__ float xs[1024];
     __shared__ float part[4];
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const half_t* x = x16 + (size_t)pair_off[pair] * 2 * hidden;     // [CLS] = the pair's first packed row (split layout)
+    const half_t* x = MX ? x16 : x16 + (size_t)pair_off[pair] * 2 * hidden;     // [CLS] = the pair's first packed row (split layout)
+    // pair_off == nullptr (MX only): x16 holds one row per pair (the compact [CLS] stream of the last layer)
     for (int i = tid; i < hidden; i += 256)
-        xs[i] = MX ? mx_load_elem(reinterpret_cast<const char*>(x16), pair_off[pair], i, hidden >> 5) : (float)x[SPLIT_IDX(i)] + (float)x[SPLIT_IDX(i) + 32];
+        xs[i] = MX ? mx_load_elem(reinterpret_cast<const char*>(x16), pair_off ? pair_off[pair] : pair, i, hidden >> 5)
+                   : (float)x[SPLIT_IDX(i)] + (float)x[SPLIT_IDX(i) + 32];
     __syncthreads();
     float acc = 0.f;
     for (int n = tid; n < hidden; n += 256) {
@@ -1238,6 +1255,49 @@ __global__ __launch_bounds__(256) void ce_pool_classify_kernel(const half_t* __r
     if (lane == 0) part[wv] = acc;
     __syncthreads();
     if (tid == 0) logits[pair] = part[0] + part[1] + part[2] + part[3] + bc[0];
+}
+
+// The same head for the compact [CLS] stream of the MX forward (one row per pair), 8 pairs per workgroup: the pooler matrix is read
+// once per 8 pairs and TRANSPOSED (wpT[k][n]: consecutive threads read consecutive floats) - the per-pair kernel above walks 590 KB of
+// weights per pair with one row per thread (0.64 ms per 7,680 pairs). fp32 sums in the same k order as the kernel above.
+#define POOL_PB 8
+__global__ __launch_bounds__(256) void mx_pool_classify_kernel(const char* __restrict__ xc8, const float* __restrict__ wpT,
+                                                                const float* __restrict__ bp, const float* __restrict__ wc,
+                                                                const float* __restrict__ bc, int P, int hidden, float* __restrict__ logits) {
+    __shared__ float xs[POOL_PB][1024];
+    __shared__ float part[POOL_PB][4];
+    const int p0 = blockIdx.x * POOL_PB, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < POOL_PB * hidden; i += 256) {
+        const int j = i / hidden, c = i % hidden;
+        xs[j][c] = p0 + j < P ? mx_load_elem(xc8, p0 + j, c, hidden >> 5) : 0.f;
+    }
+    __syncthreads();
+    float acc[POOL_PB];
+#pragma unroll
+    for (int j = 0; j < POOL_PB; ++j) acc[j] = 0.f;
+    for (int n = tid; n < hidden; n += 256) {
+        float sj[POOL_PB];
+        const float b = bp[n];
+#pragma unroll
+        for (int j = 0; j < POOL_PB; ++j) sj[j] = b;
+        for (int k = 0; k < hidden; ++k) {
+            const float w = wpT[(size_t)k * hidden + n];
+#pragma unroll
+            for (int j = 0; j < POOL_PB; ++j) sj[j] += w * xs[j][k];
+        }
+        const float c = wc[n];
+#pragma unroll
+        for (int j = 0; j < POOL_PB; ++j) acc[j] += c * tanhf(sj[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < POOL_PB; ++j) {
+        float a = acc[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0) part[j][wv] = a;
+    }
+    __syncthreads();
+    if (tid < POOL_PB && p0 + tid < P) logits[p0 + tid] = part[tid][0] + part[tid][1] + part[tid][2] + part[tid][3] + bc[0];
 }
 
 // Sentence embedding head (sentence-transformers' Pooling(mean) + Normalize): mean of the last hidden state over the pair's
@@ -1299,6 +1359,7 @@ static void ce_free_ws(rag_ce_model* m) {
 static void mx_free_ws(rag_ce_model* m) {
     auto& w = m->mx;
     hipFree(w.x8); hipFree(w.ctx8); hipFree(w.h8); hipFree(w.qf16); hipFree(w.kf16); hipFree(w.vf16);
+    hipFree(w.xc8); hipFree(w.cc8); hipFree(w.hc8); hipFree(w.m_cls);
     hipFree(w.ids); hipFree(w.tt); hipFree(w.lens); hipFree(w.pair_off); hipFree(w.row_pair); hipFree(w.m_packed);
     hipFree(w.sid); hipFree(w.stt); hipFree(w.logits);
     w = rag_ce_model::MxWs();
@@ -1410,6 +1471,13 @@ static int ce_load_model(rag_ctx* h, const rag_ce_config* cfg, const float* cons
     if (!embed) {
         const float* const* t = T + 5 + 16 * cfg->layers;
         if ((rc = up_f32(h, m, t[0], H * H, &m->wp))) return rc;
+        {
+            std::vector<float> tr(H * H);
+            for (size_t n = 0; n < H; ++n)
+                for (size_t k = 0; k < H; ++k) tr[k * H + n] = t[0][n * H + k];
+            if ((rc = up_f32(h, m, tr.data(), H * H, &m->wpT))) return rc;
+            HIP_TRY(h, hipStreamSynchronize(h->stream));          // tr is a stack-lifetime buffer
+        }
         if ((rc = up_f32(h, m, t[1], H, &m->bp))) return rc;
         if ((rc = up_f32(h, m, t[2], H, &m->wc))) return rc;
         if ((rc = up_f32(h, m, t[3], 1, &m->bc))) return rc;
@@ -1631,6 +1699,14 @@ static int mx_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t s
     HIP_TRY(h, hipMalloc(&w.x8, (size_t)Mp * H * 3));
     HIP_TRY(h, hipMalloc(&w.ctx8, (size_t)Mp * H * 3));
     HIP_TRY(h, hipMalloc(&w.h8, (size_t)Mp * F * 3));
+    const int64_t Pp = round_up((int64_t)P, MX_TN);
+    HIP_TRY(h, hipMalloc(&w.xc8, (size_t)Pp * H * 3));
+    HIP_TRY(h, hipMalloc(&w.cc8, (size_t)Pp * H * 3));
+    HIP_TRY(h, hipMalloc(&w.hc8, (size_t)Pp * F * 3));
+    HIP_TRY(h, hipMalloc(&w.m_cls, 4));
+    HIP_TRY(h, hipMemsetAsync(w.xc8, 0, (size_t)Pp * H * 3, st));
+    HIP_TRY(h, hipMemsetAsync(w.cc8, 0, (size_t)Pp * H * 3, st));
+    HIP_TRY(h, hipMemsetAsync(w.hc8, 0, (size_t)Pp * F * 3, st));
     HIP_TRY(h, hipMalloc(&w.qf16, 2 * kv * 2));
     HIP_TRY(h, hipMalloc(&w.kf16, 2 * kv * 2));
     HIP_TRY(h, hipMalloc(&w.vf16, 2 * kv * 2));
@@ -1657,7 +1733,7 @@ static int mx_ensure_ws(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream_t s
 }
 
 template <int QB>
-static int mx_launch_attention(rag_ctx* h, rag_ce_model* m, int P, int L, size_t kv_plane, hipStream_t st, const int32_t* lens_dev) {
+static int mx_launch_attention(rag_ctx* h, rag_ce_model* m, int P, int L, size_t kv_plane, hipStream_t st, const int32_t* lens_dev, int max_qblocks) {
     const int lds = L * 256;
     int& attr_lds = h->attr_ce_attn_mx_lds[QB];
     if (lds > attr_lds) {
@@ -1666,9 +1742,15 @@ static int mx_launch_attention(rag_ctx* h, rag_ce_model* m, int P, int L, size_t
         attr_lds = lds;
     }
     auto& w = m->mx;
+    if (max_qblocks == 1) {                                  // the [CLS]-only last layer: one wave per (head, pair), no LDS
+        hipLaunchKernelGGL((ce_attention_kernel<1, true, true>), dim3(m->cfg.heads, P), dim3(64), 0, st, (const half_t*)w.qf16,
+                           (const half_t*)w.kf16, (const half_t*)w.vf16, kv_plane, lens_dev, (const int32_t*)w.pair_off, L, m->cfg.hidden,
+                           m->cfg.heads, (int)w.tokens, reinterpret_cast<half_t*>(w.ctx8), 1);
+        return RAG_OK;
+    }
     hipLaunchKernelGGL((ce_attention_kernel<QB, true>), dim3(m->cfg.heads, P), dim3(64 * (L / (16 * QB))), lds, st, (const half_t*)w.qf16,
                        (const half_t*)w.kf16, (const half_t*)w.vf16, kv_plane, lens_dev, (const int32_t*)w.pair_off, L, m->cfg.hidden,
-                       m->cfg.heads, (int)w.tokens, reinterpret_cast<half_t*>(w.ctx8));
+                       m->cfg.heads, (int)w.tokens, reinterpret_cast<half_t*>(w.ctx8), max_qblocks);
     return RAG_OK;
 }
 
@@ -1693,11 +1775,42 @@ static int mx_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     const dim3 blk(512);
     for (int l = 0; l < m->cfg.layers; ++l) {
         auto& ly = m->layers[l];
+        const bool cls_tail = !m->embed && l == m->cfg.layers - 1;
+        if (cls_tail) {
+            // last layer of a classifier (see below): K and V for every token, Q for the [CLS] rows alone
+            hipLaunchKernelGGL(mx_gather_rows_kernel, dim3((unsigned)(((int64_t)P * 72 + 255) / 256)), dim3(256), 0, st, (const char*)w.x8, (const char*)nullptr,
+                               (const int32_t*)w.pair_off, P, H / 32, w.xc8, (char*)nullptr, w.m_cls);
+            hipLaunchKernelGGL((mx_gemm_kernel<mx_epi_qkv>), dim3(n_cu), blk, MX_KERNEL_LDS, st, (const char*)ly.wqkv8 + (size_t)(H / 32) * MX_A_STAGE,
+                               (const char*)w.x8, H / 32, 2, (const int32_t*)w.m_packed,
+                               mx_epi_qkv{w.qf16, w.kf16, w.vf16, kv_plane, ly.bqkv, (int)(Mp >> 4), 1, (const int32_t*)nullptr, 0});
+            hipLaunchKernelGGL((mx_gemm_kernel<mx_epi_qkv>), dim3(n_cu), blk, MX_KERNEL_LDS, st, (const char*)ly.wqkv8, (const char*)w.xc8, H / 32, 1,
+                               (const int32_t*)w.m_cls, mx_epi_qkv{w.qf16, w.kf16, w.vf16, kv_plane, ly.bqkv, (int)(Mp >> 4), 0, (const int32_t*)w.pair_off, P});
+        } else
         hipLaunchKernelGGL((mx_gemm_kernel<mx_epi_qkv>), dim3(n_cu), blk, MX_KERNEL_LDS, st, (const char*)ly.wqkv8, (const char*)w.x8, H / 32, 3,
-                           (const int32_t*)w.m_packed, mx_epi_qkv{w.qf16, w.kf16, w.vf16, kv_plane, ly.bqkv, (int)(Mp >> 4)});
+                           (const int32_t*)w.m_packed, mx_epi_qkv{w.qf16, w.kf16, w.vf16, kv_plane, ly.bqkv, (int)(Mp >> 4), 0, (const int32_t*)nullptr, 0});
+        // The classifier reads the [CLS] row of the last layer alone (pooler: hidden_states[:, 0]), and nothing after the last layer's
+        // attention mixes tokens. So in the LAST layer of a classifier only the first 16-query block of every pair goes through
+        // attention, and out-projection, FFN and both LayerNorms run on ONE row per pair (gathered into compact tensors): the same
+        // arithmetic on the rows that are read, nothing computed for the rows that are not - 4.6M rows become 25,600 for a third of
+        // the layer's kernels. An embedding model (mean pooling over all tokens) takes the full path.
         {
-            const int rc = L == 32 ? mx_launch_attention<1>(h, m, P, L, kv_plane, st, lens_dev) : mx_launch_attention<2>(h, m, P, L, kv_plane, st, lens_dev);
+            const int lim = cls_tail ? 1 : 1 << 20;
+            const int rc = L == 32 ? mx_launch_attention<1>(h, m, P, L, kv_plane, st, lens_dev, lim) : mx_launch_attention<2>(h, m, P, L, kv_plane, st, lens_dev, lim);
             if (rc != RAG_OK) return rc;
+        }
+        if (cls_tail) {
+            hipLaunchKernelGGL(mx_gather_rows_kernel, dim3((unsigned)(((int64_t)P * 72 + 255) / 256)), dim3(256), 0, st, (const char*)w.ctx8, (const char*)nullptr,
+                               (const int32_t*)w.pair_off, P, H / 32, w.cc8, (char*)nullptr, w.m_cls);
+            hipLaunchKernelGGL((mx_gemm_kernel<mx_epi_ln>), dim3(n_cu), blk, MX_KERNEL_LDS, st, (const char*)ly.wo8, (const char*)w.cc8, H / 32, 1,
+                               (const int32_t*)w.m_cls, mx_epi_ln{w.xc8, ly.bo, ly.ln1_g, ly.ln1_b, eps});
+            hipLaunchKernelGGL((mx_gemm_kernel<mx_epi_gelu>), dim3(n_cu), blk, MX_KERNEL_LDS, st, (const char*)ly.w18, (const char*)w.xc8, H / 32, F / MX_TM,
+                               (const int32_t*)w.m_cls, mx_epi_gelu{w.hc8, ly.b1, F / 32});
+            hipLaunchKernelGGL((mx_gemm_kernel<mx_epi_ln>), dim3(n_cu), blk, MX_KERNEL_LDS, st, (const char*)ly.w28, (const char*)w.hc8, F / 32, 1,
+                               (const int32_t*)w.m_cls, mx_epi_ln{w.xc8, ly.b2, ly.ln2_g, ly.ln2_b, eps});
+            hipLaunchKernelGGL(mx_pool_classify_kernel, dim3((unsigned)((P + POOL_PB - 1) / POOL_PB)), dim3(256), 0, st, (const char*)w.xc8, (const float*)m->wpT,
+                               (const float*)m->bp, (const float*)m->wc, (const float*)m->bc, P, H, logits_dev);
+            HIP_TRY(h, hipGetLastError());
+            return RAG_OK;
         }
         hipLaunchKernelGGL((mx_gemm_kernel<mx_epi_ln>), dim3(n_cu), blk, MX_KERNEL_LDS, st, (const char*)ly.wo8, (const char*)w.ctx8, H / 32, 1,
                            (const int32_t*)w.m_packed, mx_epi_ln{w.x8, ly.bo, ly.ln1_g, ly.ln1_b, eps});
