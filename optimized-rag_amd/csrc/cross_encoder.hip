@@ -1807,8 +1807,13 @@ static int mx_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
                                (const int32_t*)w.m_cls, mx_epi_gelu{w.hc8, ly.b1, F / 32});
             hipLaunchKernelGGL((mx_gemm_kernel<mx_epi_ln>), dim3(n_cu), blk, MX_KERNEL_LDS, st, (const char*)ly.w28, (const char*)w.hc8, F / 32, 1,
                                (const int32_t*)w.m_cls, mx_epi_ln{w.xc8, ly.b2, ly.ln2_g, ly.ln2_b, eps});
-            hipLaunchKernelGGL(mx_pool_classify_kernel, dim3((unsigned)((P + POOL_PB - 1) / POOL_PB)), dim3(256), 0, st, (const char*)w.xc8, (const float*)m->wpT,
-                               (const float*)m->bp, (const float*)m->wc, (const float*)m->bc, P, H, logits_dev);
+            // the batched pooler pays from ~512 pairs on; a single query's 100 pairs fill more CUs with one workgroup per pair
+            if (P >= 512)
+                hipLaunchKernelGGL(mx_pool_classify_kernel, dim3((unsigned)((P + POOL_PB - 1) / POOL_PB)), dim3(256), 0, st, (const char*)w.xc8,
+                                   (const float*)m->wpT, (const float*)m->bp, (const float*)m->wc, (const float*)m->bc, P, H, logits_dev);
+            else
+                hipLaunchKernelGGL(ce_pool_classify_kernel<true>, dim3(P), dim3(256), 0, st, reinterpret_cast<const half_t*>(w.xc8), (const float*)m->wp,
+                                   (const float*)m->bp, (const float*)m->wc, (const float*)m->bc, (const int32_t*)nullptr, H, logits_dev);
             HIP_TRY(h, hipGetLastError());
             return RAG_OK;
         }
