@@ -66,7 +66,7 @@ class Scheme:
             return hi, q8(lo * 2048.0 * wscale * TRUNC_GAIN, torch.float8_e4m3fn) / (2048.0 * wscale), top_byte(hi, False)
         if n == "bf8r":
             return hi, q8(lo * 2048.0 * wscale, torch.float8_e4m3fn) / (2048.0 * wscale), top_byte(hi, True)
-        if n in ("bf8tt", "bf8tt_stream"):     # hi8 = top byte of hi, lo8 = e5m2(lo * 2^11 * gain) round-to-nearest: ONE operand format (bf8)
+        if n in ("bf8tt", "bf8tt_stream", "ship", "ship_noplo"):     # hi8 = top byte of hi, lo8 = e5m2(lo * 2^11 * gain) round-to-nearest: ONE operand format (bf8)
             return hi, q8(lo * 2048.0 * wscale * TRUNC_GAIN, torch.float8_e5m2) / (2048.0 * wscale), top_byte(hi, False)
         if n == "bf8t_nogain":
             return hi, q8(lo * 2048.0 * wscale, torch.float8_e4m3fn) / (2048.0 * wscale), top_byte(hi, False)
@@ -74,19 +74,21 @@ class Scheme:
 
     def store(self, x):
         """what a consumer reads back from an activation tensor stored as hi16 + lo8 (the residual stream, ctx, the FFN intermediate)"""
-        if not self.name.endswith("_stream"):
+        if not (self.name.endswith("_stream") or self.name.startswith("ship")):
             return x
         hi = f16(x)
         return hi + q8((x - hi) * 2048.0 * TRUNC_GAIN, torch.float8_e5m2) / (2048.0 * TRUNC_GAIN)
 
-    def mm(self, a, b, a_scale=1.0, b_scale=1.0):
+    def mm(self, a, b, a_scale=1.0, b_scale=1.0, drop_a_lo=False):
         """a @ b^T over the last axis of both, operands rounded per scheme (leading axes broadcast as numpy matmul)"""
         ah, al, a8 = self.split(a, a_scale)
         bh, bl, b8 = self.split(b, b_scale)
         bt = lambda t: np.swapaxes(t, -1, -2)
         y = ah @ bt(bh)
         if al is not None:
-            y = y + al @ bt(b8) + a8 @ bt(bl)
+            y = y + a8 @ bt(bl)
+            if not drop_a_lo:
+                y = y + al @ bt(b8)
         return y
 
 
@@ -116,7 +118,13 @@ def forward(w, cfg, ids, tt, lens, sch, sites=None):
         s = sch.mm(sp(q), sp(k)) * (dh ** -0.5) + add_mask
         s = s - s.max(-1, keepdims=True)
         e = np.exp(s)                                   # unnormalised P in (0, 1], as the kernel's online softmax holds it
-        ctx = sch.mm(e, np.swapaxes(sp(v), -1, -2)) / e.sum(-1, keepdims=True)
+        # ship*: the shipped forward keeps attention in split fp16 whatever the GEMM scheme; *_noplo: P.V without the P_lo term
+        att = Scheme("split16") if sch.name.startswith("ship") else sch
+        if sch.name.startswith("ship"):
+            s = att.mm(sp(q), sp(k)) * (dh ** -0.5) + add_mask
+            s = s - s.max(-1, keepdims=True)
+            e = np.exp(s)
+        ctx = att.mm(e, np.swapaxes(sp(v), -1, -2), drop_a_lo=sch.name.endswith("noplo")) / e.sum(-1, keepdims=True)
         ctx = sch.store(ctx.transpose(0, 2, 1, 3).reshape(P, L, H))
         o = lin(ctx, p + "attention.output.dense")
         x = sch.store(B._ln(o + x, W[p + "attention.output.LayerNorm.weight"], W[p + "attention.output.LayerNorm.bias"], cfg["eps"]))
