@@ -63,7 +63,7 @@ static thread_local std::string g_null_err = "null handle";
 static const struct { const char* name; int rag_options::*field; } g_options[] = {
     {"force_level", &rag_options::force_level},         {"stage_growth", &rag_options::stage_growth},
     {"no_smallq", &rag_options::no_smallq},             {"no_second_pass", &rag_options::no_second_pass},
-    {"dense_linear_order", &rag_options::dense_linear_order},
+    {"dense_linear_order", &rag_options::dense_linear_order}, {"dense_persist", &rag_options::dense_persist},
     {"bm25_first_ranges", &rag_options::bm25_first_ranges}, {"bm25_no_staging", &rag_options::bm25_no_staging},
     {"bm25_packed", &rag_options::bm25_packed},         {"bm25_plan_slots", &rag_options::bm25_plan_slots},       {"bm25_ws_mb", &rag_options::bm25_ws_mb},
     {"bm25_linear_grid", &rag_options::bm25_linear_grid},            {"bm25_sort_merge", &rag_options::bm25_sort_merge},

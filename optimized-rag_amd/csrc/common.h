@@ -35,6 +35,7 @@ struct rag_options {
     int stage_growth = 0;         // dense stage growth (0 = the built-in schedule)
     int no_smallq = 0;            // disable the small-batch dense kernel variant
     int no_second_pass = 0;       // overflowed dense queries go straight to the float64 scan
+    int dense_persist = 0;        // (experiment) thresholded stages as one persistent workgroup per CU instead of one workgroup per tile
     int dense_linear_order = 0;   // walk the tiles in table order (r1 behaviour, for A/B)
     int bm25_first_ranges = 0;    // exact first-stage BM25 ranges (0 = BM_FIRST_RANGES)
     int bm25_no_staging = 0;      // exact per-range select for every BM25 range

@@ -1125,6 +1125,9 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
         else if (smallq)
             hipLaunchKernelGGL((dense_emit_kernel<false, true>), dim3(grid), dim3(512), DENSE_LDS_BYTES_SMALLQ, st,
                                EMIT_ARGS(h->q16, n_qtiles, Q, tau, h->cnt, h->cand, nullptr, nullptr));
+        else if (h->opt.dense_persist && grid > 256)       // experiment: one workgroup per CU walks the stage's tiles
+            hipLaunchKernelGGL((dense_emit_persist_kernel<false>), dim3(256), dim3(512), DENSE_LDS_BYTES, st, grid,
+                               EMIT_ARGS(h->q16, n_qtiles, Q, tau, h->cnt, h->cand, nullptr, nullptr));
         else
             hipLaunchKernelGGL((dense_emit_kernel<false, false>), dim3(grid), dim3(512), DENSE_LDS_BYTES, st,
                                EMIT_ARGS(h->q16, n_qtiles, Q, tau, h->cnt, h->cand, nullptr, nullptr));
