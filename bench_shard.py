@@ -257,6 +257,9 @@ def headline_rerank(eng, device, rows_total, rank=0, world=1, steps=20, warmup=3
         "roofline": {"bound": "mfma", "kernel": "cross-encoder forward of one batch on rank 0 (mx_gemm_kernel<qkv | ln | gelu> + ce_attention_kernel + "
                                                   "embedding / pooler), all chunks; dominant kernel mx_gemm_kernel<mx_epi_gelu> (FFN up-projection)",
                      "achieved": round(ce_tf, 2), "peak": BE.PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ce_tf / BE.PEAK_MFMA_TFLOPS, 4),
+                     "traffic": BM._profile_number("r04_ce_traffic.json", ("per_forward_bytes", "total")) if (world == 1 and rows_total == 1_000_000) else None,
+                     "traffic_source": "profiles/r04_ce_traffic.json: HBM bytes of one 25,600-pair forward (FETCH_SIZE x 2 + WRITE_SIZE, separate "
+                                       "rocprofv3 --pmc passes of `bench.py --mode rerank`; Infinity-Cache hits are counted in FETCH_SIZE)",
                      "avg_forward_ms": round(fwd_ms, 3), "algorithmic_flops_per_forward": flops / world,
                      "share_of_batch_time": round(fwd_ms / (t * 1e3), 4),
                      "note": "algorithmic FLOPs / device time of the forward (HIP events on the launch stream). Operands are hi16 + lo8: per "
