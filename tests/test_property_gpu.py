@@ -195,11 +195,12 @@ _CE_WEIGHTS = {}
 
 @settings(**{**COMMON, "max_examples": max(10, N_EX // 12)})
 @given(seed=st.integers(0, 2**31 - 1), layers=st.integers(1, 2), n_pairs=st.integers(1, 48), l_in=st.integers(2, 160),
-       extremes=st.booleans())
-def test_cross_encoder_logits_equal_the_float64_forward(seed, layers, n_pairs, l_in, extremes):
-    """MiniLM-shaped cross-encoder (hidden 384, the fused-LayerNorm path) on random pair sets: any input width (padded to the
-    next supported attention length), lengths down to 1 token and up to the full width, one pair or several token tiles;
-    logits within 4e-3 of the float64 restatement of BertForSequenceClassification."""
+       extremes=st.booleans(), forward=st.sampled_from([1, -1, 0]))
+def test_cross_encoder_logits_equal_the_float64_forward(seed, layers, n_pairs, l_in, extremes, forward):
+    """MiniLM-shaped cross-encoder (hidden 384) on random pair sets: any input width (padded to the next supported attention length),
+    lengths down to 1 token and up to the full width, one pair or several token tiles, on each of the forwards (option ce_mx: 1 =
+    the MX kernels with the [CLS]-only last layer, -1 = the split-fp16 kernels, 0 = the size rule); logits within 4e-3 of the float64
+    restatement of BertForSequenceClassification."""
     from oracle import bert_oracle as B
     from optimized_rag_amd.cross_encoder import flatten_state_dict
     cfg = dict(vocab_size=3000, hidden=384, layers=layers, heads=12, ffn=1536, max_pos=256, type_vocab=2, eps=1e-12)
@@ -218,7 +219,11 @@ def test_cross_encoder_logits_equal_the_float64_forward(seed, layers, n_pairs, l
     ids = rng.integers(5, cfg["vocab_size"], (n_pairs, l_in)).astype(np.int32)
     ids[np.arange(l_in)[None, :] >= lens[:, None]] = 0
     tt = ((np.arange(l_in)[None, :] >= 7) & (np.arange(l_in)[None, :] < lens[:, None])).astype(np.int32)
-    got = eng.ce_score(ids, tt, lens)
+    eng.set_option("ce_mx", forward)
+    try:
+        got = eng.ce_score(ids, tt, lens)
+    finally:
+        eng.set_option("ce_mx", 0)
     sel = np.unique(np.concatenate([[0, n_pairs - 1], rng.integers(0, n_pairs, 3)]))      # the float64 forward is the slow side
     exp = B.forward_logits(w, cfg, ids[sel].astype(np.int64), tt[sel].astype(np.int64), lens[sel], fast_erf=True)
     assert np.isfinite(got).all()
