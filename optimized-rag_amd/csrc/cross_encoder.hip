@@ -674,7 +674,7 @@ __global__ __launch_bounds__(512) void ce_gemm_ln_kernel(const half_t* __restric
 #define FFN_LDS (FFN_RING + FFN_HBUF)
 #define FFN_CH 128                                // intermediate features per chunk
 #define FFN_FUSED_MIN_ROWS (5120 * 256)            // P x L from which the fused kernel is used (below: the two-launch form)
-#define MX_MIN_ROWS (20 * 256)                     // P x L from which the MX forward (ce_mx.h) runs instead of the split-fp16 kernels (tools/ce_mx_sweep.py: 13 pairs tie, 25 pairs and up MX is 10-19 % faster)
+#define MX_MIN_ROWS 0                              // P x L from which the MX forward (ce_mx.h) runs instead of the split-fp16 kernels: every size. tools/ce_mx_sweep.py: 13 pairs tie (0.82 | 0.80 ms), 25 pairs and up MX is 10-19 % faster - and a pair's logit must not depend on how a batch was split over ranks or chunks, so the rule is by SHAPE only
 template <int TERMS>
 __global__ __launch_bounds__(512) void ce_ffn_ln_kernel(const half_t* __restrict__ W1, const float* __restrict__ b1,
                                                          const half_t* __restrict__ W2, const float* __restrict__ b2, int F,
@@ -1856,8 +1856,8 @@ static int ce_run(rag_ctx* h, rag_ce_model* m, const int32_t* ids, const int32_t
     // the multi-chunk loop on small inputs.
     const int64_t chunk_tokens = h->opt.ce_chunk_tokens >= 32 ? h->opt.ce_chunk_tokens : 2'000'000;
     const int chunk = std::max(1, std::min(P, (int)(chunk_tokens / L)));
-    // Which forward: the MX kernels (hi16 + lo8 operands, 384 x 128 tiles; ce_mx.h) from MX_MIN_ROWS padded rows on - a single query's
-    // 100 pairs fill the CUs better with the split-fp16 kernels' finer tiles. Option ce_mx: 1 = always (when the shape allows), -1 = never.
+    // Which forward: the MX kernels (hi16 + lo8 operands, 384 x 128 tiles; ce_mx.h) whenever the SHAPE allows (hidden 384, ffn a multiple
+    // of 384), the split-fp16 kernels for every other model. Option ce_mx: -1 = never (1 = always, the same as the default today).
     const bool use_mx = m->mx_ok && L >= 32 && h->opt.ce_mx >= 0 && (h->opt.ce_mx > 0 || (int64_t)P * L >= MX_MIN_ROWS);
     int rc = use_mx ? mx_ensure_ws(h, m, chunk, L, st) : ce_ensure_ws(h, m, chunk, L, st);
     if (rc) return rc;
