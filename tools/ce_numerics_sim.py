@@ -13,6 +13,8 @@ Schemes (x = hi + lo, hi = fp16(x)):
   bf8tt    hi8 = top byte of hi (truncation), lo8 = e5m2(lo * 2^11 * gain): both correction operands in ONE 8-bit format, so the
            two correction products of a K range can share one block-scaled MFMA ([lo8 | hi8] . [hi8 | lo8])   (2 units, 3 B)
   bf8tt_stream  bf8tt, and every stored activation (residual stream, ctx, FFN intermediate) read back as hi16 + lo8
+  ship     bf8tt_stream with attention in split fp16 (what the first MX build shipped); ship_noplo: without the P_lo term of P.V
+  shiprn   ship with hi8 rounded to NEAREST (top byte of hi + 0x80) and no gain on lo8: what ships now
 usage: python tools/ce_numerics_sim.py [pairs] [L] [scheme,scheme...]"""
 import math
 import os
@@ -68,6 +70,8 @@ class Scheme:
             return hi, q8(lo * 2048.0 * wscale, torch.float8_e4m3fn) / (2048.0 * wscale), top_byte(hi, True)
         if n in ("bf8tt", "bf8tt_stream", "ship", "ship_noplo"):     # hi8 = top byte of hi, lo8 = e5m2(lo * 2^11 * gain) round-to-nearest: ONE operand format (bf8)
             return hi, q8(lo * 2048.0 * wscale * TRUNC_GAIN, torch.float8_e5m2) / (2048.0 * wscale), top_byte(hi, False)
+        if n == "shiprn":                        # ship with hi8 rounded to nearest (top byte of hi + 0x80), no gain
+            return hi, q8(lo * 2048.0 * wscale, torch.float8_e5m2) / (2048.0 * wscale), top_byte(hi, True)
         if n == "bf8t_nogain":
             return hi, q8(lo * 2048.0 * wscale, torch.float8_e4m3fn) / (2048.0 * wscale), top_byte(hi, False)
         raise ValueError(n)
@@ -77,7 +81,8 @@ class Scheme:
         if not (self.name.endswith("_stream") or self.name.startswith("ship")):
             return x
         hi = f16(x)
-        return hi + q8((x - hi) * 2048.0 * TRUNC_GAIN, torch.float8_e5m2) / (2048.0 * TRUNC_GAIN)
+        g = 1.0 if self.name == "shiprn" else TRUNC_GAIN
+        return hi + q8((x - hi) * 2048.0 * g, torch.float8_e5m2) / (2048.0 * g)
 
     def mm(self, a, b, a_scale=1.0, b_scale=1.0, drop_a_lo=False):
         """a @ b^T over the last axis of both, operands rounded per scheme (leading axes broadcast as numpy matmul)"""
