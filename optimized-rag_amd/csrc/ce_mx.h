@@ -4,12 +4,12 @@
 // Numerics (tools/ce_numerics_sim.py): x = hi + lo, hi = fp16(x). rounds 1-3 kept lo as a second fp16 and
 // spent three fp16 MFMAs per product (hi.hi + lo.hi + hi.lo). The two correction products only have to be good to a few
 // per cent, so here
-//   * lo8 = e5m2(lo * 2^11 * G) (one byte, round to nearest),
-//   * hi8 = the TOP BYTE of hi's fp16 pattern = e5m2(hi) rounded toward zero: not stored, made in registers by v_perm_b32 from the
-//     fp16 fragment the wave holds anyway; G = 1 / 0.915 undoes the mean loss of that truncation. (Rounding hi8 to nearest instead -
-//     one v_pk_add_u16 per dword before the perm, G = 1 - halves the simulated logit error, 5.6e-4 / 8.8e-4 against 1.40e-3 / 1.56e-3,
-//     and its 56 extra vector instructions per wave and K-step slow the main loop by 10 %: measured in tools/ce_mx_probe.hip, not
-//     kept while the truncating form holds the 4e-3 bar with a factor 2.5),
+//   * lo8 = e5m2(lo * 2^11) (one byte, round to nearest),
+//   * hi8 = e5m2(hi) = the TOP BYTE of (hi's fp16 pattern + 0x80): not stored, made in registers from the fp16 fragment the wave holds
+//     anyway - one 32-bit add per dword (round to nearest on the magnitude of both halves) and one v_perm_b32 per four elements.
+//     (-DMX_HI8_TRUNCATE keeps the first form of round 4: the top byte as it stands = rounding toward zero, with lo8 scaled up by
+//     the mean loss 1 / 0.915. One instruction per dword less, 3.8 % faster main loop in tools/ce_mx_probe.hip - and 1.6e-3
+//     instead of 1.0e-3 of logit error on the GPU, 1.5e-3 instead of 8.8e-4 in the simulation: the rounded form ships.)
 //   * both correction products of a 32-element K range run as ONE block-scaled bf8 MFMA of 64 K-slots:
 //     A = [lo8 | hi8], B = [hi8 | lo8], scale 2^-11 (v_mfma_scale_f32_32x32x64_f8f6f4: twice the fp16 rate per K-slot).
 // Per 32x32 block and 32-deep K-step: 2 x v_mfma_f32_32x32x16_f16 (64 cycles) + 1 x scaled bf8 (64 cycles) = 128 cycles against
@@ -39,8 +39,11 @@ typedef int mx_v4i __attribute__((ext_vector_type(4)));
 #define MX_STAGE (MX_A_STAGE + MX_B_STAGE)        // 49152 B
 #define MX_STAGES 3
 #define MX_LDS (MX_STAGES * MX_STAGE)             // 147456 B
-#define MX_LO_GAIN 1.0928961748633879f            // 1 / 0.915: mean of hi / trunc_e5m2(hi)
-#define MX_LO_SCALE (2048.0f * MX_LO_GAIN)        // lo8 = e5m2(lo * MX_LO_SCALE)
+#ifndef MX_HI8_TRUNCATE
+#define MX_LO_SCALE 2048.0f                       // lo8 = e5m2(lo * 2^11): |lo| <= 2^-11 |x|, so lo8 spans x's own range
+#else
+#define MX_LO_SCALE (2048.0f * 1.0928961748633879f)   // truncating hi8: the mean loss 1 / 0.915 goes into lo8
+#endif
 #define MX_SCALE_A 116                            // E8M0 of 2^-11: the correction MFMA's block scale (B side: 127 = 2^0)
 #define MX_SCALE_B 127
 
@@ -71,8 +74,17 @@ __device__ __forceinline__ float mx_lo_decode(unsigned lo8) {
     return (float)__builtin_bit_cast(half_t, (unsigned short)(lo8 << 8)) * (1.0f / MX_LO_SCALE);
 }
 
-// the top bytes of four halfs held in two dwords (lo dword first)
-__device__ __forceinline__ int mx_top4(int d0, int d1) { return (int)__builtin_amdgcn_perm((unsigned)d1, (unsigned)d0, 0x07050301u); }
+// e5m2 of four halfs held in two dwords (lo dword first): + 0x80 on each 16-bit pattern (round half up on the magnitude; a carry
+// into the exponent is the right result), then the top bytes. The two halves of a dword are rounded by ONE 32-bit add: the low
+// half carries into the high one only from 0xFF80 up, which is a NaN pattern (a packed v_pk_add_u16 does the same per half and,
+// like every packed op beside MFMAs, slowed the loop by 10 %). |x| >= 61440 rounds to Inf: activations never get there (65504
+// overflows fp16 itself).
+#ifndef MX_HI8_TRUNCATE
+__device__ __forceinline__ unsigned mx_round8(int d) { return (unsigned)d + 0x00800080u; }
+#else
+__device__ __forceinline__ unsigned mx_round8(int d) { return (unsigned)d; }
+#endif
+__device__ __forceinline__ int mx_top4(int d0, int d1) { return (int)__builtin_amdgcn_perm(mx_round8(d1), mx_round8(d0), 0x07050301u); }
 
 // hi8 of a lane's two fp16 fragments of one K-step, in the byte order of the lo8 planes
 __device__ __forceinline__ mx_v4i mx_hi8(half8 f0, half8 f1) {
@@ -110,6 +122,9 @@ __device__ __forceinline__ void mx_bdma(__amdgpu_buffer_rsrc_t rs, unsigned voff
 #endif
 #ifndef MX_BLOCK
 #define MX_BLOCK(SWAP, ...) mx_block<SWAP>(__VA_ARGS__)       // the three MFMAs of one 32 x 32 block
+#endif
+#ifndef MX_W_HI8
+#define MX_W_HI8(h0, h1, lo) mx_hi8(h0, h1)                   // hi8 of a weight fragment pair (4 v_perm_b32)
 #endif
 #ifndef MX_STEP_WAIT
 #define MX_STEP_WAIT "s_waitcnt vmcnt(6)"                     // own pieces of the step have landed (six per wave and step in flight)
@@ -179,7 +194,7 @@ __device__ __forceinline__ void mx_ksteps(f32x16 (&acc)[6], const mx_stream& S, 
         const mx_v8i x8 = SWAP ? mx_cat(xl, mx_hi8(xh0, xh1)) : mx_cat(mx_hi8(xh0, xh1), xl);
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-            const mx_v4i w8h = mx_hi8(wh0[b & 1], wh1[b & 1]);
+            const mx_v4i w8h = MX_W_HI8(wh0[b & 1], wh1[b & 1], wl[b & 1]);
             const mx_v8i w8 = SWAP ? mx_cat(w8h, wl[b & 1]) : mx_cat(wl[b & 1], w8h);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);

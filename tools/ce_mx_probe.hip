@@ -4,7 +4,7 @@
 // Checks (a) the kernel against a float64 emulation of ITS OWN arithmetic (hi.hi + 2^-11 (lo8.hi8 + hi8.lo8) on the rounded
 // operands: validates the layout, the lane maps of both MFMA forms and the K-slot pairing) and (b) against the exact W.X^T (what
 // the scheme is worth), then times the launch with a store-nothing epilogue and with the image-layout epilogue.
-// timing experiments (WRONG results; -DMX_DIAG=<bits>): 1 = no DMA, 2 = no MFMA, 4 = no weight DMA, 8 = no token DMA
+// timing experiments (WRONG results; -DMX_DIAG=<bits>): 1 = no DMA, 2 = no MFMA, 4 = no weight DMA, 8 = no token DMA, 16 = no weight-side v_perm
 #ifndef MX_DIAG
 #define MX_DIAG 0
 #endif
@@ -20,6 +20,9 @@
 #endif
 #if MX_DIAG & 13
 #define MX_STEP_WAIT "s_waitcnt vmcnt(0)"
+#endif
+#if MX_DIAG & 16                      // no weight-side v_perm (what a STORED weight hi8 plane would save in vector work)
+#define MX_W_HI8(h0, h1, lo) (lo)
 #endif
 #include "../optimized-rag_amd/csrc/ce_mx.h"
 
@@ -118,7 +121,11 @@ static void to_image(const std::vector<float>& m, int rows, int K, int tile, std
             *reinterpret_cast<unsigned short*>(base + mx_hi_off(tile, r % tile, k % 32)) = hb;
             *reinterpret_cast<unsigned char*>(base + mx_lo_off(tile, r % tile, k % 32)) = (unsigned char)lb;
             hi[(size_t)r * K + k] = (float)h;
+#ifndef MX_HI8_TRUNCATE
+            hi8[(size_t)r * K + k] = e5m2_val(((unsigned)(hb + 0x80u) >> 8) & 0xFFu);     // the kernel's in-register rounding
+#else
             hi8[(size_t)r * K + k] = e5m2_val(hb >> 8);
+#endif
             lo8[(size_t)r * K + k] = e5m2_val(lb);
         }
 }
