@@ -106,36 +106,76 @@ def gen_queries(Q, total_rows, n_chunks, chunk_rows, device, kind="iid"):
     return (q / q.norm(dim=1, keepdim=True)).contiguous(), rows
 
 
-def choose_exchange(eng, rank, world, device, backend, torch_comm=False):
+def choose_exchange(eng, rank, world, device, backend, torch_comm=False, make_probe=None, probe_timeout=90.0):
     """Which gather the sharded classes use, decided COLLECTIVELY: RCCL behind the C-ABI (rag_comm_allgather_dev) when every rank
-    could create its communicator, torch.distributed otherwise. The 128-byte id travels through the process group that launched
+    could create its communicator, torch.distributed otherwise. The 128-byte ids travel through the process group that launched
     the ranks; a failure on ANY rank (librccl not loadable, ncclCommInitRank failing) sends ALL of them to the torch path - a
-    rank that did succeed destroys its communicator again, so no rank is left alone inside a collective. Returns the label the
-    bench line reports as `config.exchange` (tests/test_bench_launcher.py drives this with a failing rank on gloo)."""
+    rank that did succeed destroys its communicator again, so no rank is left alone inside a collective.
+    ncclCommInitRank is itself a collective and has never run with more than one rank in this repository's own runs: it is first
+    tried on a throw-away PROBE handle in a thread with a deadline, so that a rendezvous that never completes costs `probe_timeout`
+    seconds and the torch path, not the whole line (a thread stuck inside the library holds only the probe handle's lock; the
+    engine the bench measures is not touched until every rank's probe has succeeded). Returns the label the bench line reports as
+    `config.exchange` (tests/test_bench_launcher.py drives this with failing and hanging ranks on gloo)."""
     if world <= 1:
         return "single process"
     label = "torch.distributed (%s)" % backend
     if backend != "nccl" or torch_comm:
         return label
+    import threading
     ok = 1
     try:
-        uid = [eng.comm_unique_id() if rank == 0 else None]
+        uid = [(eng.comm_unique_id(), eng.comm_unique_id()) if rank == 0 else None]
     except Exception:
         uid, ok = [None], 0
     dist.broadcast_object_list(uid, src=0)
-    try:
-        if uid[0] is not None and ok:
-            eng.comm_init(rank, world, uid[0])
-        else:
+    probe, done = None, {"ok": False}
+    if uid[0] is not None and ok:
+        try:
+            if make_probe is None:
+                from optimized_rag_amd import RagEngine
+                probe = RagEngine(dim=8, device=device.index or 0)
+            else:
+                probe = make_probe()
+
+            def run():
+                try:
+                    probe.comm_init(rank, world, uid[0][0])
+                    done["ok"] = True
+                except Exception:
+                    done["ok"] = False
+
+            th = threading.Thread(target=run, daemon=True)
+            th.start()
+            th.join(probe_timeout)
+            ok = 1 if (done["ok"] and not th.is_alive()) else 0
+        except Exception:
             ok = 0
-    except Exception:
+    else:
         ok = 0
     flag = torch.tensor([ok], device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 1:
-        return "rag_comm_allgather_dev (RCCL behind the C-ABI)"
-    if ok:
-        eng.comm_destroy()
+        try:
+            eng.comm_init(rank, world, uid[0][1])
+            ok2 = 1
+        except Exception:
+            ok2 = 0
+        flag2 = torch.tensor([ok2], device=device)
+        dist.all_reduce(flag2, op=dist.ReduceOp.MIN)
+        try:
+            probe.comm_destroy()
+        except Exception:
+            pass
+        if int(flag2.item()) == 1:
+            return "rag_comm_allgather_dev (RCCL behind the C-ABI)"
+        if ok2:
+            eng.comm_destroy()
+        return label
+    if ok and probe is not None:
+        try:
+            probe.comm_destroy()
+        except Exception:
+            pass
     return label
 
 

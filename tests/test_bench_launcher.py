@@ -42,21 +42,26 @@ def test_launched_rank_does_not_relaunch():
 
 
 _EXCHANGE_WORKER = r"""
-import json, os, sys
+import json, os, sys, time
 sys.path.insert(0, sys.argv[1])
 import torch
 import torch.distributed as dist
 import bench
 
 class FakeEngine:
-    # the C-ABI's communicator calls, as far as choose_exchange uses them; rank FAIL_RANK cannot create its communicator
-    def __init__(self, rank, fail_rank):
-        self.rank, self.fail_rank, self.inited, self.destroyed = rank, fail_rank, False, False
+    # the C-ABI's communicator calls, as far as choose_exchange uses them; rank `fail_rank` cannot create its communicator
+    # (mode "raise") or never returns from the rendezvous (mode "hang")
+    def __init__(self, rank, fail_rank, mode="raise"):
+        self.rank, self.fail_rank, self.mode, self.inited, self.destroyed = rank, fail_rank, mode, False, False
+        self.n_ids = 0
     def comm_unique_id(self):
-        return b"u" * 128
+        self.n_ids += 1
+        return bytes([self.n_ids]) * 128
     def comm_init(self, rank, world, uid):
-        assert uid == b"u" * 128
+        assert len(uid) == 128
         if rank == self.fail_rank:
+            if self.mode == "hang":
+                time.sleep(3600)
             raise RuntimeError("ncclCommInitRank failed")
         self.inited = True
     def comm_destroy(self):
@@ -65,20 +70,30 @@ class FakeEngine:
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 out = {}
-for name, fail in (("one_rank_fails", 1), ("all_ok", -1)):
-    e = FakeEngine(rank, fail)
+for name, fail, mode in (("one_rank_fails", 1, "raise"), ("one_rank_hangs", 1, "hang"), ("all_ok", -1, "raise")):
+    e = FakeEngine(rank, -1)                     # the measured engine itself never fails: the PROBE decides
+    probes = []
+    def make_probe():
+        probes.append(FakeEngine(rank, fail, mode))
+        return probes[-1]
     # backend label "nccl": the decision logic of the real runs; the collectives themselves run on this gloo group
-    out[name] = dict(label=bench.choose_exchange(e, rank, world, torch.device("cpu"), "nccl"), inited=e.inited, destroyed=e.destroyed)
+    t0 = time.time()
+    label = bench.choose_exchange(e, rank, world, torch.device("cpu"), "nccl", make_probe=make_probe, probe_timeout=3.0)
+    out[name] = dict(label=label, inited=e.inited, destroyed=e.destroyed, probe_inited=probes[0].inited, probe_destroyed=probes[0].destroyed,
+                     seconds=time.time() - t0)
 out["torch_comm"] = bench.choose_exchange(FakeEngine(rank, -1), rank, world, torch.device("cpu"), "nccl", torch_comm=True)
 print("RANK%d %s" % (rank, json.dumps(out)), flush=True)
 dist.destroy_process_group()
+os._exit(0)                                      # a probe thread may still sleep inside its fake rendezvous
 """
 
 
-def test_one_rank_failing_comm_init_sends_every_rank_to_the_torch_path(tmp_path):
-    """the exchange is chosen collectively. Two gloo ranks drive bench.choose_exchange with a stand-in for the engine's
-    communicator calls: when rank 1 cannot create its communicator BOTH ranks report the torch path and rank 0 destroys the
-    communicator it had created; when every rank succeeds both report RCCL behind the C-ABI; --torch-comm never tries."""
+def test_one_rank_failing_or_hanging_comm_init_sends_every_rank_to_the_torch_path(tmp_path):
+    """the exchange is chosen collectively, and ncclCommInitRank (never run here with more than one rank) is first tried
+    on a throw-away probe handle under a deadline. Two gloo ranks drive bench.choose_exchange with stand-ins for the engine's
+    communicator calls: when rank 1's probe raises OR never returns, BOTH ranks report the torch path within the deadline, the
+    measured engine is never initialised and the probe that did succeed is destroyed; when every probe succeeds both ranks report
+    RCCL behind the C-ABI with the measured engine initialised; --torch-comm never tries."""
     import socket
     script = tmp_path / "worker.py"
     script.write_text(_EXCHANGE_WORKER)
@@ -97,8 +112,13 @@ def test_one_rank_failing_comm_init_sends_every_rank_to_the_torch_path(tmp_path)
             res[int(ln[4])] = json.loads(ln[6:])
     assert set(res) == {0, 1}
     for r in (0, 1):
-        assert res[r]["one_rank_fails"]["label"] == "torch.distributed (nccl)"
+        for case in ("one_rank_fails", "one_rank_hangs"):
+            assert res[r][case]["label"] == "torch.distributed (nccl)", (r, case)
+            assert not res[r][case]["inited"] and not res[r][case]["destroyed"]             # the measured engine was never touched
+            assert res[r][case]["seconds"] < 30
         assert res[r]["all_ok"]["label"].startswith("rag_comm_allgather_dev") and res[r]["all_ok"]["inited"] and not res[r]["all_ok"]["destroyed"]
+        assert res[r]["all_ok"]["probe_inited"] and res[r]["all_ok"]["probe_destroyed"]
         assert res[r]["torch_comm"] == "torch.distributed (nccl)"
-    assert res[0]["one_rank_fails"]["inited"] and res[0]["one_rank_fails"]["destroyed"]        # the rank that succeeded backs out
-    assert not res[1]["one_rank_fails"]["inited"] and not res[1]["one_rank_fails"]["destroyed"]
+    for case in ("one_rank_fails", "one_rank_hangs"):
+        assert res[0][case]["probe_inited"] and res[0][case]["probe_destroyed"]            # the rank whose probe succeeded backs out
+        assert not res[1][case]["probe_inited"]
