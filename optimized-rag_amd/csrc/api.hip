@@ -22,7 +22,8 @@ int bm25_scores_adhoc_host(rag_ctx* h, const int64_t* indptr, const int32_t* doc
 int64_t bm25_n_docs(const rag_ctx* h);
 int bm25_index_bytes(const int64_t* indptr, int64_t n_docs, int64_t n_terms, int64_t* postings_out, int64_t* meta_out, int64_t* table_out);
 int bm25_grid_plan(int n_ranges_in_launch, int n_queries, int linear, int64_t* out5);
-int bm25_scores_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, double* out_dev, hipStream_t st);
+int bm25_scores_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, double* out_dev, hipStream_t st,
+                    float* raw32_dev, int64_t ld, unsigned long long* max_key_dev, int tenant);
 int bm25_scores_host(rag_ctx* h, const int32_t* term_ptr, const int32_t* terms, int Q, double* out);
 int bm25_topk_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int k, int tenant, int64_t* ids_dev,
                   int32_t* rows_dev, double* scores_dev, double* raw_max_dev, hipStream_t st);
@@ -562,24 +563,32 @@ int rag_hybrid_linear_dev(rag_handle_t h, const float* q_dev, const int32_t* ter
     // queries per sub-batch: one query tile when the all-document scores fit 8 GB (2 GB + 1 GB at 1M rows), fewer on large
     // shards (12.5M rows: 53 queries, 8 GB instead of 38 GB)
     const int QB = (int)std::max<int64_t>(16, std::min<int64_t>(256, ((int64_t)8 << 30) / (n * 12)));
-    const size_t need = stage_size((size_t)QB * n, 8) + stage_size((size_t)QB * ld, 4) + stage_size(QB, 8);
+    const size_t need = stage_size((size_t)QB * n, 8) + stage_size((size_t)QB * ld, 4) + 2 * stage_size(QB, 8) + stage_size(QB, 4) + stage_size(ld, 4);
     if (need > h->lin_ws_bytes) {
         hipFree(h->lin_ws);
         h->lin_ws = nullptr;
         h->lin_ws_bytes = 0;
         HIP_TRY(h, hipMalloc(&h->lin_ws, need));
         h->lin_ws_bytes = need;
+        HIP_TRY(h, hipMemsetAsync(h->lin_ws, 0, need, st));      // the pad rows [n, ld) of raw32 are read by the last tile: keep them 0
     }
     char* p = (char*)h->lin_ws;
     double* raw = stage_take<double>(p, (size_t)QB * n);
-    float* bias = stage_take<float>(p, (size_t)QB * ld);
+    float* raw32 = stage_take<float>(p, (size_t)QB * ld);
     double* mx = stage_take<double>(p, QB);
+    unsigned long long* max_key = stage_take<unsigned long long>(p, QB);
+    float* qscale = stage_take<float>(p, QB);
+    float* gt = (h->temporal != nullptr && gamma != 0.0) ? stage_take<float>(p, ld) : nullptr;
     for (int q0 = 0; q0 < Q; q0 += QB) {
         const int qc = std::min(QB, Q - q0);
-        int rc = bm25_scores_dev(h, term_ptr_dev + q0, terms_dev, qc, raw, st);
+        // ONE pass of the scoring kernel writes the float64 scores (exact fusion of the survivors), their float32 copy (the emission
+        // operand) and the per-query maximum; r3 re-read the 2 GB twice more (a one-workgroup-per-query max: 1.8 ms of a 4.5-ms call;
+        // a bias pass: 0.6 ms)
+        HIP_TRY(h, hipMemsetAsync(max_key, 0, (size_t)qc * sizeof(unsigned long long), st));
+        int rc = bm25_scores_dev(h, term_ptr_dev + q0, terms_dev, qc, raw, st, raw32, ld, max_key, tenant);
         if (rc) return rc;
-        if ((rc = linear_prepare(h, raw, qc, n, h->temporal, beta, gamma, mx, bias, ld, tenant, st))) return rc;
-        const dense_fused fz = {bias, ld, raw, n, mx, h->temporal, alpha, beta, gamma};
+        if ((rc = linear_prepare(h, max_key, qc, n, h->temporal, beta, gamma, mx, qscale, q0 == 0 ? gt : nullptr, ld, st))) return rc;
+        const dense_fused fz = {raw32, ld, qscale, gt, raw, n, mx, h->temporal, alpha, beta, gamma};
         rc = dense_search_fused(h, q_dev + (size_t)q0 * h->dim, qc, k, tenant, ids_out_dev + (size_t)q0 * k, rows_out_dev + (size_t)q0 * k,
                                 hybrid_out_dev + (size_t)q0 * k, st, &fz);
         if (rc) return rc;

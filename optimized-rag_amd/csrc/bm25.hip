@@ -257,6 +257,10 @@ __global__ __launch_bounds__(256) void bm25_plan_kernel(const bm_term_meta* __re
 // that every XCD owns >= 16 columns or so and the XCDs finish together. Few queries (qgroup_len = 0): range-major, the ranges
 // of one query spread over the chip. The id -> XCD rule is a performance assumption only; any placement gives the same result.
 struct bm_grid { unsigned blocks; int nr_l, n_queries, n_groups, qgroup_len, plan_t; };
+// mode 1 (all-document scores) can also hand the index-level linear fusion what it needs, in the same pass over the accumulators:
+// a float32 copy of the raw scores [q][ld] (the emission operand of the fused dense search) and the per-query maximum over the
+// tenant's documents as an orderable key (atomicMax: order-independent, so the result is the bits a sequential max gives).
+struct bm_dense_extra { float* raw32; int64_t ld; unsigned long long* max_key; };
 static bm_grid bm_make_grid(int nr_l, int Q, int linear) {
     bm_grid g{(unsigned)((int64_t)nr_l * Q), nr_l, Q, 1, 0, BM_PLAN_T};
     if (linear || Q < 128) return g;
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_num_sgpr(96))) vo
                                                                  const uint64_t* __restrict__ tau_key, int* __restrict__ part_cnt,
                                                                  const int32_t* __restrict__ tenants, int tenant,
                                                                  const int32_t* __restrict__ plan_off, const bm_plan_meta* __restrict__ plan_meta,
-                                                                 const bm_grid gm) {
+                                                                 const bm_grid gm, const bm_dense_extra dx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // workgroup -> (range, query), see bm_make_grid: XCD x (= workgroup id % 8) walks its columns (range, query group) one after the
     // other, every query of the group on the SAME range side by side, so a range's postings are fetched into that XCD's L2 once
@@ -527,7 +531,18 @@ __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_num_sgpr(96))) vo
         __syncthreads();                                     // adds done before the next batch's metadata / the select
     }
     if (mode == 1) {
-        for (int i = tid; i < lim; i += BM_THREADS) dense_out[(size_t)q * n_docs + base + i] = sc[SC_IDX(i)];
+        double m = -INFINITY;
+        for (int i = tid; i < lim; i += BM_THREADS) {
+            const double v = sc[SC_IDX(i)];
+            dense_out[(size_t)q * n_docs + base + i] = v;
+            if (dx.raw32 != nullptr) dx.raw32[(size_t)q * dx.ld + base + i] = (float)v;
+            if (dx.max_key != nullptr && (tenants == nullptr || tenants[base + i] == tenant)) m = fmax(m, v);
+        }
+        if (dx.max_key != nullptr) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+            if (lane == 0 && m > -INFINITY) atomicMax(&dx.max_key[q], (unsigned long long)f64_orderable(m));
+        }
         return;
     }
     // ---- exact top-k of sc[0..lim): radix select of the k-th largest key, ties by lower doc ------------
@@ -1040,16 +1055,16 @@ struct bm25_topk_out {
 // compacts keys >= tau. Expected survivors per stage ~ k * growth per query however large the shard is (a single
 // threshold from 32768 docs left ~k/2 per range: 38 k entries per query to merge on a 12.5M-doc shard).
 // the scoring launch: packed 4-byte postings when the index has them, the 12-byte form otherwise
-#define BM_RANGE_LAUNCH(H, IX, NR_L, NQ, ST, NR, TP, TM, K, MODE, ...)                                                             \
+#define BM_RANGE_LAUNCH(H, IX, NR_L, NQ, ST, DX, NR, TP, TM, K, MODE, ...)                                                             \
     {                                                                                                                              \
         bm_grid gm_ = bm_make_grid(NR_L, NQ, (H)->opt.bm25_linear_grid);                                                           \
         gm_.plan_t = (IX)->plan_t;                                                                                                 \
         if ((IX)->packed != nullptr)                                                                                               \
             hipLaunchKernelGGL(bm25_range_kernel<true>, dim3(gm_.blocks), dim3(BM_THREADS), BM_LDS_BYTES, ST, (IX)->meta, (IX)->doc, (IX)->w, \
-                               (IX)->packed, (IX)->gtab, (IX)->range_tab, NR, TP, TM, (IX)->n_docs, (IX)->n_terms, K, MODE, __VA_ARGS__, gm_); \
+                               (IX)->packed, (IX)->gtab, (IX)->range_tab, NR, TP, TM, (IX)->n_docs, (IX)->n_terms, K, MODE, __VA_ARGS__, gm_, DX); \
         else                                                                                                                       \
             hipLaunchKernelGGL(bm25_range_kernel<false>, dim3(gm_.blocks), dim3(BM_THREADS), BM_LDS_BYTES, ST, (IX)->meta, (IX)->doc, (IX)->w, \
-                               (IX)->packed, (IX)->gtab, (IX)->range_tab, NR, TP, TM, (IX)->n_docs, (IX)->n_terms, K, MODE, __VA_ARGS__, gm_); \
+                               (IX)->packed, (IX)->gtab, (IX)->range_tab, NR, TP, TM, (IX)->n_docs, (IX)->n_terms, K, MODE, __VA_ARGS__, gm_, DX); \
     }
 static int bm25_pick_plan_t(const rag_ctx* h, const rag_bm25_index* ix, int Q) {
     if (h->opt.bm25_plan_slots > 0) return std::min(BM_PLAN_T, h->opt.bm25_plan_slots);
@@ -1073,7 +1088,7 @@ static void bm25_launch_topk(const rag_ctx* h, const rag_bm25_index* ix, const i
     while (begin < nr) {
         int end = !staged ? nr : (stage == 0 ? first_cfg : (int)std::min<int64_t>(nr, (int64_t)begin * BM_STAGE_GROWTH));
         if (staged && nr - end < end / 4) end = nr;                   // no tiny trailing stage
-        BM_RANGE_LAUNCH(h, ix, end - begin, Q, st, nr, term_ptr_dev, terms_dev, k, 0, (double*)nullptr,
+        BM_RANGE_LAUNCH(h, ix, end - begin, Q, st, (bm_dense_extra{nullptr, 0, nullptr}), nr, term_ptr_dev, terms_dev, k, 0, (double*)nullptr,
                         w.part_key, w.part_row, begin, stage == 0 ? (const uint64_t*)nullptr : (const uint64_t*)w.tau, w.part_cnt,
                         tenants, tenant, (const int32_t*)w.plan.off, (const bm_plan_meta*)w.plan.meta)
         const int last = end == nr;
@@ -1315,7 +1330,7 @@ static int bm25_run(rag_ctx* h, rag_bm25_index* ix, const int32_t* term_ptr, con
         if (raw_max_out) HIP_TRY(h, hipMemcpyAsync(raw_max_out, mxd, (size_t)Q * sizeof(double), hipMemcpyDeviceToHost, st));
     } else {
         bm25_launch_plan(ix, tp, tm, Q, w.plan, st);
-        BM_RANGE_LAUNCH(h, ix, nr, Q, st, nr, tp, tm, k, 1, dd, (uint64_t*)nullptr, (uint32_t*)nullptr, 0,
+        BM_RANGE_LAUNCH(h, ix, nr, Q, st, (bm_dense_extra{nullptr, 0, nullptr}), nr, tp, tm, k, 1, dd, (uint64_t*)nullptr, (uint32_t*)nullptr, 0,
                         (const uint64_t*)nullptr, (int*)nullptr, (const int32_t*)nullptr, -1, (const int32_t*)w.plan.off,
                         (const bm_plan_meta*)w.plan.meta)
         HIP_TRY(h, hipGetLastError());
@@ -1425,17 +1440,22 @@ static int bm25_topk_dev_batch(rag_ctx* h, const int32_t* term_ptr_dev, const in
 
 // raw float64 scores of EVERY document for Q queries, device pointers, asynchronous: out_dev[Q][n_docs]
 // (the all-document BM25Okapi.get_scores of rag/retrieval.py:340-341, for the index-level linear fusion)
-int bm25_scores_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, double* out_dev, hipStream_t st) {
+// raw32_dev / ld / max_key_dev (all optional): see bm_dense_extra; `tenant` restricts the maximum to the tenant's documents
+int bm25_scores_dev(rag_ctx* h, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, double* out_dev, hipStream_t st,
+                    float* raw32_dev, int64_t ld, unsigned long long* max_key_dev, int tenant) {
     ARG_CHECK(h, h->bm25 != nullptr, "no BM25 index loaded");
     ARG_CHECK(h, Q > 0 && Q <= 65535 && term_ptr_dev && out_dev, "bm25_scores_dev: bad arguments");
     rag_bm25_index* ix = h->bm25;
     int rc = bm25_set_attr(h);
     if (rc) return rc;
+    const int32_t* tenants = nullptr;
+    if (max_key_dev != nullptr && (rc = bm25_tenant_args(h, ix, tenant, &tenants))) return rc;
+    const bm_dense_extra dx = {raw32_dev, ld, max_key_dev};
     if ((rc = bm25_ensure_plan(h, ix, Q))) return rc;
     const bm25_plan_ws pw = {ix->ws_plan_off, ix->ws_plan_meta};
     bm25_launch_plan(ix, term_ptr_dev, terms_dev, Q, pw, st);
-    BM_RANGE_LAUNCH(h, ix, ix->n_ranges, Q, st, ix->n_ranges, term_ptr_dev, terms_dev, 1, 1, out_dev, (uint64_t*)nullptr,
-                    (uint32_t*)nullptr, 0, (const uint64_t*)nullptr, (int*)nullptr, (const int32_t*)nullptr, -1,
+    BM_RANGE_LAUNCH(h, ix, ix->n_ranges, Q, st, dx, ix->n_ranges, term_ptr_dev, terms_dev, 1, 1, out_dev, (uint64_t*)nullptr,
+                    (uint32_t*)nullptr, 0, (const uint64_t*)nullptr, (int*)nullptr, tenants, tenants ? tenant : -1,
                     (const int32_t*)pw.off, (const bm_plan_meta*)pw.meta)
     HIP_TRY(h, hipGetLastError());
     return RAG_OK;

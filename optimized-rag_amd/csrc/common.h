@@ -233,7 +233,9 @@ int dense_search(rag_ctx* h, const float* q_dev, int Q, int k, int tenant, int64
 // linear fusion inputs of one query sub-batch (rag_hybrid_linear_dev): float32 emission bias [Q][bias_ld], float64 raw BM25
 // scores [Q][n] with their per-query divisor, per-row temporal scores (or null), the three weights
 struct dense_fused {
-    const float* bias; int64_t bias_ld;
+    const float* bias; int64_t bias_ld;          // float32 raw BM25 scores [Q][bias_ld] (written by the scoring kernel itself)
+    const float* qscale;                         // [Q] float(beta / max of the query)
+    const float* gt;                             // [bias_ld] float(gamma * temporal) or null
     const double* raw; int64_t n;
     const double* mx; const double* temporal;
     double alpha, beta, gamma;
@@ -243,8 +245,8 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
 void comm_free(rag_ctx* h);
 int hybrid_legs(rag_ctx* h, const float* q_dev, const int32_t* term_ptr_dev, const int32_t* terms_dev, int Q, int pool, int tenant,
                 int64_t* lists_dev, double* scores_ws_dev, hipStream_t st);
-int linear_prepare(rag_ctx* h, const double* raw, int Q, int64_t n, const double* temporal, double beta, double gamma, double* mx,
-                   float* bias, int64_t ld, int tenant, hipStream_t st);
+int linear_prepare(rag_ctx* h, const unsigned long long* max_key, int Q, int64_t n, const double* temporal, double beta, double gamma, double* mx,
+                   float* qscale, float* gt, int64_t ld, hipStream_t st);
 int linear_components(rag_ctx* h, const float* q_dev, const int32_t* rows_dev, int Q, int k, const dense_fused* fz, double* sem_out,
                       double* kw_out, double* tmp_out, hipStream_t st);
 int dense_free(rag_ctx* h);

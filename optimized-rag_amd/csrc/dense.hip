@@ -160,10 +160,10 @@ __device__ __forceinline__ void load_fragB(FragB& f, const char* base, const int
         int n_rows_valid, int q_valid, const float *__restrict__ tau, unsigned *__restrict__ cnt, uint64_t *__restrict__ cand, \
         const int32_t *__restrict__ tenants, int tenant, const int32_t *__restrict__ tile_list, int tile_mul, int tile_mod,    \
         int tile_cnt, const int *__restrict__ active_count, const float *__restrict__ bias, int64_t bias_ld, float alpha,      \
-        const int *__restrict__ qmap
+        const int *__restrict__ qmap, const float *__restrict__ qscale, const float *__restrict__ gt
 #define EMIT_PASS                                                                                                     \
     corpus16, q16, Dp, rtile_begin, n_rtiles, n_qtiles, n_rows_valid, q_valid, tau, cnt, cand, tenants, tenant, tile_list,    \
-        tile_mul, tile_mod, tile_cnt, active_count, bias, bias_ld, alpha, qmap
+        tile_mul, tile_mod, tile_cnt, active_count, bias, bias_ld, alpha, qmap, qscale, gt
 // one 256 x 256 tile; vb = the (virtual) block index that selects it
 template <bool DENSE0, bool SMALLQ, bool FUSED>
 __device__ __forceinline__ void dense_emit_tile(const int vb, EMIT_PARAMS) {
@@ -270,19 +270,26 @@ __device__ __forceinline__ void dense_emit_tile(const int vb, EMIT_PARAMS) {
     const float scale = 1.0f / (float)(1 << (2 * RAG_SCALE_LOG2));
     if (FUSED) {
         // accumulators -> fused score, kept in the accumulators' 2^14 scale so that the threshold / key code below is shared:
-        // acc' = acc * alpha + bias * 2^14. Each (query, row) bias element is read exactly once per pass (float4 per 4 rows).
+        // acc' = acc * alpha + (raw32[q][row] * qscale[q] + gt[row]) * 2^14 with raw32 the float32 raw BM25 score, qscale = beta / max
+        // of the query and gt[row] = gamma * temporal (round 4: the per-(query, row) bias array that held this sum - a 2-GB read and a
+        // 1-GB write per 256 queries to build - is gone; the scoring kernel writes raw32 itself). Each (query, row) element is read
+        // exactly once per pass (float4 per 4 rows); the float32 roundings are inside the emission margin (dense_search).
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int q = q0 + wn * 64 + j * 16 + fr;
             if (q >= q_valid) continue;
-            const float* brow = bias + (size_t)(qmap != nullptr ? qmap[q] : q) * bias_ld + row0 + wm * 128 + fq * 4;
+            const int qi = qmap != nullptr ? qmap[q] : q;
+            const float qs = qscale[qi];
+            const float* brow = bias + (size_t)qi * bias_ld + row0 + wm * 128 + fq * 4;
+            const float* grow = gt != nullptr ? gt + row0 + wm * 128 + fq * 4 : nullptr;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float4 b = *reinterpret_cast<const float4*>(brow + i * 16);
-                acc[i][j][0] = fmaf(acc[i][j][0], alpha, b.x * (float)(1 << (2 * RAG_SCALE_LOG2)));
-                acc[i][j][1] = fmaf(acc[i][j][1], alpha, b.y * (float)(1 << (2 * RAG_SCALE_LOG2)));
-                acc[i][j][2] = fmaf(acc[i][j][2], alpha, b.z * (float)(1 << (2 * RAG_SCALE_LOG2)));
-                acc[i][j][3] = fmaf(acc[i][j][3], alpha, b.w * (float)(1 << (2 * RAG_SCALE_LOG2)));
+                const float4 g = grow != nullptr ? *reinterpret_cast<const float4*>(grow + i * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc[i][j][0] = fmaf(acc[i][j][0], alpha, fmaf(b.x, qs, g.x) * (float)(1 << (2 * RAG_SCALE_LOG2)));
+                acc[i][j][1] = fmaf(acc[i][j][1], alpha, fmaf(b.y, qs, g.y) * (float)(1 << (2 * RAG_SCALE_LOG2)));
+                acc[i][j][2] = fmaf(acc[i][j][2], alpha, fmaf(b.z, qs, g.z) * (float)(1 << (2 * RAG_SCALE_LOG2)));
+                acc[i][j][3] = fmaf(acc[i][j][3], alpha, fmaf(b.w, qs, g.w) * (float)(1 << (2 * RAG_SCALE_LOG2)));
             }
         }
     }
@@ -797,37 +804,29 @@ __global__ __launch_bounds__(256) void overflow_gather_kernel(int* __restrict__ 
 // ---- linear fusion over the resident index (rag_hybrid_linear_dev) -------------------------------------------------------
 // rag/retrieval.py:294-322 evaluated over ALL rows: hybrid = (alpha * cosine + beta * keyword) + gamma * temporal, keyword =
 // raw BM25 / max over the corpus (1.0 when that max is <= 0), stable sort descending, [:top_k].
-// raw[Q][N] are the float64 BM25 scores of every document (bm25_range_kernel, mode 1).
-// Under a tenant filter the corpus hybrid_search was handed is the tenant's own documents (`WHERE agent_id = %s`,
-// rag/document_store.py:457), so the max is taken over the tenant's rows only - as rag_bm25_topk_* do.
-__global__ __launch_bounds__(256) void linear_max_kernel(const double* __restrict__ raw, int64_t n, double* __restrict__ mx,
-                                                          const int32_t* __restrict__ tenants, int tenant) {
-    __shared__ double part[4];
-    const double* r = raw + (size_t)blockIdx.x * n;
+// raw[Q][N] are the float64 BM25 scores of every document (bm25_range_kernel, mode 1), max_key[q] the orderable key of the largest
+// one over the tenant's documents (atomicMax in that same kernel; 0 = no document). Under a tenant filter the corpus hybrid_search
+// was handed is the tenant's own documents (`WHERE agent_id = %s`, rag/document_store.py:457), as rag_bm25_topk_* do.
+// -> mx[q] = `max_score if max_score > 0 else 1.0` (rag/retrieval.py:343-344), qscale[q] = float(beta / mx[q]) for the emission.
+__global__ void linear_scale_kernel(const unsigned long long* __restrict__ max_key, int Q, double beta, double* __restrict__ mx,
+                                    float* __restrict__ qscale) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const unsigned long long kq = max_key[q];
     double m = -INFINITY;
-    for (int64_t i = threadIdx.x; i < n; i += 256)
-        if (tenants == nullptr || tenants[i] == tenant) m = fmax(m, r[i]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmax(fmax(part[0], part[1]), fmax(part[2], part[3]));
-        mx[blockIdx.x] = m > 0.0 ? m : 1.0;                       // `max_score if max_score > 0 else 1.0`, retrieval.py:343-344
+    if (kq != 0ull) {
+        const unsigned long long u = (kq & 0x8000000000000000ull) ? (kq & 0x7fffffffffffffffull) : ~kq;
+        m = __builtin_bit_cast(double, u);
     }
+    const double d = m > 0.0 ? m : 1.0;
+    mx[q] = d;
+    qscale[q] = (float)(beta / d);
 }
 
-// float32 emission bias of every (query, row): beta * keyword + gamma * temporal (the float64 values are recomputed exactly
-// for the survivors; the float32 rounding is covered by the emission margin)
-__global__ __launch_bounds__(256) void linear_bias_kernel(const double* __restrict__ raw, const double* __restrict__ mx,
-                                                           const double* __restrict__ temporal, int64_t n, int64_t ld, double beta,
-                                                           double gamma, float* __restrict__ bias) {
-    const int q = blockIdx.y;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= ld) return;
-    float b = 0.f;
-    if (i < n) b = (float)(beta * (raw[(size_t)q * n + i] / mx[q]) + gamma * (temporal ? temporal[i] : 0.0));
-    bias[(size_t)q * ld + i] = b;
+// float32 recency term of every row for the emission: gamma * temporal (zero past the last row)
+__global__ void linear_gt_kernel(const double* __restrict__ temporal, int64_t n, int64_t ld, double gamma, float* __restrict__ gt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ld) gt[i] = i < n ? (float)(gamma * temporal[i]) : 0.f;
 }
 
 // survivors: exact[q][j] holds the float64 cosine (rescore_kernel) -> the float64 hybrid score, CPython's operation order
@@ -1028,10 +1027,14 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
     // raw / max (in [0, 1] whenever the max is positive; the raw scores themselves, all <= 0, in the `else 1.0` case of
     // rag/retrieval.py:344, where 8 covers any realistic BM25 magnitude); max|t| is tracked by rag_index_set_temporal_host.
     const double f32_mag = fz ? fabs(fz->alpha) + 8.0 * fabs(fz->beta) + fabs(fz->gamma) * h->temporal_absmax : 0.0;
-    const double eps = fz ? fabs(fz->alpha) * fp16_pass_eps(h->dim_pad) + f32_mag / 8388608.0 + 1e-7 : fp16_pass_eps(h->dim_pad);
+    // (round 4: the emitted keyword + recency term is formed in float32 from raw32 * qscale + gt: raw32, qscale and gt each carry one
+    // 2^-24 rounding, the two fmas one each - 2^-21 of the magnitude covers them with a factor of two to spare)
+    const double eps = fz ? fabs(fz->alpha) * fp16_pass_eps(h->dim_pad) + f32_mag / 2097152.0 + 1e-7 : fp16_pass_eps(h->dim_pad);
     const float two_eps = (float)(2.0 * eps * 1.0001 + 1e-7);        // float subtraction in the select kernel: round up
     const float* bias = fz ? fz->bias : nullptr;
     const int64_t bias_ld = fz ? fz->bias_ld : 0;
+    const float* qscale = fz ? fz->qscale : nullptr;
+    const float* gt = fz ? fz->gt : nullptr;
     const float alpha_f = fz ? (float)fz->alpha : 1.0f;
     const int qpad = (int)round_up(Q, RAG_TILE);
     const int n_qtiles = qpad / RAG_TILE;
@@ -1111,7 +1114,7 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
         }
 #define EMIT_ARGS(QP, NQT, QV, TAU, CNT, CAND, ACT, QMAP)                                                        \
     h->emb16, QP, h->dim_pad, begin_, n_rt_, NQT, (int)h->n_rows, QV, TAU, CNT, CAND, tenants, tenant, tile_list, tile_mul, tile_mod, \
-        n_tiles, (const int*)(ACT), bias, bias_ld, alpha_f, (const int*)(QMAP)
+        n_tiles, (const int*)(ACT), bias, bias_ld, alpha_f, (const int*)(QMAP), qscale, gt
         const int begin_ = begin, n_rt_ = n_rt;
         if (stage == 0 && fz)
             hipLaunchKernelGGL((dense_emit_kernel<true, false, true>), dim3(grid), dim3(512), DENSE_LDS_BYTES, st,
@@ -1216,10 +1219,10 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
 }
 
 // bias / max / components of the linear fusion (called by rag_hybrid_linear_dev around dense_search_fused)
-int linear_prepare(rag_ctx* h, const double* raw, int Q, int64_t n, const double* temporal, double beta, double gamma, double* mx,
-                   float* bias, int64_t ld, int tenant, hipStream_t st) {
-    hipLaunchKernelGGL(linear_max_kernel, dim3(Q), dim3(256), 0, st, raw, n, mx, tenant >= 0 ? (const int32_t*)h->tenants : (const int32_t*)nullptr, tenant);
-    hipLaunchKernelGGL(linear_bias_kernel, dim3((unsigned)((ld + 255) / 256), Q), dim3(256), 0, st, raw, mx, temporal, n, ld, beta, gamma, bias);
+int linear_prepare(rag_ctx* h, const unsigned long long* max_key, int Q, int64_t n, const double* temporal, double beta, double gamma, double* mx,
+                   float* qscale, float* gt, int64_t ld, hipStream_t st) {
+    hipLaunchKernelGGL(linear_scale_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, max_key, Q, beta, mx, qscale);
+    if (gt != nullptr) hipLaunchKernelGGL(linear_gt_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, st, temporal, n, ld, gamma, gt);
     HIP_TRY(h, hipGetLastError());
     return RAG_OK;
 }
