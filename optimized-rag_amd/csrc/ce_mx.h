@@ -126,6 +126,9 @@ __device__ __forceinline__ void mx_bdma(__amdgpu_buffer_rsrc_t rs, unsigned voff
 #ifndef MX_W_HI8
 #define MX_W_HI8(h0, h1, lo) mx_hi8(h0, h1)                   // hi8 of a weight fragment pair (4 v_perm_b32)
 #endif
+#ifndef MX_READ_A_IF
+#define MX_READ_A_IF(b) true                                  // weight fragments of block b are read from the stage (always, in the product)
+#endif
 #ifndef MX_STEP_WAIT
 #define MX_STEP_WAIT "s_waitcnt vmcnt(6)"                     // own pieces of the step have landed (six per wave and step in flight)
 #endif
@@ -201,7 +204,7 @@ __device__ __forceinline__ void mx_ksteps(f32x16 (&acc)[6], const mx_stream& S, 
             MX_BLOCK(SWAP, acc[b], wh0[b & 1], wh1[b & 1], w8, xh0, xh1, x8);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            if (b + 2 < 6) { MX_READ_A(b + 2, b & 1) }
+            if (b + 2 < 6 && MX_READ_A_IF(b + 2)) { MX_READ_A(b + 2, b & 1) }
             MX_PIECE(S, b, dst, wsrc, xsrc, ks_)
         }
 #undef MX_READ_A

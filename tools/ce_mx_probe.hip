@@ -4,7 +4,7 @@
 // Checks (a) the kernel against a float64 emulation of ITS OWN arithmetic (hi.hi + 2^-11 (lo8.hi8 + hi8.lo8) on the rounded
 // operands: validates the layout, the lane maps of both MFMA forms and the K-slot pairing) and (b) against the exact W.X^T (what
 // the scheme is worth), then times the launch with a store-nothing epilogue and with the image-layout epilogue.
-// timing experiments (WRONG results; -DMX_DIAG=<bits>): 1 = no DMA, 2 = no MFMA, 4 = no weight DMA, 8 = no token DMA, 16 = no weight-side v_perm
+// timing experiments (WRONG results; -DMX_DIAG=<bits>): 1 = no DMA, 2 = no MFMA, 4 = no weight DMA, 8 = no token DMA, 16 = no weight-side v_perm, 32 = 6-bit correction MFMA, 64 / 128 = fewer weight fragment reads (5 / 3 per step instead of 7)
 #ifndef MX_DIAG
 #define MX_DIAG 0
 #endif
@@ -23,6 +23,20 @@
 #endif
 #if MX_DIAG & 16                      // no weight-side v_perm (what a STORED weight hi8 plane would save in vector work)
 #define MX_W_HI8(h0, h1, lo) (lo)
+#endif
+#if MX_DIAG & 64                      // read the weight fragments of blocks 0, 1, 2, 3 only (4 and 5 reuse them): 5 fragment reads per step instead of 7, what a 3 x 2 wave tile would read
+#define MX_READ_A_IF(b) ((b) < 4)
+#endif
+#if MX_DIAG & 128                     // blocks 0 and 1 only: 3 reads per step
+#define MX_READ_A_IF(b) ((b) < 2)
+#endif
+#if MX_DIAG & 32                      // the correction MFMA in a 6-bit format (e2m3: half the cycles of the 8-bit one), same registers: what fp6 corrections could buy at best
+#define MX_BLOCK(SWAP, acc, wh0, wh1, w8, xh0, xh1, x8)                                                      \
+    {                                                                                                        \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, xh0, acc, 0, 0, 0);                                \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, xh1, acc, 0, 0, 0);                                \
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8, x8, acc, 2, 2, 0, MX_SCALE_A, 0, MX_SCALE_B); \
+    }
 #endif
 #include "../optimized-rag_amd/csrc/ce_mx.h"
 

@@ -15,6 +15,8 @@ Schemes (x = hi + lo, hi = fp16(x)):
   bf8tt_stream  bf8tt, and every stored activation (residual stream, ctx, FFN intermediate) read back as hi16 + lo8
   ship     bf8tt_stream with attention in split fp16 (what the first MX build shipped); ship_noplo: without the P_lo term of P.V
   shiprn   ship with hi8 rounded to NEAREST (top byte of hi + 0x80) and no gain on lo8: what ships now
+  shipfp6_<e2m3|e3m2>_<group>  the correction operands as 6-bit floats (twice the MFMA rate of 8-bit ones) under one E8M0 scale per
+           <group> consecutive K elements; lo6 = fp6(lo * 2^11 / scale) shares the scale of hi6; stored activations = hi16 + lo6
 usage: python tools/ce_numerics_sim.py [pairs] [L] [scheme,scheme...]"""
 import math
 import os
@@ -46,6 +48,29 @@ def top_byte(hi, rnd):
     return u.view(np.float16).astype(np.float64)
 
 
+def q6(v, mb, emin, vmax):
+    """round to a 6-bit float grid: mb mantissa bits, smallest normal exponent emin (below it the subnormal step), clipped to vmax"""
+    a = np.abs(v)
+    e = np.floor(np.log2(np.maximum(a, 2.0 ** emin)))
+    step = 2.0 ** (e - mb)
+    return np.clip(np.rint(v / step) * step, -vmax, vmax)
+
+
+FP6 = {"e2m3": (3, 0, 7.5), "e3m2": (2, -2, 28.0)}
+
+
+def fp6_pair(hi, lo, fmt, group):
+    """(hi6, lo6) as real values: both in one 6-bit format under ONE power-of-two scale per `group` consecutive K elements (the
+    scale byte a lane hands the block-scaled MFMA), lo carried as lo * 2^11 so it shares the scale of hi"""
+    mb, emin, vmax = FP6[fmt]
+    sh = hi.shape
+    g = hi.reshape(sh[:-1] + (sh[-1] // group, group))
+    l = (lo * 2048.0).reshape(g.shape)
+    m = np.maximum(np.abs(g).max(-1, keepdims=True), 1e-30)
+    sc = 2.0 ** np.ceil(np.log2(m / vmax))
+    return (q6(g / sc, mb, emin, vmax) * sc).reshape(sh), (q6(l / sc, mb, emin, vmax) * sc / 2048.0).reshape(sh)
+
+
 TRUNC_GAIN = 1.0 / 0.915       # mean of hi / trunc(hi) for uniformly distributed low mantissa bits
 
 
@@ -72,6 +97,10 @@ class Scheme:
             return hi, q8(lo * 2048.0 * wscale * TRUNC_GAIN, torch.float8_e5m2) / (2048.0 * wscale), top_byte(hi, False)
         if n == "shiprn":                        # ship with hi8 rounded to nearest (top byte of hi + 0x80), no gain
             return hi, q8(lo * 2048.0 * wscale, torch.float8_e5m2) / (2048.0 * wscale), top_byte(hi, True)
+        if n.startswith("shipfp6"):             # shipfp6_<fmt>_<group>: hi16 + (hi6, lo6) pairs under a per-group scale, attention in split fp16
+            _, fmt, grp = n.split("_")
+            h6, l6 = fp6_pair(hi, lo, fmt, int(grp))
+            return hi, l6, h6
         if n == "bf8t_nogain":
             return hi, q8(lo * 2048.0 * wscale, torch.float8_e4m3fn) / (2048.0 * wscale), top_byte(hi, False)
         raise ValueError(n)
@@ -81,6 +110,9 @@ class Scheme:
         if not (self.name.endswith("_stream") or self.name.startswith("ship")):
             return x
         hi = f16(x)
+        if self.name.startswith("shipfp6"):
+            _, fmt, grp = self.name.split("_")
+            return hi + fp6_pair(hi, x - hi, fmt, int(grp))[1]
         g = 1.0 if self.name == "shiprn" else TRUNC_GAIN
         return hi + q8((x - hi) * 2048.0 * g, torch.float8_e5m2) / (2048.0 * g)
 
