@@ -36,6 +36,11 @@ if have("r4m_bench.json"):
     line = [ln for ln in open(os.path.join(O, "r4m_bench.json")) if ln.startswith("{")][-1]
     json.dump(json.loads(line), open(os.path.join(P, "r04_bench_line.json"), "w"), indent=1)
 
+if have("r4m_full_line_kernel_stats.csv"):
+    shutil.copy(os.path.join(O, "r4m_full_line_kernel_stats.csv"), os.path.join(P, "r04_full_line_kernel_stats.csv"))
+    if have("r4m_full_line_bench.json") and os.path.getsize(os.path.join(O, "r4m_full_line_bench.json")) > 2:
+        json.dump(json.loads(open(os.path.join(O, "r4m_full_line_bench.json")).read()), open(os.path.join(P, "r04_full_line_bench_under_rocprof.json"), "w"), indent=1)
+
 # ---- cross-encoder: kernel stats, traffic, SQ counters of `bench.py --mode rerank`
 if have("r4m_ce_kernel_stats.csv"):
     shutil.copy(os.path.join(O, "r4m_ce_kernel_stats.csv"), os.path.join(P, "r04_ce_kernel_stats.csv"))

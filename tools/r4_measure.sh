@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-4 measurement passes (GPU box, through gpurun). Usage: bash tools/r4_measure.sh <part> ...
 #   bench    : the default bench line -> gpurun_out/r4m_bench.json
+#   fullstats: rocprofv3 --kernel-trace --stats of the default `python3 bench.py` (every block of the line) + the line of that run
 #   cestats  : rocprofv3 --kernel-trace --stats of `bench.py --mode rerank` (the cross-encoder forward of one 25,600-pair batch x steps)
 #   cepmc    : FETCH_SIZE | WRITE_SIZE passes of the same command (per-kernel HBM traffic of the forward)
 #   cesq     : three SQ-counter passes of the same command (where the waves of the MX GEMM kernels spend their cycles)
@@ -23,6 +24,11 @@ for part in "$@"; do
 case $part in
 bench)
   cd $R; echo "== default bench"; timeout -k 10 900 python bench.py > $O/r4m_bench.json 2> $O/r4m_bench.err || echo FAILED; tail -c 600 $O/r4m_bench.json; cd /tmp ;;
+fullstats)
+  echo "== kernel stats of the whole default bench line"; timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $S/full_stats -o s -- python3 $R/bench.py > $O/r4m_full_stats.log 2>&1 || echo FAILED
+  python3 $R/tools/rocpd_top.py $S/full_stats/s_results.db > $O/r4m_full_line_kernel_stats.csv
+  grep '^{' $O/r4m_full_stats.log | tail -1 > $O/r4m_full_line_bench.json
+  rm -rf $S/full_stats ;;
 cestats)
   CMD="python3 $R/bench.py --mode rerank --steps 30"
   echo "== rerank kernel stats"; timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $S/ce_stats -o s -- $CMD > $O/r4m_ce_stats.log 2>&1 || echo FAILED
