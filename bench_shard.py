@@ -130,6 +130,30 @@ def shard_blocks(eng, st, device, rank=0, world=1, steps=3, pool=100, k=20, L_pa
     blocks["hybrid_q%d" % Q] = {"queries_per_sec": round(Q / t, 1), "ms_per_batch": round(t * 1e3, 3),
                                 "workload": f"dense top-{pool} + BM25 top-{pool} + RRF -> top-{k}" +
                                             ("" if world == 1 else ", one all-gather of both lists")}
+    # the BM25 leg of that call alone on this rank's share (device time from HIP events on the launch stream), priced like the 1M-row
+    # `hybrid` block: algorithmic posting bytes against the L2 roof (the kernel is issue-bound, DESIGN 4.2: neither byte roof binds)
+    try:
+        ids_d = torch.empty((Q, pool), dtype=torch.int64, device=device)
+        sc_d = torch.empty((Q, pool), dtype=torch.float64, device=device)
+        eng.bm25_topk_dev(st["ptr_d"], st["terms_d"], pool, ids_d, None, sc_d)
+        torch.cuda.synchronize()
+        eng.set_profiling(True)
+        for _ in range(steps):
+            eng.bm25_topk_dev(st["ptr_d"], st["terms_d"], pool, ids_d, None, sc_d)
+        torch.cuda.synchronize()
+        bm_ms, bm_spans = eng.stage_kernel_ms(1)
+        eng.set_profiling(False)
+        counts = np.diff(st["post"].indptr)
+        tq = np.asarray(st["terms"])
+        tq = tq[(tq >= 0) & (tq < counts.shape[0])]
+        bm_bytes = float(counts[tq].sum()) * 12.0
+        leg = bm_ms / max(1, bm_spans)
+        blocks["hybrid_q%d" % Q]["bm25_leg"] = {
+            "ms_per_batch_on_this_share": round(leg, 3), "algorithmic_bytes": bm_bytes,
+            "l2_roof_frac": round(bm_bytes / (leg * 1e-3) / 1e9 / BM.PEAK_L2_GBS, 4),
+            "bound": "issue (vector + scalar ALU of bm25_range_kernel; postings served by the L2s)"}
+    except Exception as e:                                   # a secondary figure must not cost the line
+        blocks["hybrid_q%d" % Q]["bm25_leg"] = {"error": repr(e)[:200]}
     if with_rerank:
         pipe = ShardedPipeline(eng, rank=rank, world=world)
 
@@ -142,6 +166,20 @@ def shard_blocks(eng, st, device, rank=0, world=1, steps=3, pool=100, k=20, L_pa
         blocks["retrieve_rerank_q%d" % Q] = {"queries_per_sec": round(Q / t, 2), "ms_per_batch": round(t * 1e3, 2),
                                              "workload": f"hybrid top-{pool} -> MiniLM-L-6 cross-encoder (L={L_pair}, pairs split over the "
                                                          f"ranks) -> top-{k}"}
+        if world == 1:
+            # algorithmic FLOPs of the scored pairs (SURVEY 8d per-pair formula on their real token counts) over the WHOLE batch time,
+            # retrieval included: a lower bound of the forward's own fraction (the headline block prices the forward alone)
+            try:
+                res = run()
+                torch.cuda.synchronize()
+                plens, _ = token_lengths(res[3].cpu().numpy().reshape(-1), st["total_rows"], device, st["cfg"]["vocab_size"])
+                plen = np.minimum(16 + plens.astype(np.float64) + 3, L_pair)
+                flops = float((6.0 * plen * (3.539e6 + 1536.0 * plen)).sum())
+                blocks["retrieve_rerank_q%d" % Q]["mfma_roof_frac_of_the_whole_batch"] = round(flops / t / 1e12 / BE.PEAK_MFMA_TFLOPS, 4)
+                blocks["retrieve_rerank_q%d" % Q]["algorithmic_flops_per_batch"] = flops
+            except Exception as e:
+                blocks["retrieve_rerank_q%d" % Q]["mfma_roof_frac_of_the_whole_batch"] = None
+                blocks["retrieve_rerank_q%d" % Q]["roofline_error"] = repr(e)[:200]
         # BASELINE.json's second metric on this configuration: p50 latency of ONE query through retrieve + rerank (every rank
         # searches its shard, the 100 pairs are split over the ranks), synchronised per call, max over the ranks per call
         q1, ptr1 = q[:1].contiguous(), st["ptr_d"][:2].contiguous()
