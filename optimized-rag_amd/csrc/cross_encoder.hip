@@ -30,6 +30,7 @@
 //   ce_pool_classify   tanh(Wp.x_cls + bp) -> wc.pooled + bc, fp32
 #include "common.h"
 #include "ce_mx.h"
+#include <type_traits>
 
 #include <cmath>
 #include <cstdlib>
@@ -1099,6 +1100,13 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
             ce_dma_at(vf16 + g0 + (size_t)c * 512, sv_hi + c * 1024);
             ce_dma_at(vf16 + g0 + kv_plane + (size_t)c * 512, sv_lo + c * 1024);
         }
+        // an odd tile count leaves the second half of the last 32-key block outside the pair: P is 0 there (masked keys), V must be
+        // finite - the never-staged tile is zeroed once instead of selecting zeros at every fragment read (DIRECT reads the next
+        // pair's rows or the zeroed slack of the buffer there: finite too)
+        if ((nt & 1) && wv == 0) {
+            *reinterpret_cast<u32x4*>(sv_hi + nt * 1024 + lane * 16) = (u32x4){0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(sv_lo + nt * 1024 + lane * 16) = (u32x4){0u, 0u, 0u, 0u};
+        }
     }
     const size_t row0 = (size_t)po;
     const int qb0 = wv * QB;
@@ -1136,23 +1144,26 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
         __syncthreads();
     }
     if (!has_rows) return;
-    for (int kb = 0; kb < nkb; ++kb) {
+    // v_med3_f32(a, b, +inf) = max(a, b): fmaxf on MFMA results costs a canonicalising v_max x, x per input (15 instructions for 8
+    // scores where 7 do); the +inf sits in a scalar register the compiler cannot fold
+    float ce_inf;
+    asm volatile("s_mov_b32 %0, 0x7f800000" : "=s"(ce_inf));
+#define CE_MAX2(a_, b_) __builtin_amdgcn_fmed3f(a_, b_, ce_inf)
+    // one 32-key block; EDGE (the pair's last block only: the loop is peeled) masks the keys past the pair's length
+    auto key_block = [&](const int kb, auto edge_c) {
+        constexpr bool EDGE = decltype(edge_c)::value;
         const int fo = kb * 2048 + lane * 16;
         const half8 k0h = *reinterpret_cast<const half8*>(k_hi + fo), k1h = *reinterpret_cast<const half8*>(k_hi + fo + 1024);
         const half8 k0l = *reinterpret_cast<const half8*>(k_lo + fo), k1l = *reinterpret_cast<const half8*>(k_lo + fo + 1024);
-        // V fragment = the lane's 4 key slots of tile 2kb | of tile 2kb+1 (tile = [d half][lane][4 slots], 512 B per half)
+        // V fragment = the lane's 4 key slots of tile 2kb | of tile 2kb+1 (tile = [d half][lane][4 slots], 512 B per half); tile 2kb+1
+        // of an odd-count pair is zeros (LDS) or another pair's finite rows (DIRECT) under P = 0
         const int vo = kb * 2048 + lane * 8;
-        const half4 z4 = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
-        const bool half2 = kb * 32 + 16 < Lp;      // else tile 2kb+1 is not this pair's (never staged): P is 0 there, V must be finite
-        const half4 a0h = *reinterpret_cast<const half4*>(v_hi + vo), a1h = *reinterpret_cast<const half4*>(v_hi + vo + 512);
-        const half4 a0l = *reinterpret_cast<const half4*>(v_lo + vo), a1l = *reinterpret_cast<const half4*>(v_lo + vo + 512);
-        const half4 b0h = half2 ? *reinterpret_cast<const half4*>(v_hi + vo + 1024) : z4;
-        const half4 b1h = half2 ? *reinterpret_cast<const half4*>(v_hi + vo + 1536) : z4;
-        const half4 b0l = half2 ? *reinterpret_cast<const half4*>(v_lo + vo + 1024) : z4;
-        const half4 b1l = half2 ? *reinterpret_cast<const half4*>(v_lo + vo + 1536) : z4;
+        const half4 a0h = *reinterpret_cast<const half4*>(v_hi + vo), b0h = *reinterpret_cast<const half4*>(v_hi + vo + 1024);
+        const half4 a1h = *reinterpret_cast<const half4*>(v_hi + vo + 512), b1h = *reinterpret_cast<const half4*>(v_hi + vo + 1536);
+        const half4 a0l = *reinterpret_cast<const half4*>(v_lo + vo), b0l = *reinterpret_cast<const half4*>(v_lo + vo + 1024);
+        const half4 a1l = *reinterpret_cast<const half4*>(v_lo + vo + 512), b1l = *reinterpret_cast<const half4*>(v_lo + vo + 1536);
         const half8 v0h = __builtin_shufflevector(a0h, b0h, 0, 1, 2, 3, 4, 5, 6, 7), v1h = __builtin_shufflevector(a1h, b1h, 0, 1, 2, 3, 4, 5, 6, 7);
         const half8 v0l = __builtin_shufflevector(a0l, b0l, 0, 1, 2, 3, 4, 5, 6, 7), v1l = __builtin_shufflevector(a1l, b1l, 0, 1, 2, 3, 4, 5, 6, 7);
-        const bool edge = (kb + 1) * 32 > len;
 #pragma unroll
         for (int b = 0; b < QB; ++b) {
             f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
@@ -1163,17 +1174,17 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
             z0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, qh[b], z0, 0, 0, 0);
             z1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, qh[b], z1, 0, 0, 0);
             // lane (fr, fq): z0[r] = S[query fr][key kb*32 + fq*4 + r], z1[r] = same + 16
-            if (edge) {
+            if (EDGE) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (kb * 32 + fq * 4 + r >= len) z0[r] = -INFINITY;
                     if (kb * 32 + 16 + fq * 4 + r >= len) z1[r] = -INFINITY;
                 }
             }
-            float mx = fmaxf(fmaxf(fmaxf(z0[0], z0[1]), fmaxf(z0[2], z0[3])), fmaxf(fmaxf(z1[0], z1[1]), fmaxf(z1[2], z1[3])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrun[b], mx);                  // finite: key 0 is always real
+            float mx = CE_MAX2(CE_MAX2(CE_MAX2(z0[0], z0[1]), CE_MAX2(z0[2], z0[3])), CE_MAX2(CE_MAX2(z1[0], z1[1]), CE_MAX2(z1[2], z1[3])));
+            mx = CE_MAX2(mx, __shfl_xor(mx, 16));
+            mx = CE_MAX2(mx, __shfl_xor(mx, 32));
+            const float mnew = CE_MAX2(mrun[b], mx);                // finite: key 0 is always real
             const float alpha = __builtin_amdgcn_exp2f((mrun[b] - mnew) * cs);
             mrun[b] = mnew;
             const float off = -mnew * cs;
@@ -1201,7 +1212,10 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
             c0[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0h, ph, c0[b], 0, 0, 0);
             c1[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1h, ph, c1[b], 0, 0, 0);
         }
-    }
+    };
+    for (int kb = 0; kb + 1 < nkb; ++kb) key_block(kb, std::false_type{});
+    key_block(nkb - 1, std::true_type{});
+#undef CE_MAX2
     // lane (fr, fq): c0[r] = ctx[query fr][d = fq*4 + r], c1[r] = d + 16; the row sum is spread over the 4 fq lanes
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
