@@ -287,13 +287,54 @@ typedef unsigned mx_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ size_t mx_img_base(int64_t m, int k, int nk) { return ((size_t)(m >> 7) * nk + (k >> 5)) * MX_B_STAGE; }
 
 // four consecutive features of one token -> 4 halfs (hi) + 4 bytes (lo8)
+typedef short mx_s2 __attribute__((ext_vector_type(2)));
+typedef float mx_f2 __attribute__((ext_vector_type(2)));
+#ifndef MX_HI8_TRUNCATE
+// Two vector instructions per element instead of four, same bits (tools/cvt_probe.hip: 1M pairs incl. ties, saturation, denormals):
+// v - hi as ONE v_fma_mix_f32 (fp16 operand, times a -1.0 the compiler cannot fold into a subtraction that needs a conversion first),
+// and the 2^11 scaling inside v_cvt_scalef32_pk_bf8_f32 (scale 2^-11 = the block scale of the value it encodes).
+__device__ __forceinline__ void mx_split4(float v0, float v1, float v2, float v3, mx_u2& hi, unsigned& lo) {
+    const half4 h = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+    hi = __builtin_bit_cast(mx_u2, h);
+    float neg1;
+    asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(neg1));
+    const float l0 = __builtin_fmaf((float)h[0], neg1, v0), l1 = __builtin_fmaf((float)h[1], neg1, v1);
+    const float l2 = __builtin_fmaf((float)h[2], neg1, v2), l3 = __builtin_fmaf((float)h[3], neg1, v3);
+    mx_s2 r = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32((mx_s2){0, 0}, l0, l1, 1.0f / MX_LO_SCALE, false);
+    r = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(r, l2, l3, 1.0f / MX_LO_SCALE, true);
+    lo = __builtin_bit_cast(unsigned, r);
+}
+// hi + lo8 / 2^11 for four elements: the byte pairs convert two at a time, the power-of-two scale rides in the fma (exact product:
+// one rounding, the bits of the two-step form)
+__device__ __forceinline__ void mx_join4(half4 hi, unsigned lo, float (&out)[4]) {
+    const mx_f2 a = __builtin_amdgcn_cvt_pk_f32_bf8((int)lo, false), b = __builtin_amdgcn_cvt_pk_f32_bf8((int)lo, true);
+    out[0] = __builtin_fmaf(a[0], 1.0f / MX_LO_SCALE, (float)hi[0]);
+    out[1] = __builtin_fmaf(a[1], 1.0f / MX_LO_SCALE, (float)hi[1]);
+    out[2] = __builtin_fmaf(b[0], 1.0f / MX_LO_SCALE, (float)hi[2]);
+    out[3] = __builtin_fmaf(b[1], 1.0f / MX_LO_SCALE, (float)hi[3]);
+}
+#else
 __device__ __forceinline__ void mx_split4(float v0, float v1, float v2, float v3, mx_u2& hi, unsigned& lo) {
     const half4 h = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
     hi = __builtin_bit_cast(mx_u2, h);
     int r = __builtin_amdgcn_cvt_pk_bf8_f32((v0 - (float)h[0]) * MX_LO_SCALE, (v1 - (float)h[1]) * MX_LO_SCALE, 0, false);
     lo = (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32((v2 - (float)h[2]) * MX_LO_SCALE, (v3 - (float)h[3]) * MX_LO_SCALE, r, true);
 }
+__device__ __forceinline__ void mx_join4(half4 hi, unsigned lo, float (&out)[4]) {
+    out[0] = (float)hi[0] + mx_lo_decode(lo & 0xFF);
+    out[1] = (float)hi[1] + mx_lo_decode((lo >> 8) & 0xFF);
+    out[2] = (float)hi[2] + mx_lo_decode((lo >> 16) & 0xFF);
+    out[3] = (float)hi[3] + mx_lo_decode(lo >> 24);
+}
+#endif
 __device__ __forceinline__ float mx_join(half_t hi, unsigned lo8) { return (float)hi + mx_lo_decode(lo8); }
+// v - hi for four elements as v_fma_mix_f32 (see mx_split4): the fp16 operand needs no conversion instruction of its own
+__device__ __forceinline__ half4 mx_resid4(half4 h, float v0, float v1, float v2, float v3) {
+    float neg1;
+    asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(neg1));
+    return (half4){(half_t)__builtin_fmaf((float)h[0], neg1, v0), (half_t)__builtin_fmaf((float)h[1], neg1, v1),
+                   (half_t)__builtin_fmaf((float)h[2], neg1, v2), (half_t)__builtin_fmaf((float)h[3], neg1, v3)};
+}
 
 // v_permlane32_swap: lane l < 32 and lane l + 32 exchange so that BOTH end up with {a of the lower lane | ... }:
 // returns (x, y) with  lower lane: x = its own a, y = the upper lane's a;  upper lane: x = the lower lane's b, y = its own b
@@ -461,7 +502,7 @@ struct mx_epi_qkv {
                     const float4 bv = *reinterpret_cast<const float4*>(bias + ft * MX_TM + head * 32 + 8 * q + 4 * hh);
                     const float v0 = acc[b][q * 4] + bv.x, v1 = acc[b][q * 4 + 1] + bv.y, v2 = acc[b][q * 4 + 2] + bv.z, v3 = acc[b][q * 4 + 3] + bv.w;
                     const half4 hi = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
-                    const half4 lo = {(half_t)(v0 - (float)hi[0]), (half_t)(v1 - (float)hi[1]), (half_t)(v2 - (float)hi[2]), (half_t)(v3 - (float)hi[3])};
+                    const half4 lo = mx_resid4(hi, v0, v1, v2, v3);
                     __builtin_nontemporal_store(hi, reinterpret_cast<half4*>(tile + q * 128));
                     __builtin_nontemporal_store(lo, reinterpret_cast<half4*>(tile + q * 128 + kv_plane));
                 }
@@ -477,7 +518,7 @@ struct mx_epi_qkv {
                 for (int q = 0; q < 4; ++q) {
                     const float v0 = acc[b][q * 4] + bv, v1 = acc[b][q * 4 + 1] + bv, v2 = acc[b][q * 4 + 2] + bv, v3 = acc[b][q * 4 + 3] + bv;
                     const half4 hi = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
-                    const half4 lo = {(half_t)(v0 - (float)hi[0]), (half_t)(v1 - (float)hi[1]), (half_t)(v2 - (float)hi[2]), (half_t)(v3 - (float)hi[3])};
+                    const half4 lo = mx_resid4(hi, v0, v1, v2, v3);
                     half_t* o = vf16 + ((((size_t)head * m_tiles16 + (m0 >> 4) + (q >> 1)) * 2 + (li >> 4)) * 64 + (2 * (q & 1) + hh) * 16 + (li & 15)) * 4;
                     __builtin_nontemporal_store(hi, reinterpret_cast<half4*>(o));
                     __builtin_nontemporal_store(lo, reinterpret_cast<half4*>(o + kv_plane));
@@ -554,10 +595,12 @@ struct mx_epi_ln {
                 const float4 bv = *reinterpret_cast<const float4*>(bias + f0 + 8 * q + 4 * hh);
                 const half4 rh = *reinterpret_cast<const half4*>(img + ((q >> 1) * 2 + (q & 1)) * MX_B_PLANE + trow * 16 + hh * 8);
                 const unsigned rl = (q & 1) ? l1[q >> 1] : l0[q >> 1];
-                acc[b][q * 4] += bv.x + mx_join(rh[0], rl & 0xFF);
-                acc[b][q * 4 + 1] += bv.y + mx_join(rh[1], (rl >> 8) & 0xFF);
-                acc[b][q * 4 + 2] += bv.z + mx_join(rh[2], (rl >> 16) & 0xFF);
-                acc[b][q * 4 + 3] += bv.w + mx_join(rh[3], rl >> 24);
+                float res[4];
+                mx_join4(rh, rl, res);
+                acc[b][q * 4] += bv.x + res[0];
+                acc[b][q * 4 + 1] += bv.y + res[1];
+                acc[b][q * 4 + 2] += bv.z + res[2];
+                acc[b][q * 4 + 3] += bv.w + res[3];
                 sm += (acc[b][q * 4] + acc[b][q * 4 + 1]) + (acc[b][q * 4 + 2] + acc[b][q * 4 + 3]);
             }
         }
