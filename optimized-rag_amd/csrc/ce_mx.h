@@ -214,7 +214,8 @@ __device__ __forceinline__ void mx_ksteps(f32x16 (&acc)[6], const mx_stream& S, 
 // EPI functor: called once per finished tile with the 6 accumulator blocks of the wave.
 //   acc[b][r]: SWAP = false: feature ft*384 + wm*192 + b*32 + (r&3) + 8*(r>>2) + 4*(lane>>5), token tt*128 + wn*32 + (lane&31)
 //              SWAP = true : feature ft*384 + wm*192 + b*32 + (lane&31), token tt*128 + wn*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)
-// The functor may use `scratch` (MX_LDS .. 160 KiB) and must not touch the ring. swap_for(ft) picks the operand order per tile.
+// The functor may use `scratch` (MX_LDS .. MX_KERNEL_LDS: 2 KiB of exchange space, then MX_PARAM_OFF.. for what prepare() staged) and must
+// not touch the ring. prepare(scratch) runs once per workgroup before the first tile. swap_for(ft) picks the operand order per tile.
 template <class EPI>
 __device__ __forceinline__ void mx_gemm_loop(const char* __restrict__ W, const char* __restrict__ X, int nk, int n_ft,
                                              int n_tt, char* smem, EPI& epi) {
@@ -245,6 +246,11 @@ __device__ __forceinline__ void mx_gemm_loop(const char* __restrict__ W, const c
 #pragma unroll
         for (int k = 0; k < 6; ++k) MX_PIECE(S, k, st_, S.w_cur, S.x_cur, (unsigned)u)
     }
+    // the epilogue's per-feature parameters (bias, LayerNorm weights) go to LDS once per workgroup, under the prologue's DMA latency:
+    // a tile's epilogue then reads them with ds_read_b128 instead of 24-72 global float4 loads per thread
+    epi.prepare(smem + MX_LDS);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    MX_BAR
     for (bool first = true;; first = false) {
         {
             mx_tile_iter nx = it;
@@ -280,6 +286,10 @@ __device__ __forceinline__ void mx_gemm_loop(const char* __restrict__ W, const c
 // =====================================================================================================================
 // Epilogues and kernels of the MX forward (hidden = 384: one feature tile IS the hidden state, so LayerNorm stays on the CU)
 // =====================================================================================================================
+#define MX_PARAM_OFF 2048                          // scratch bytes [0, 2048): LayerNorm row statistics; parameters from here on (<= 6 KiB)
+__device__ __forceinline__ void mx_stage_params(float* dst, const float* __restrict__ src, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
 typedef unsigned mx_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned mx_u4 __attribute__((ext_vector_type(4)));
 
@@ -481,7 +491,9 @@ struct mx_epi_qkv {
     const int32_t* row_map;
     int n_map;
     __device__ __forceinline__ bool swap_for(int ft) const { return ft + ft_base == 2; }
-    __device__ __forceinline__ void operator()(f32x16 (&acc)[6], int tt, int ft_launch, bool swap, char*) const {
+    __device__ __forceinline__ void prepare(char* scratch) const { mx_stage_params(reinterpret_cast<float*>(scratch + MX_PARAM_OFF), bias, 3 * MX_TM); }
+    __device__ __forceinline__ void operator()(f32x16 (&acc)[6], int tt, int ft_launch, bool swap, char* scratch) const {
+        const float* const bias = reinterpret_cast<const float*>(scratch + MX_PARAM_OFF);      // the staged copy
         const int ft = ft_launch + ft_base;
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wm = wid >> 2, wn = wid & 3;
         const int li = lane & 31, hh = lane >> 5;
@@ -529,7 +541,7 @@ struct mx_epi_qkv {
 };
 
 // ---- FFN up-projection: bias + erf-GELU -> h8 (image layout, K = ffn for the down-projection)
-__device__ __forceinline__ float mx_gelu(float x) {     // as ce_gelu (cross_encoder.hip): A&S 7.1.26, |erf error| <= 1.5e-7
+__device__ __forceinline__ float mx_gelu(float x) {     // erf as ce_gelu (cross_encoder.hip): A&S 7.1.26, |erf error| <= 1.5e-7
     const float z = fabsf(x) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
@@ -538,14 +550,19 @@ __device__ __forceinline__ float mx_gelu(float x) {     // as ce_gelu (cross_enc
     p = fmaf(p, t, 0.254829592f);
     const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
     const float erf_abs = fmaf(-p * t, e, 1.0f);
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+    // x/2 (1 + sign(x) erf|z|) = x/2 + |x/2| erf|z|: one multiply and one fma (|.| is an operand modifier) where the literal form
+    // takes a bit-field insert, an add and two multiplies; one rounding less
+    const float hx = 0.5f * x;
+    return fmaf(fabsf(hx), erf_abs, hx);
 }
 struct mx_epi_gelu {
     char* h8;
     const float* bias;
     int nk_out;                    // K-steps of the consumer = ffn / 32
     __device__ __forceinline__ bool swap_for(int) const { return false; }
-    __device__ __forceinline__ void operator()(f32x16 (&acc)[6], int tt, int ft, bool, char*) const {
+    __device__ __forceinline__ void prepare(char* scratch) const { mx_stage_params(reinterpret_cast<float*>(scratch + MX_PARAM_OFF), bias, nk_out * 32); }
+    __device__ __forceinline__ void operator()(f32x16 (&acc)[6], int tt, int ft, bool, char* scratch) const {
+        const float* const bias = reinterpret_cast<const float*>(scratch + MX_PARAM_OFF);      // the staged copy
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wm = wid >> 2, wn = wid & 3;
         const int trow = wn * 32 + (lane & 31), hh = lane >> 5;
         char* tile = h8 + (size_t)tt * nk_out * MX_B_STAGE;
@@ -572,8 +589,16 @@ struct mx_epi_ln {
     const float *bias, *gamma, *beta;
     float eps;
     __device__ __forceinline__ bool swap_for(int) const { return false; }
+    __device__ __forceinline__ void prepare(char* scratch) const {
+        float* p = reinterpret_cast<float*>(scratch + MX_PARAM_OFF);
+        mx_stage_params(p, bias, 384);
+        mx_stage_params(p + 384, gamma, 384);
+        mx_stage_params(p + 768, beta, 384);
+    }
     __device__ __forceinline__ void operator()(f32x16 (&acc)[6], int tt, int, bool, char* scratch) const {
         constexpr int H = 384;
+        const float* const bias = reinterpret_cast<const float*>(scratch + MX_PARAM_OFF);      // the staged copies
+        const float *const gamma = bias + 384, *const beta = bias + 768;
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wm = wid >> 2, wn = wid & 3;
         const int li = lane & 31, hh = lane >> 5, trow = wn * 32 + li;
         char* tile = x8 + (size_t)tt * (H / 32) * MX_B_STAGE;
@@ -644,4 +669,4 @@ __global__ __launch_bounds__(512) void mx_gemm_kernel(const char* __restrict__ W
     const int n_tt = (m_packed[0] + MX_TN - 1) / MX_TN;
     mx_gemm_loop(W, X, nk, n_ft, n_tt, smem, epi);
 }
-#define MX_KERNEL_LDS (MX_LDS + 4096)
+#define MX_KERNEL_LDS (MX_LDS + MX_PARAM_OFF + 6144)      // 155,648 B: ring + exchange space + staged parameters (<= 1536 floats)

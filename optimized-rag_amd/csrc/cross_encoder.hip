@@ -68,7 +68,7 @@ struct rag_ce_model {
     float* logits = nullptr;
     // the MX forward (ce_mx.h: hi16 + lo8 operands) has a workspace of its own: it runs the large batches, the split-fp16 kernels
     // above the small ones (their tiles are finer), and neither path must size or evict the other's buffers
-    bool mx_ok = false;                                // the shape allows the MX path (hidden 384, ffn a multiple of 384) and its weights are loaded
+    bool mx_ok = false;                                // the shape allows the MX path (hidden 384, ffn a multiple of 384 up to 1536) and its weights are loaded
     struct MxWs {
         int pairs = 0, L = 0;
         int64_t tokens = 0;                            // padded rows (a multiple of 256)
@@ -1456,7 +1456,7 @@ static int ce_load_model(rag_ctx* h, const rag_ce_config* cfg, const float* cons
     if ((rc = up_f32(h, m, T[3], H, &m->emb_ln_g))) return rc;
     if ((rc = up_f32(h, m, T[4], H, &m->emb_ln_b))) return rc;
     m->layers.resize(cfg->layers);
-    m->mx_ok = H == MX_TM && F % MX_TM == 0;           // one feature tile = the hidden state (LayerNorm in the epilogue)
+    m->mx_ok = H == MX_TM && F % MX_TM == 0 && F <= 1536;    // one feature tile = the hidden state (LayerNorm in the epilogue); the FFN bias is staged in 6 KiB of LDS
     for (int l = 0; l < cfg->layers; ++l) {
         const float* const* t = T + 5 + 16 * l;
         auto& ly = m->layers[l];

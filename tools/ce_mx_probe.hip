@@ -54,6 +54,7 @@ struct epi_f32 {          // verification: C[token][feature] fp32
     int N;
     bool want_swap;
     __device__ bool swap_for(int) const { return want_swap; }
+    __device__ void prepare(char*) const {}
     __device__ void operator()(f32x16 (&acc)[6], int tt, int ft, bool swap, char*) const {
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wm = wid >> 2, wn = wid & 3;
 #pragma unroll
@@ -71,6 +72,7 @@ struct epi_f32 {          // verification: C[token][feature] fp32
 struct epi_none {         // timing: main loop only
     float* sink;
     __device__ bool swap_for(int) const { return false; }
+    __device__ void prepare(char*) const {}
     __device__ void operator()(f32x16 (&acc)[6], int, int, bool, char*) const {
         if (acc[0][0] == 12345.678f) sink[0] = acc[1][1] + acc[2][2] + acc[3][3] + acc[4][4] + acc[5][5];
     }
@@ -81,6 +83,7 @@ struct epi_img {          // timing + layout check: + bias -> image layout of th
     const float* bias;
     int N;
     __device__ bool swap_for(int) const { return false; }
+    __device__ void prepare(char*) const {}
     __device__ void operator()(f32x16 (&acc)[6], int tt, int ft, bool, char*) const {
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wm = wid >> 2, wn = wid & 3;
         const int t = wn * 32 + (lane & 31), hh = lane >> 5;
