@@ -19,10 +19,13 @@
 // consecutive bytes = 8 whole lines, and a fragment read is conflict-free without a swizzle):
 //   a ROW TILE is 384 rows for weights (MX_TM: all features a workgroup owns), 128 rows for activations (MX_TN tokens);
 //   tensor = [row tile][K-step s = k / 32][plane c = 0..5][row in tile][16 B]
-//   planes 0..3: hi16, plane 2*j + h holds elements k%32 = 16*j + 8*h + i (i = 0..7) as 8 halfs - the fragment of lane half h
-//                for the j-th v_mfma_f32_32x32x16_f16 of the step;
-//   planes 4..5: lo8, plane 4 + h byte p = (i >> 2) * 8 + j * 4 + (i & 3) holds element 16*j + 8*h + i - the order in which
-//                v_perm_b32 leaves the top bytes of the lane's two fp16 fragments.
+//   planes 0..3: hi16, plane 2*j + h holds elements k%32 = 16*j + 8*(i >> 2) + 4*h + (i & 3) (i = 0..7) as 8 halfs - the fragment
+//                of lane half h for the j-th v_mfma_f32_32x32x16_f16 of the step. (A K permutation inside each 16-element chunk,
+//                the same for both operands: it makes lane half h of a 32 x 32 ACCUMULATOR - features 8q + 4h + r of a block - the
+//                owner of whole 16-B fragments of the next GEMM's operand, so epilogues store and re-read the image without a
+//                lane exchange.)
+//   planes 4..5: lo8, plane 4 + h byte p = (i >> 2) * 8 + j * 4 + (i & 3) holds the element of fragment (j, h) position i - the order
+//                in which v_perm_b32 leaves the top bytes of the lane's two fp16 fragments.
 // A stage (one K-step of a 384 x 128 tile) is 36 KiB of weights + 12 KiB of tokens; three stages = 144 KiB.
 #pragma once
 #include "common.h"
@@ -48,12 +51,14 @@ typedef int mx_v4i __attribute__((ext_vector_type(4)));
 #define MX_SCALE_B 127
 
 // byte offset of element (row r of the tile, column k % 32 = e) inside one K-step image with `rows` rows per plane
+// element e of a K-step -> MFMA j = e >> 4, lane half h = (e >> 2) & 1, fragment position i = 4 * ((e >> 3) & 1) + (e & 3)
 __host__ __device__ __forceinline__ int mx_hi_off(int rows, int r, int e) {
-    return ((e >> 4) * 2 + ((e >> 3) & 1)) * rows * 16 + r * 16 + (e & 7) * 2;
+    const int j = e >> 4, h = (e >> 2) & 1, i = ((e >> 3) & 1) * 4 + (e & 3);
+    return (j * 2 + h) * rows * 16 + r * 16 + i * 2;
 }
 __host__ __device__ __forceinline__ int mx_lo_off(int rows, int r, int e) {
-    const int i = e & 7;
-    return (4 + ((e >> 3) & 1)) * rows * 16 + r * 16 + (i >> 2) * 8 + (e >> 4) * 4 + (i & 3);
+    const int j = e >> 4, h = (e >> 2) & 1, i = ((e >> 3) & 1) * 4 + (e & 3);
+    return (4 + h) * rows * 16 + r * 16 + (i >> 2) * 8 + j * 4 + (i & 3);
 }
 
 // fp16 bit pattern -> e5m2 byte, round to nearest even on the magnitude (a carry into the exponent is the right result)
@@ -346,39 +351,22 @@ __device__ __forceinline__ half4 mx_resid4(half4 h, float v0, float v1, float v2
                    (half_t)__builtin_fmaf((float)h[2], neg1, v2), (half_t)__builtin_fmaf((float)h[3], neg1, v3)};
 }
 
-// v_permlane32_swap: lane l < 32 and lane l + 32 exchange so that BOTH end up with {a of the lower lane | ... }:
-// returns (x, y) with  lower lane: x = its own a, y = the upper lane's a;  upper lane: x = the lower lane's b, y = its own b
-__device__ __forceinline__ void mx_pair_swap(unsigned a, unsigned b, unsigned& x, unsigned& y) {
-    const mx_u2 s = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-    x = s[0];
-    y = s[1];
-}
-
 #ifndef MX_STORE16
 #define MX_STORE16(p, v) *reinterpret_cast<mx_u4*>(p) = (v)
 #endif
-// Stores one 32-feature block of a NON-swapped accumulator tile (+ the values in v[16], already biased / activated) into the image
+// Stores one 32-feature block of a NON-swapped accumulator tile (the values in v[16], already biased / activated) into the image
 // layout of the next GEMM's token operand: row `trow` of the tile image `img` (K-step = this block's 32 features).
-// v[4q + e] = feature 8q + 4hh + e of the block. The two lane halves exchange so that every lane stores whole 16-B chunks:
-// lane half 0 the chunks of q = 0, 2 and lo plane 4, lane half 1 those of q = 1, 3 and lo plane 5.
+// v[4q + r] = feature 8q + 4hh + r of the block = position 4 (q & 1) + r of fragment (j = q >> 1, h = hh): the lane owns the whole
+// 16 B of planes hh, 2 + hh and 4 + hh of its row - three 16-B stores, no exchange with the other lane half.
 __device__ __forceinline__ void mx_store_block(char* img, int trow, int hh, const float (&v)[16]) {
     mx_u2 hi[4];
     unsigned lo[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) mx_split4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3], hi[q], lo[q]);
-    // fragment (j = q >> 1, h = q & 1) is plane 2j + h; the lane's 8 B sit at byte 8 * hh of the row's 16
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        unsigned c0, c1, c2, c3;
-        mx_pair_swap(hi[2 * j][0], hi[2 * j + 1][0], c0, c2);
-        mx_pair_swap(hi[2 * j][1], hi[2 * j + 1][1], c1, c3);
-        MX_STORE16(img + (2 * j + hh) * MX_B_PLANE + trow * 16, ((mx_u4){c0, c1, c2, c3}));
-    }
-    // lo plane 4 + h: the lane's bytes hh*8 .. +8 = (j = 0: q = h) then (j = 1: q = 2 + h)
-    unsigned c0, c1, c2, c3;
-    mx_pair_swap(lo[0], lo[1], c0, c2);
-    mx_pair_swap(lo[2], lo[3], c1, c3);
-    MX_STORE16(img + (4 + hh) * MX_B_PLANE + trow * 16, ((mx_u4){c0, c1, c2, c3}));
+    MX_STORE16(img + hh * MX_B_PLANE + trow * 16, ((mx_u4){hi[0][0], hi[0][1], hi[1][0], hi[1][1]}));
+    MX_STORE16(img + (2 + hh) * MX_B_PLANE + trow * 16, ((mx_u4){hi[2][0], hi[2][1], hi[3][0], hi[3][1]}));
+    // lo byte p = (i >> 2) * 8 + j * 4 + (i & 3): dword (q & 1) * 2 + (q >> 1) holds the four bytes of q
+    MX_STORE16(img + (4 + hh) * MX_B_PLANE + trow * 16, ((mx_u4){lo[0], lo[2], lo[1], lo[3]}));
 }
 
 // ---- weights: fp32 [N][K] (nn.Linear) -> image layout [N / 384][K / 32][36 KiB]
@@ -446,12 +434,14 @@ __global__ __launch_bounds__(256) void mx_embed_ln_kernel(const int32_t* __restr
               (v[3] - mean) * rstd * g0.w + b0.w, h0, l0);
     mx_split4((v[4] - mean) * rstd * g1.x + b1.x, (v[5] - mean) * rstd * g1.y + b1.y, (v[6] - mean) * rstd * g1.z + b1.z,
               (v[7] - mean) * rstd * g1.w + b1.w, h1, l1);
-    // chunk c = features 8c..8c+7: K-step c >> 2, fragment j = (c >> 1) & 1, lane half h = c & 1
-    const int j = (c >> 1) & 1, h = c & 1, trow = (int)(row & 127);
-    char* img = x8 + mx_img_base(row, c * 8, H / 32);
-    *reinterpret_cast<mx_u4*>(img + (2 * j + h) * MX_B_PLANE + trow * 16) = (mx_u4){h0[0], h0[1], h1[0], h1[1]};
-    *reinterpret_cast<unsigned*>(img + (4 + h) * MX_B_PLANE + trow * 16 + j * 4) = l0;
-    *reinterpret_cast<unsigned*>(img + (4 + h) * MX_B_PLANE + trow * 16 + 8 + j * 4) = l1;
+    // chunk c = features 8c..8c+7: K-step c >> 2, MFMA j = (c >> 1) & 1; its first four features are positions 4 (c & 1) .. of the
+    // fragment of lane half 0, the other four the same positions of lane half 1 (mx_hi_off / mx_lo_off)
+    const int j = (c >> 1) & 1, u = c & 1, trow = (int)(row & 127);
+    char* img = x8 + mx_img_base(row, c * 8, H / 32) + trow * 16;
+    *reinterpret_cast<mx_u2*>(img + (2 * j) * MX_B_PLANE + u * 8) = h0;
+    *reinterpret_cast<mx_u2*>(img + (2 * j + 1) * MX_B_PLANE + u * 8) = h1;
+    *reinterpret_cast<unsigned*>(img + 4 * MX_B_PLANE + u * 8 + j * 4) = l0;
+    *reinterpret_cast<unsigned*>(img + 5 * MX_B_PLANE + u * 8 + j * 4) = l1;
 }
 
 // Row pair_off[p] of one or two (b may be null) image-layout tensors with nk K-steps -> row p of their compact counterparts (one row per pair); also
@@ -612,14 +602,16 @@ struct mx_epi_ln {
         for (int b = 0; b < 6; ++b) {
             const int f0 = wm * 192 + b * 32;
             const char* img = tile + (size_t)(f0 >> 5) * MX_B_STAGE;
-            // the lane's residual bytes: hi 8 B of fragment (j, h) at byte 8hh; lo 4 B of plane 4 + h at byte 8hh + 4j
-            const mx_u2 l0 = *reinterpret_cast<const mx_u2*>(img + 4 * MX_B_PLANE + trow * 16 + hh * 8);      // h = 0: q = 0 | q = 2
-            const mx_u2 l1 = *reinterpret_cast<const mx_u2*>(img + 5 * MX_B_PLANE + trow * 16 + hh * 8);      // h = 1: q = 1 | q = 3
+            // the lane's residual: the 16 B of planes hh, 2 + hh (hi: q = 2j | q = 2j + 1) and 4 + hh (lo dwords: q = 0, 2, 1, 3)
+            const half8 r0 = *reinterpret_cast<const half8*>(img + hh * MX_B_PLANE + trow * 16);
+            const half8 r1 = *reinterpret_cast<const half8*>(img + (2 + hh) * MX_B_PLANE + trow * 16);
+            const mx_u4 rl4 = *reinterpret_cast<const mx_u4*>(img + (4 + hh) * MX_B_PLANE + trow * 16);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bv = *reinterpret_cast<const float4*>(bias + f0 + 8 * q + 4 * hh);
-                const half4 rh = *reinterpret_cast<const half4*>(img + ((q >> 1) * 2 + (q & 1)) * MX_B_PLANE + trow * 16 + hh * 8);
-                const unsigned rl = (q & 1) ? l1[q >> 1] : l0[q >> 1];
+                const half8 rj = (q >> 1) ? r1 : r0;
+                const half4 rh = (q & 1) ? (half4){rj[4], rj[5], rj[6], rj[7]} : (half4){rj[0], rj[1], rj[2], rj[3]};
+                const unsigned rl = rl4[(q & 1) * 2 + (q >> 1)];
                 float res[4];
                 mx_join4(rh, rl, res);
                 acc[b][q * 4] += bv.x + res[0];

@@ -1225,16 +1225,16 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
         const float inv = 1.0f / l;
         if ((qb0 + b) * 16 >= Lp || qb0 + b >= max_qblocks) break;
         if (MX) {
-            // K-step = head; c0 = dims 4fq..4fq+3 (fragment j = 0), c1 = 16 + the same (j = 1); lane half h = fq >> 1, i = 4 (fq & 1) + r
+            // K-step = head; c0 = dims 4fq..4fq+3 (MFMA j = 0), c1 = 16 + the same (j = 1); lane half h = fq & 1, position 4 (fq >> 1) + r
             const int64_t mrow = (int64_t)row0 + (qb0 + b) * 16 + fr;
-            char* img = reinterpret_cast<char*>(ctx16) + mx_img_base(mrow, head * 32, hidden >> 5) + (int)(mrow & 127) * 16 + (fq & 1) * 8;
+            char* img = reinterpret_cast<char*>(ctx16) + mx_img_base(mrow, head * 32, hidden >> 5) + (int)(mrow & 127) * 16 + (fq >> 1) * 8;
             mx_u2 h0, h1;
             unsigned l0, l1;
             mx_split4(c0[b][0] * inv, c0[b][1] * inv, c0[b][2] * inv, c0[b][3] * inv, h0, l0);
             mx_split4(c1[b][0] * inv, c1[b][1] * inv, c1[b][2] * inv, c1[b][3] * inv, h1, l1);
-            *reinterpret_cast<mx_u2*>(img + (fq >> 1) * MX_B_PLANE) = h0;
-            *reinterpret_cast<mx_u2*>(img + (2 + (fq >> 1)) * MX_B_PLANE) = h1;
-            *reinterpret_cast<mx_u2*>(img + (4 + (fq >> 1)) * MX_B_PLANE) = (mx_u2){l0, l1};
+            *reinterpret_cast<mx_u2*>(img + (fq & 1) * MX_B_PLANE) = h0;
+            *reinterpret_cast<mx_u2*>(img + (2 + (fq & 1)) * MX_B_PLANE) = h1;
+            *reinterpret_cast<mx_u2*>(img + (4 + (fq & 1)) * MX_B_PLANE) = (mx_u2){l0, l1};
             continue;
         }
         half_t* o = ctx16 + (row0 + (qb0 + b) * 16 + fr) * (2 * hidden) + head * 64 + fq * 4;
