@@ -383,65 +383,87 @@ __global__ void mx_pack_weight_kernel(const float* __restrict__ w, int N, int K,
         (unsigned char)mx_e5m2_rn((unsigned)__builtin_bit_cast(unsigned short, l));
 }
 
-// ---- embeddings + LayerNorm -> x8 (hidden = 384 = 48 chunks of 8 features: lanes 0..47 of the token's wave own one chunk each)
+// ---- embeddings + LayerNorm -> x8 (hidden = 384 = 48 chunks of 8 features: lanes 0..47 of the token's wave own one chunk each).
+// A workgroup owns 16 consecutive packed rows (four per wave) and assembles their image rows in LDS first: a token's 1152 B are
+// 4-8 B pieces spread over 72 (K-step, plane) rows of the image, which written straight from the waves were 192 partial-line stores
+// per token (1.05 ms per 362 k rows, under 1 TB/s); from LDS every (K-step, plane) leaves as 16 rows x 16 B = 256 contiguous bytes.
+#define MX_EMB_ROWS 16
 __global__ __launch_bounds__(256) void mx_embed_ln_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ tt,
                                                            const float* __restrict__ word, const float* __restrict__ pos,
                                                            const float* __restrict__ type, const float* __restrict__ g,
                                                            const float* __restrict__ b, const int32_t* __restrict__ m_packed,
                                                            const int32_t* __restrict__ row_pair, const int32_t* __restrict__ pair_off,
                                                            int L, int vocab, float eps, char* __restrict__ x8) {
-    constexpr int H = 384;
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= m_packed[0]) return;
-    const int pr = row_pair[row];
-    const int p = (int)row - pair_off[pr];
-    const size_t src = (size_t)pr * L + p;
-    int id = ids[src];
-    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-    const int ty = tt[src] != 0;
+    constexpr int H = 384, NK = H / 32;
+    __shared__ __attribute__((aligned(16))) char tile[NK * 6 * MX_EMB_ROWS * 16];       // [K-step][plane][row][16 B] = 18 KiB
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * MX_EMB_ROWS;
+    const int n_rows = m_packed[0];
+    if (base >= n_rows) return;
     const bool on = lane < H / 8;
     const int c = on ? lane : 0;
-    float v[8];
-    {
-        const float4* wp = reinterpret_cast<const float4*>(word + (size_t)id * H + c * 8);
-        const float4* tp = reinterpret_cast<const float4*>(type + (size_t)ty * H + c * 8);
-        const float4* pp = reinterpret_cast<const float4*>(pos + (size_t)p * H + c * 8);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const float4 a = wp[u], t4 = tp[u], q = pp[u];
-            v[u * 4] = a.x + t4.x + q.x; v[u * 4 + 1] = a.y + t4.y + q.y; v[u * 4 + 2] = a.z + t4.z + q.z; v[u * 4 + 3] = a.w + t4.w + q.w;
-        }
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += on ? v[i] : 0.f;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s * (1.0f / H);
-    float qd = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { const float d = v[i] - mean; qd += on ? d * d : 0.f; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) qd += __shfl_xor(qd, o);
-    const float rstd = 1.0f / sqrtf(qd * (1.0f / H) + eps);
-    if (!on) return;
     const float4 g0 = *reinterpret_cast<const float4*>(g + c * 8), g1 = *reinterpret_cast<const float4*>(g + c * 8 + 4);
     const float4 b0 = *reinterpret_cast<const float4*>(b + c * 8), b1 = *reinterpret_cast<const float4*>(b + c * 8 + 4);
-    mx_u2 h0, h1;
-    unsigned l0, l1;
-    mx_split4((v[0] - mean) * rstd * g0.x + b0.x, (v[1] - mean) * rstd * g0.y + b0.y, (v[2] - mean) * rstd * g0.z + b0.z,
-              (v[3] - mean) * rstd * g0.w + b0.w, h0, l0);
-    mx_split4((v[4] - mean) * rstd * g1.x + b1.x, (v[5] - mean) * rstd * g1.y + b1.y, (v[6] - mean) * rstd * g1.z + b1.z,
-              (v[7] - mean) * rstd * g1.w + b1.w, h1, l1);
     // chunk c = features 8c..8c+7: K-step c >> 2, MFMA j = (c >> 1) & 1; its first four features are positions 4 (c & 1) .. of the
     // fragment of lane half 0, the other four the same positions of lane half 1 (mx_hi_off / mx_lo_off)
-    const int j = (c >> 1) & 1, u = c & 1, trow = (int)(row & 127);
-    char* img = x8 + mx_img_base(row, c * 8, H / 32) + trow * 16;
-    *reinterpret_cast<mx_u2*>(img + (2 * j) * MX_B_PLANE + u * 8) = h0;
-    *reinterpret_cast<mx_u2*>(img + (2 * j + 1) * MX_B_PLANE + u * 8) = h1;
-    *reinterpret_cast<unsigned*>(img + 4 * MX_B_PLANE + u * 8 + j * 4) = l0;
-    *reinterpret_cast<unsigned*>(img + 5 * MX_B_PLANE + u * 8 + j * 4) = l1;
+    const int j = (c >> 1) & 1, u = c & 1;
+    char* const my = tile + (c >> 2) * 6 * MX_EMB_ROWS * 16;
+#pragma unroll
+    for (int r4 = 0; r4 < MX_EMB_ROWS / 4; ++r4) {
+        const int rl = wv * (MX_EMB_ROWS / 4) + r4;
+        const int64_t row = base + rl;
+        if (row >= n_rows) break;                            // wave-uniform
+        const int pr = row_pair[row];
+        const int p = (int)row - pair_off[pr];
+        const size_t src = (size_t)pr * L + p;
+        int id = ids[src];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const int ty = tt[src] != 0;
+        float v[8];
+        {
+            const float4* wp = reinterpret_cast<const float4*>(word + (size_t)id * H + c * 8);
+            const float4* tp = reinterpret_cast<const float4*>(type + (size_t)ty * H + c * 8);
+            const float4* pp = reinterpret_cast<const float4*>(pos + (size_t)p * H + c * 8);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4 a = wp[q], t4 = tp[q], qq = pp[q];
+                v[q * 4] = a.x + t4.x + qq.x; v[q * 4 + 1] = a.y + t4.y + qq.y; v[q * 4 + 2] = a.z + t4.z + qq.z; v[q * 4 + 3] = a.w + t4.w + qq.w;
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += on ? v[i] : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * (1.0f / H);
+        float qd = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = v[i] - mean; qd += on ? d * d : 0.f; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) qd += __shfl_xor(qd, o);
+        const float rstd = 1.0f / sqrtf(qd * (1.0f / H) + eps);
+        if (on) {
+            mx_u2 h0, h1;
+            unsigned l0, l1;
+            mx_split4((v[0] - mean) * rstd * g0.x + b0.x, (v[1] - mean) * rstd * g0.y + b0.y, (v[2] - mean) * rstd * g0.z + b0.z,
+                      (v[3] - mean) * rstd * g0.w + b0.w, h0, l0);
+            mx_split4((v[4] - mean) * rstd * g1.x + b1.x, (v[5] - mean) * rstd * g1.y + b1.y, (v[6] - mean) * rstd * g1.z + b1.z,
+                      (v[7] - mean) * rstd * g1.w + b1.w, h1, l1);
+            char* o = my + rl * 16;                          // + plane * MX_EMB_ROWS * 16
+            *reinterpret_cast<mx_u2*>(o + (2 * j) * MX_EMB_ROWS * 16 + u * 8) = h0;
+            *reinterpret_cast<mx_u2*>(o + (2 * j + 1) * MX_EMB_ROWS * 16 + u * 8) = h1;
+            *reinterpret_cast<unsigned*>(o + 4 * MX_EMB_ROWS * 16 + u * 8 + j * 4) = l0;
+            *reinterpret_cast<unsigned*>(o + 5 * MX_EMB_ROWS * 16 + u * 8 + j * 4) = l1;
+        }
+    }
+    __syncthreads();
+    // the 16 rows sit in one 128-row image tile (16 | 128): (K-step, plane) rows of 256 contiguous bytes
+    const int trow0 = (int)(base & 127);
+    char* const out = x8 + (size_t)(base >> 7) * NK * MX_B_STAGE + trow0 * 16;
+    for (int i = threadIdx.x; i < NK * 6 * MX_EMB_ROWS; i += 256) {
+        const int sp = i >> 4, r = i & (MX_EMB_ROWS - 1);
+        if (base + r < n_rows) *reinterpret_cast<mx_u4*>(out + (size_t)sp * MX_B_PLANE + r * 16) = *reinterpret_cast<const mx_u4*>(tile + i * 16);
+    }
 }
 
 // Row pair_off[p] of one or two (b may be null) image-layout tensors with nk K-steps -> row p of their compact counterparts (one row per pair); also

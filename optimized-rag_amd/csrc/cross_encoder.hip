@@ -1782,7 +1782,7 @@ static int mx_forward_chunk(rag_ctx* h, rag_ce_model* m, int P, int L, hipStream
     }
     hipLaunchKernelGGL(ce_pack_scan_kernel, dim3(1), dim3(1024), 0, st, lens_dev, P, L, w.pair_off, w.m_packed);
     hipLaunchKernelGGL(ce_pack_rows_kernel, dim3((unsigned)((Mp + 255) / 256)), dim3(256), 0, st, (const int32_t*)w.pair_off, P, L, Mp, w.row_pair);
-    hipLaunchKernelGGL(mx_embed_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const int32_t*)w.ids, (const int32_t*)w.tt,
+    hipLaunchKernelGGL(mx_embed_ln_kernel, dim3((unsigned)((M + MX_EMB_ROWS - 1) / MX_EMB_ROWS)), dim3(256), 0, st, (const int32_t*)w.ids, (const int32_t*)w.tt,
                        (const float*)m->word, (const float*)m->pos, (const float*)m->type, (const float*)m->emb_ln_g, (const float*)m->emb_ln_b,
                        (const int32_t*)w.m_packed, (const int32_t*)w.row_pair, (const int32_t*)w.pair_off, L, m->cfg.vocab_size, eps, w.x8);
     static const unsigned n_cu = [] { int d = 0, n = 0; hipGetDevice(&d); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return (unsigned)(n >= 8 ? n / 8 * 8 : 256); }();
