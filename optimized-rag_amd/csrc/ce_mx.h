@@ -619,7 +619,7 @@ struct mx_epi_ln {
         const float* pr_sum = reinterpret_cast<const float*>(scratch) + (wid ^ 4) * 32;
         const float* pr_sq = reinterpret_cast<const float*>(scratch) + 256 + (wid ^ 4) * 32;
         // v = acc + bias + residual, in place in the accumulators
-        float sm = 0.f;
+        float sm = 0.f, sq = 0.f;
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             const int f0 = wm * 192 + b * 32;
@@ -641,22 +641,23 @@ struct mx_epi_ln {
                 acc[b][q * 4 + 2] += bv.z + res[2];
                 acc[b][q * 4 + 3] += bv.w + res[3];
                 sm += (acc[b][q * 4] + acc[b][q * 4 + 1]) + (acc[b][q * 4 + 2] + acc[b][q * 4 + 3]);
+                sq = fmaf(acc[b][q * 4], acc[b][q * 4], sq);
+                sq = fmaf(acc[b][q * 4 + 1], acc[b][q * 4 + 1], sq);
+                sq = fmaf(acc[b][q * 4 + 2], acc[b][q * 4 + 2], sq);
+                sq = fmaf(acc[b][q * 4 + 3], acc[b][q * 4 + 3], sq);
             }
         }
-        // row statistics: a token's 384 features = 2 lane halves x 2 feature-half waves x 96 registers; two passes (mean, centred squares)
+        // row statistics: a token's 384 features = 2 lane halves x 2 feature-half waves x 96 registers. ONE pass (sum and sum of squares
+        // in fp32: the stream's rows have |mean| << rms, the cancellation in E[x^2] - mean^2 costs ~1e-6 of the variance) and ONE
+        // exchange with the other feature-half wave; the scratch is rewritten only after the >= 12 K-step barriers of the next tile
         sm += __shfl_xor(sm, 32);
-        if (hh == 0) st_sum[li] = sm;
+        sq += __shfl_xor(sq, 32);
+        if (hh == 0) { st_sum[li] = sm; st_sq[li] = sq; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         MX_BAR
         const float mu = (sm + pr_sum[li]) * (1.0f / H);
-        float sq = 0.f;
-#pragma unroll
-        for (int b = 0; b < 6; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const float d = acc[b][r] - mu; sq += d * d; }
-        sq += __shfl_xor(sq, 32);
-        if (hh == 0) st_sq[li] = sq;
-        MX_BAR
-        const float rs = 1.0f / sqrtf((sq + pr_sq[li]) * (1.0f / H) + eps);
+        const float var = fmaxf(fmaf(-mu, mu, (sq + pr_sq[li]) * (1.0f / H)), 0.f);
+        const float rs = 1.0f / sqrtf(var + eps);
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             const int f0 = wm * 192 + b * 32;
@@ -665,14 +666,13 @@ struct mx_epi_ln {
             for (int q = 0; q < 4; ++q) {
                 const float4 gv = *reinterpret_cast<const float4*>(gamma + f0 + 8 * q + 4 * hh);
                 const float4 be = *reinterpret_cast<const float4*>(beta + f0 + 8 * q + 4 * hh);
-                v[q * 4] = (acc[b][q * 4] - mu) * rs * gv.x + be.x;
-                v[q * 4 + 1] = (acc[b][q * 4 + 1] - mu) * rs * gv.y + be.y;
-                v[q * 4 + 2] = (acc[b][q * 4 + 2] - mu) * rs * gv.z + be.z;
-                v[q * 4 + 3] = (acc[b][q * 4 + 3] - mu) * rs * gv.w + be.w;
+                v[q * 4] = fmaf(acc[b][q * 4] - mu, rs * gv.x, be.x);
+                v[q * 4 + 1] = fmaf(acc[b][q * 4 + 1] - mu, rs * gv.y, be.y);
+                v[q * 4 + 2] = fmaf(acc[b][q * 4 + 2] - mu, rs * gv.z, be.z);
+                v[q * 4 + 3] = fmaf(acc[b][q * 4 + 3] - mu, rs * gv.w, be.w);
             }
             mx_store_block(tile + (size_t)(f0 >> 5) * MX_B_STAGE, trow, hh, v);
         }
-        MX_BAR                                                    // the statistics scratch is reused by the next tile
     }
 };
 
