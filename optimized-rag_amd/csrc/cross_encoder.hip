@@ -1870,7 +1870,10 @@ static int ce_run(rag_ctx* h, rag_ce_model* m, const int32_t* ids, const int32_t
     // ~2M tokens of activations per chunk (~30 GB). Option ce_chunk_tokens (diagnostic) shrinks it so that parity tests can run
     // the multi-chunk loop on small inputs.
     const int64_t chunk_tokens = h->opt.ce_chunk_tokens >= 32 ? h->opt.ce_chunk_tokens : 2'000'000;
-    const int chunk = std::max(1, std::min(P, (int)(chunk_tokens / L)));
+    // equal chunks: 25,600 pairs at L = 256 go as 4 x 6,400 and not 3 x 7,812 + 2,164 (a small last chunk leaves the persistent
+    // GEMM workgroups of its one-feature-tile kernels 12-or-13 tiles each: 6 % of that chunk idle)
+    const int chunk_max = std::max(1, std::min(P, (int)(chunk_tokens / L)));
+    const int chunk = (P + (P + chunk_max - 1) / chunk_max - 1) / ((P + chunk_max - 1) / chunk_max);
     // Which forward: the MX kernels (hi16 + lo8 operands, 384 x 128 tiles; ce_mx.h) whenever the SHAPE allows (hidden 384, ffn a multiple
     // of 384), the split-fp16 kernels for every other model. Option ce_mx: -1 = never (1 = always, the same as the default today).
     const bool use_mx = m->mx_ok && L >= 32 && h->opt.ce_mx >= 0 && (h->opt.ce_mx > 0 || (int64_t)P * L >= MX_MIN_ROWS);

@@ -24,10 +24,10 @@ def stats(name):
 
 
 def short(k):
-    for s in ("mx_gemm_kernel<mx_epi_qkv", "mx_gemm_kernel<mx_epi_ln", "mx_gemm_kernel<mx_epi_gelu", "ce_attention_kernelILi2ELb1ELb0", "ce_attention_kernelILi1ELb1ELb1",
+    for s in ("mx_gemm_kernel<mx_epi_qkv", "mx_gemm_kernel<mx_epi_ln", "mx_gemm_kernel<mx_epi_gelu", "ce_attention_kernelILi2ELb1ELb0", "ce_attention_kernelILi1ELb1ELb0", "ce_attention_kernelILi1ELb1ELb1",
               "mx_embed_ln_kernel", "mx_pool_classify_kernel", "mx_gather_rows_kernel", "ce_pack", "ce_pad"):
         if s in k:
-            return {"ce_attention_kernelILi2ELb1ELb0": "ce_attention_kernel<2, MX>", "ce_attention_kernelILi1ELb1ELb1": "ce_attention_kernel<1, MX, DIRECT> ([CLS] block of the last layer)"}.get(s, s + (">" if "<" in s else ""))
+            return {"ce_attention_kernelILi2ELb1ELb0": "ce_attention_kernel<2, MX>", "ce_attention_kernelILi1ELb1ELb0": "ce_attention_kernel<1, MX>", "ce_attention_kernelILi1ELb1ELb1": "ce_attention_kernel<1, MX, DIRECT> ([CLS] block of the last layer)"}.get(s, s + (">" if "<" in s else ""))
     return k[:60]
 
 
