@@ -47,7 +47,7 @@ def test_minilm_golden_logits(eng, golden_dir):
     assert np.abs(sg - se).max() < SCORE_TOL
 
 
-@pytest.mark.parametrize("P,L", [(3, 32), (5, 64), (2, 200), (1, 512), (7, 100)])
+@pytest.mark.parametrize("P,L", [(3, 32), (5, 64), (2, 200), (1, 512), (7, 100), (2, 300)])
 def test_minilm_shapes_vs_oracle(eng, P, L):
     cfg = B.minilm_config()
     w = B.seeded_weights(cfg, 99)
