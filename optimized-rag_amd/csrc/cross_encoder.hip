@@ -1051,6 +1051,7 @@ __global__ __launch_bounds__(256) void ce_layernorm_kernel(const float* __restri
 // stored in that slot order, so P goes registers -> MFMA without touching LDS. Online (flash-style) softmax over
 // 32-key blocks in the exp2 domain; key blocks past the pair's length are skipped, the boundary block is masked.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t ce_pk(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
@@ -1182,8 +1183,18 @@ __global__ __launch_bounds__(1024) void ce_attention_kernel(const half_t* __rest
                 }
             }
             float mx = CE_MAX2(CE_MAX2(CE_MAX2(z0[0], z0[1]), CE_MAX2(z0[2], z0[3])), CE_MAX2(CE_MAX2(z1[0], z1[1]), CE_MAX2(z1[2], z1[3])));
-            mx = CE_MAX2(mx, __shfl_xor(mx, 16));
-            mx = CE_MAX2(mx, __shfl_xor(mx, 32));
+            // lane ^ 16 and lane ^ 32 by v_permlane16_swap / v_permlane32_swap of (mx, copy of mx): after the swap the two registers hold
+            // the lane's own value and its partner's (tools/permlane_probe.hip) - no LDS round trip on the softmax's critical path. The
+            // instructions are issued by hand: through the builtins this compiler folds the swap's second result into its first when both
+            // feed one expression, and the maximum silently becomes "the value of lane group 0".
+            {
+                float cp = mx;
+                asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(mx), "+v"(cp));
+                mx = CE_MAX2(mx, cp);
+                cp = mx;
+                asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(mx), "+v"(cp));
+                mx = CE_MAX2(mx, cp);
+            }
             const float mnew = CE_MAX2(mrun[b], mx);                // finite: key 0 is always real
             const float alpha = __builtin_amdgcn_exp2f((mrun[b] - mnew) * cs);
             mrun[b] = mnew;
