@@ -530,22 +530,37 @@ __global__ __launch_bounds__(256) void select_kernel(uint64_t* __restrict__ cand
 // K3: float64 cosine of shortlisted rows. One wave per (query, candidate).
 // cos = dot / (sqrt(|q|^2) * sqrt(|c|^2)), 0.0 when a norm is 0 or not finite (rag/retrieval.py:362-371).
 // ------------------------------------------------------------------------------------------------
+// |q|^2 of a query the way exact_cosine_wave accumulates and reduces it (same lane partition, same butterfly: the same bits), for
+// callers that score many rows against one query
+__device__ __forceinline__ double exact_norm2_wave(const float* __restrict__ qv, int dim, int lane) {
+    double nq = 0.0;
+    for (int i = lane * 4; i < dim; i += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(qv + i);
+        nq += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nq += __shfl_xor(nq, o);
+    return nq;
+}
+// KNOWN_NQ: |q|^2 comes from exact_norm2_wave (a third of the float64 work and of the cross-lane steps per row less)
+template <bool KNOWN_NQ = false>
 __device__ __forceinline__ double exact_cosine_wave(const float* __restrict__ qv, const float* __restrict__ cv, int dim,
-                                                    int lane) {
+                                                    int lane, double nq_known = 0.0) {
     double dot = 0.0, nq = 0.0, nc = 0.0;
     for (int i = lane * 4; i < dim; i += 256) {
         const float4 a = *reinterpret_cast<const float4*>(qv + i);
         const float4 c = *reinterpret_cast<const float4*>(cv + i);
         dot += (double)a.x * c.x + (double)a.y * c.y + (double)a.z * c.z + (double)a.w * c.w;
-        nq += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
+        if (!KNOWN_NQ) nq += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
         nc += (double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z + (double)c.w * c.w;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         dot += __shfl_xor(dot, o);
-        nq += __shfl_xor(nq, o);
+        if (!KNOWN_NQ) nq += __shfl_xor(nq, o);
         nc += __shfl_xor(nc, o);
     }
+    if (KNOWN_NQ) nq = nq_known;
     const bool ok = (nq > 0.0) && (nq < 1e300) && (nc > 0.0) && (nc < 1e300);
     return ok ? dot / (sqrt(nq) * sqrt(nc)) : 0.0;
 }
@@ -556,9 +571,11 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
     const int q = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int m = n_sorted[q];
+    if ((int)(blockIdx.x * 4 + (threadIdx.x >> 6)) >= m) return;       // (wave-uniform) nothing for this wave
+    const double nq = exact_norm2_wave(q32 + (size_t)q * dim, dim, lane);
     for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < m; j += gridDim.x * 4) {
         const uint32_t row = key_row(cand[(size_t)q * RAG_CAND_CAP + j]);
-        const double c = exact_cosine_wave(q32 + (size_t)q * dim, emb32 + (size_t)row * dim, dim, lane);
+        const double c = exact_cosine_wave<true>(q32 + (size_t)q * dim, emb32 + (size_t)row * dim, dim, lane, nq);
         if (lane == 0) exact[(size_t)q * RAG_CAND_CAP + j] = c;
     }
 }
@@ -1172,7 +1189,7 @@ int dense_search_fused(rag_ctx* h, const float* q_dev, int Q, int k, int tenant,
         HIP_TRY(h, hipGetLastError());
     }
 
-    hipLaunchKernelGGL(rescore_kernel, dim3(16, Q), dim3(256), 0, st, q_dev, h->emb32, h->cand, h->n_sorted, h->exact, h->dim);
+    hipLaunchKernelGGL(rescore_kernel, dim3(4, Q), dim3(256), 0, st, q_dev, h->emb32, h->cand, h->n_sorted, h->exact, h->dim);
     if (fz)
         hipLaunchKernelGGL(linear_fuse_kernel, dim3(4, Q), dim3(256), 0, st, h->cand, h->n_sorted, h->exact, fz->raw, fz->n, fz->mx,
                            fz->temporal, fz->alpha, fz->beta, fz->gamma);
