@@ -641,22 +641,26 @@ struct mx_epi_ln {
                 acc[b][q * 4 + 2] += bv.z + res[2];
                 acc[b][q * 4 + 3] += bv.w + res[3];
                 sm += (acc[b][q * 4] + acc[b][q * 4 + 1]) + (acc[b][q * 4 + 2] + acc[b][q * 4 + 3]);
-                sq = fmaf(acc[b][q * 4], acc[b][q * 4], sq);
-                sq = fmaf(acc[b][q * 4 + 1], acc[b][q * 4 + 1], sq);
-                sq = fmaf(acc[b][q * 4 + 2], acc[b][q * 4 + 2], sq);
-                sq = fmaf(acc[b][q * 4 + 3], acc[b][q * 4 + 3], sq);
             }
         }
-        // row statistics: a token's 384 features = 2 lane halves x 2 feature-half waves x 96 registers. ONE pass (sum and sum of squares
-        // in fp32: the stream's rows have |mean| << rms, the cancellation in E[x^2] - mean^2 costs ~1e-6 of the variance) and ONE
-        // exchange with the other feature-half wave; the scratch is rewritten only after the >= 12 K-step barriers of the next tile
-        sm += __shfl_xor(sm, 32);
-        sq += __shfl_xor(sq, 32);
-        if (hh == 0) { st_sum[li] = sm; st_sq[li] = sq; }
+        // row statistics: a token's 384 features = 2 lane halves x 2 feature-half waves x 96 registers. Every lane takes the mean and the
+        // centred sum of squares of ITS 96 values (no cancellation whatever the row's mean is), the four parts are combined pairwise
+        // (Chan et al.: M2 = M2_a + M2_b + (m_a - m_b)^2 n / 2 for equal counts n): ONE exchange with the other feature-half wave and one
+        // barrier per tile; the scratch is rewritten only after the >= 12 K-step barriers of the next tile
+        const float m_l = sm * (1.0f / 96.0f);
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = acc[b][r] - m_l; sq = fmaf(d, d, sq); }
+        const float m_o = __shfl_xor(m_l, 32), sq_o = __shfl_xor(sq, 32);
+        const float m_w = 0.5f * (m_l + m_o);                                  // this wave's 192 features of the row
+        const float sq_w = (sq + sq_o) + (m_l - m_o) * (m_l - m_o) * 48.0f;
+        if (hh == 0) { st_sum[li] = m_w; st_sq[li] = sq_w; }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         MX_BAR
-        const float mu = (sm + pr_sum[li]) * (1.0f / H);
-        const float var = fmaxf(fmaf(-mu, mu, (sq + pr_sq[li]) * (1.0f / H)), 0.f);
+        const float m_p = pr_sum[li], sq_p = pr_sq[li];
+        const float mu = 0.5f * (m_w + m_p);
+        const float var = ((sq_w + sq_p) + (m_w - m_p) * (m_w - m_p) * 96.0f) * (1.0f / H);
         const float rs = 1.0f / sqrtf(var + eps);
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
